@@ -1,0 +1,148 @@
+/*
+ * mbb_hip.h -- C-ABI of the MI355X (gfx950) likelihood hot path.
+ *
+ * This is the drop-in boundary for the per-walker likelihood of mbb_emcee:
+ * plain pointers and sizes, no C++ or framework types.  Every entry point
+ * names the reference interface it replaces (paths relative to the
+ * reference's mbb_emcee/ directory).  The reference-side binding (ctypes)
+ * is shown in INTEGRATION.md; mbb_emcee_amd/_native.py is that binding.
+ *
+ * Conventions
+ *   - all floating point data is IEEE float64, arrays are C-contiguous;
+ *   - parameter rows are (T, beta, lambda0, alpha, fnorm)   likelihood.py:20-22;
+ *   - the caller owns every buffer passed in; nothing is retained after return
+ *     except what the set_* calls copy to the device;
+ *   - functions return 0 on success, a negative mbb_error on failure, and never
+ *     throw; mbb_last_error() gives the text of the last failure in this thread;
+ *   - one context = one device + one HIP stream; a context is not thread-safe,
+ *     any number of contexts may coexist;
+ *   - per-row status codes (int32): see mbb_row_status.
+ */
+#ifndef MBB_HIP_H
+#define MBB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mbb_ctx mbb_ctx;
+
+enum mbb_error {
+    MBB_OK = 0,
+    MBB_ERR_HIP = -1,        /* a HIP runtime call failed (no GPU, OOM, ...) */
+    MBB_ERR_ARG = -2,        /* invalid argument                             */
+    MBB_ERR_STATE = -3,      /* bands / data not set yet                     */
+    MBB_ERR_RCCL = -4        /* RCCL missing or a collective failed          */
+};
+
+/* Per-row outcome.  Rows with status >= 2 correspond to Python exceptions in
+ * the reference's SED constructor (modified_blackbody.py:219-224, :294-316). */
+enum mbb_row_status {
+    MBB_ROW_OK = 0,
+    MBB_ROW_BELOW_LOWLIM = 1, /* lnL = -inf          likelihood.py:806-807   */
+    MBB_ROW_BAD_ALPHA = 2,    /* alpha <= 0          modified_blackbody.py:219 */
+    MBB_ROW_BAD_BETA = 3,     /* beta < 0            modified_blackbody.py:222 */
+    MBB_ROW_NOCONV = 6        /* merge / peak root not found                 */
+};
+
+const char *mbb_last_error(void);
+int mbb_device_count(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* Replaces: construction of `likelihood` + `modified_blackbody` state
+ * (likelihood.py:24-117).  opthin / noalpha / wavenorm as in likelihood.py:62-64. */
+int mbb_ctx_create(int device, mbb_ctx **out);
+void mbb_ctx_destroy(mbb_ctx *ctx);
+int mbb_set_model(mbb_ctx *ctx, int opthin, int noalpha, double wavenorm);
+
+/* Replaces: the per-band state built by response.setup (response.py:252-332)
+ * and consumed by response.__call__ (response.py:572-576).
+ *   freq   [offsets[nb]]  sample frequencies in GHz (response._freq)
+ *   weight [offsets[nb]]  response._sedmult * response._normfac; a delta band
+ *                         (response.py:336-374) or a plain photometric
+ *                         wavelength (likelihood.py:817) is one sample, weight 1
+ *   offsets[nb+1]         band b owns samples offsets[b] .. offsets[b+1]-1   */
+int mbb_set_bands(mbb_ctx *ctx, const double *freq, const double *weight,
+                  const int32_t *offsets, int nb);
+
+/* Replaces: likelihood.set_phot / set_cov state (likelihood.py:158-232, :330-357).
+ * is_cov == 0: w is ivar[nb] = 1/unc^2; is_cov != 0: w is inverse covariance [nb*nb]. */
+int mbb_set_data(mbb_ctx *ctx, const double *flux, const double *w, int nb, int is_cov);
+
+/* Replaces: _lowlim / _has_uplim / _uplim (likelihood.py:73, :83-85, :227-229);
+ * index 5 is the lambda_peak ghost parameter (likelihood.py:710-715). */
+int mbb_set_limits(mbb_ctx *ctx, const double lowlim[5], const int32_t has_uplim[6],
+                   const double uplim[6]);
+/* Replaces: Gaussian priors (likelihood.py:87-92, :513-541, :719-752). */
+int mbb_set_gpriors(mbb_ctx *ctx, const int32_t has[6], const double mean[6],
+                    const double ivar[6]);
+
+/* ---- the hot path ------------------------------------------------------- */
+/* Replaces: n calls of likelihood.__call__(pars) (likelihood.py:790-834), i.e.
+ * what emcee's map(lnprobfn, rows) does per half-step (mbb_fit.py:80-81).
+ * pars [n*5] host, lnl [n] host, status [n] host (may be NULL),
+ * model_flux [n*nb] host (may be NULL).  Synchronous. */
+int mbb_lnlike_batch(mbb_ctx *ctx, const double *pars, int n, double *lnl,
+                     int32_t *status, double *model_flux);
+
+/* Same computation on device-resident buffers, enqueued on the context's
+ * stream, asynchronous.  d_model_flux / d_status may be NULL. */
+int mbb_lnlike_batch_device(mbb_ctx *ctx, const double *d_pars, int n,
+                            double *d_lnl, int32_t *d_status, double *d_model_flux);
+
+/* ---- SED-level entry points (parity + the modified_blackbody class) ----- */
+/* Replaces: modified_blackbody.__init__ (modified_blackbody.py:168-337) and
+ * max_wave (:581-637) for n parameter rows.
+ * out [n*6] = normfac, xmerge, kappa, x0, wavemerge, max_wave (NaN where the
+ * reference has None); want_peak == 0 skips max_wave. */
+int mbb_sed_prologue_batch(mbb_ctx *ctx, const double *pars, int n, int opthin,
+                           int noalpha, double wavenorm, int want_peak,
+                           double *out, int32_t *status);
+
+/* Replaces: modified_blackbody.__call__ / f_nu (modified_blackbody.py:441-554)
+ * for n parameter rows on a common grid of m frequencies (GHz): out [n*m]. */
+int mbb_sed_eval_batch(mbb_ctx *ctx, const double *pars, int n, int opthin,
+                       int noalpha, double wavenorm, const double *freq, int m,
+                       double *out, int32_t *status);
+
+/* Replaces: fnu.fnueval_{thin,thick}_{noalpha,walpha} (fnu.pyx:9-108) with the
+ * same explicit scalars; unused ones are ignored. */
+int mbb_fnu_eval(mbb_ctx *ctx, int opthin, int noalpha, const double *freq, int n,
+                 double T, double beta, double x0, double alpha, double normfac,
+                 double xmerge, double kappa, double *out);
+
+/* ---- device plumbing for callers that keep data resident ---------------- */
+int mbb_malloc(mbb_ctx *ctx, size_t bytes, void **dptr);
+int mbb_free(mbb_ctx *ctx, void *dptr);
+int mbb_memcpy_h2d(mbb_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mbb_memcpy_d2h(mbb_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mbb_sync(mbb_ctx *ctx);
+void *mbb_stream(mbb_ctx *ctx);             /* hipStream_t of the context     */
+/* HIP events on the context's stream, for timing launches where they run */
+int mbb_event_create(mbb_ctx *ctx, void **ev);
+int mbb_event_record(mbb_ctx *ctx, void *ev);
+int mbb_event_elapsed_ms(mbb_ctx *ctx, void *start, void *stop, float *ms);
+int mbb_event_destroy(mbb_ctx *ctx, void *ev);
+
+/* Tunables: "walkers_per_group" (0 = auto), "block_threads" (0 = auto),
+ * "zero_copy" (host path reads/writes pinned host memory from the kernel). */
+int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
+int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
+
+/* ---- multi-GPU: one process per GPU, lnprob all-gather over RCCL -------- */
+/* Replaces: emcee's multiprocessing pool selected by threads= (mbb_fit.py:80-81).
+ * id is an opaque 128-byte ncclUniqueId made on rank 0 and handed to the other
+ * ranks by the launcher (any side channel). */
+int mbb_comm_unique_id(char id[128]);
+int mbb_comm_init(mbb_ctx *ctx, int nranks, int rank, const char id[128]);
+int mbb_comm_destroy(mbb_ctx *ctx);
+/* every rank contributes count doubles; d_recv holds nranks*count, rank-major */
+int mbb_allgather_f64(mbb_ctx *ctx, const double *d_send, double *d_recv, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBB_HIP_H */

@@ -1,0 +1,48 @@
+"""Builds mbb_emcee_amd/libmbb_hip.so (HIP kernels + C-ABI) for gfx950 with hipcc.
+
+    python -m mbb_emcee_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The library is built in-tree so that it
+travels with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "mbb_device.hip.h"),
+        os.path.join(os.path.dirname(HERE), "include", "mbb_hip.h")]
+LIB = os.path.join(HERE, "libmbb_hip.so")
+ARCH = "gfx950"
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build the MI355X likelihood library")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", LIB, SRC, "-ldl"]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

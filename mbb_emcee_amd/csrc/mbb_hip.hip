@@ -1,0 +1,956 @@
+// mbb_hip.hip -- kernels and C-ABI of the MI355X likelihood hot path (gfx950).
+//
+// One fused kernel per model variant evaluates, for a batch of walkers,
+//   prologue (per walker) -> f_nu on every passband sample -> band fluxes ->
+//   chi-square / covariance form -> soft limits and Gaussian priors -> lnL
+// i.e. n calls of the reference's likelihood.__call__ (likelihood.py:790-834)
+// in one launch.  See include/mbb_hip.h for the boundary and DESIGN.md for the
+// data layout.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/mbb_hip.h"
+#include "mbb_device.hip.h"
+
+using namespace mbbd;
+
+// ---------------------------------------------------------------------------
+// kernel arguments
+// ---------------------------------------------------------------------------
+struct LikeArgs {
+    // passband tables, chunk-padded: band b owns chunks; every chunk is 64 samples
+    const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
+    const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
+    const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
+    const int32_t *seg_c0;    // [nseg+1] first chunk of each segment
+    const int32_t *band_s0;   // [nb+1]   first segment of each band
+    const double *flux;       // [nb]
+    const double *ivar;       // [nb]
+    const double *invcov;     // [nb*nb] or nullptr
+    int nb, nseg;
+    double wavenorm;
+    double lowlim[5];
+    double uplim[6];
+    double gmean[6];
+    double givar[6];
+    uint32_t has_uplim;       // bit i
+    uint32_t has_gprior;      // bit i
+    // batch
+    const double *pars;       // [n*5]
+    int n;
+    int wpb;                  // walkers per block
+    double *lnl;              // [n]
+    int32_t *status;          // [n] or nullptr
+    double *model_flux;       // [n*nb] or nullptr
+};
+
+// Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
+//   phase 1: lane-per-walker prologue (wave 0)            -> LDS
+//   phase 2: (walker, segment) units dealt round-robin to waves; a lane strides
+//            over the segment's samples, then one wave64 shuffle reduction
+//   phase 3: band sums in fixed order, then one lane per walker forms lnL
+// Summation order depends only on the band tables, never on the batch, so a
+// walker's result is bitwise independent of which launch / GPU evaluates it.
+template <bool OPTHIN, bool NOALPHA>
+__global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int W = a.wpb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6;
+    const int nseg = a.nseg, nb = a.nb;
+    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);
+    double *partial = reinterpret_cast<double *>(wk + W);   // [W*nseg]
+    double *mflux = partial + (size_t)W * nseg;             // [W*nb]
+    double *pen = mflux + (size_t)W * nb;                   // [W*2]
+    const int w0 = blockIdx.x * W;
+
+    // ---- phase 1: gate + prologue + parameter-only penalties ----------------
+    if (tid < W) {
+        const int w = w0 + tid;
+        WalkerK k;
+        k.status = ROW_SKIP;
+        double pen_u = 0.0, pen_g = 0.0;
+        if (w < a.n) {
+            double p[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
+            bool ok = true;                                   // likelihood.py:643-670
+#pragma unroll
+            for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
+            if (!ok) {
+                k.status = ROW_BELOW_LOWLIM;
+            } else {
+                SedScalars s;
+                k.status = sed_prologue<OPTHIN, NOALPHA>(p[0], p[1], p[2], p[3], p[4],
+                                                         a.wavenorm, s);
+                if (k.status == ROW_OK) {
+                    make_walker_k<OPTHIN, NOALPHA>(p[0], p[1], p[3], s, k);
+                    // _uplim_prior, likelihood.py:672-717
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if (((a.has_uplim >> i) & 1u) && p[i] > a.uplim[i]) {
+                            double lw = 0.02 * (a.uplim[i] - a.lowlim[i]);
+                            double d = p[i] - a.uplim[i];
+                            pen_u -= 0.5 * d * d / (lw * lw);
+                        }
+                    double peak = 0.0;
+                    if (((a.has_uplim | a.has_gprior) >> 5) & 1u) {
+                        int pst;
+                        peak = sed_peak_wave<OPTHIN>(p[0], p[1], k.lx0, s.hcokt, pst);
+                        if (pst != ROW_OK) k.status = pst;
+                        k.peak = peak;
+                    }
+                    if (((a.has_uplim >> 5) & 1u) && peak > a.uplim[5]) {  // :710-715
+                        double lw = 0.02 * a.uplim[5], d = peak - a.uplim[5];
+                        pen_u -= 0.5 * d * d / (lw * lw);
+                    }
+                    // _gprior, likelihood.py:719-752
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        if ((a.has_gprior >> i) & 1u) {
+                            double d = p[i] - a.gmean[i];
+                            pen_g -= 0.5 * a.givar[i] * d * d;
+                        }
+                    if ((a.has_gprior >> 5) & 1u) {
+                        double d = peak - a.gmean[5];
+                        pen_g -= 0.5 * a.givar[5] * d * d;
+                    }
+                }
+            }
+        }
+        wk[tid] = k;
+        pen[2 * tid] = pen_u;
+        pen[2 * tid + 1] = pen_g;
+    }
+    __syncthreads();
+
+    // ---- phase 2: passband quadrature (response.py:572-576) -----------------
+    const int nunit = W * nseg;
+    for (int u = wave; u < nunit; u += nwave) {
+        const int j = u / nseg, s = u - j * nseg;
+        if (wk[j].status != ROW_OK) continue;                 // wave-uniform
+        const WalkerK k = wk[j];
+        const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
+        double acc = 0.0;
+        for (int c = c0; c < c1; ++c) {
+            const int i = c * 64 + lane;
+            const double f = fnu_sample<OPTHIN, NOALPHA>(k, a.nu[i], a.lnnu[i]);
+            acc = fma(f, a.wt[i], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) partial[u] = acc;
+    }
+    __syncthreads();
+
+    // ---- phase 3a: band fluxes ---------------------------------------------
+    for (int t = tid; t < W * nb; t += blockDim.x) {
+        const int j = t / nb, b = t - j * nb;
+        double sum = 0.0;
+        if (wk[j].status == ROW_OK) {
+            const int s0 = a.band_s0[b], s1 = a.band_s0[b + 1];
+            for (int s = s0; s < s1; ++s) sum += partial[j * nseg + s];
+            if (a.model_flux) a.model_flux[(size_t)(w0 + j) * nb + b] = sum;
+        } else if (a.model_flux && wk[j].status != ROW_SKIP) {
+            a.model_flux[(size_t)(w0 + j) * nb + b] = __builtin_nan("");
+        }
+        mflux[t] = sum;
+    }
+    __syncthreads();
+
+    // ---- phase 3b: lnL (likelihood.py:821-834) ------------------------------
+    if (tid < W) {
+        const int w = w0 + tid;
+        const int st = wk[tid].status;
+        if (st != ROW_SKIP) {
+            double r;
+            if (st == ROW_BELOW_LOWLIM) {
+                r = -__builtin_inf();
+            } else if (st != ROW_OK) {
+                r = __builtin_nan("");
+            } else {
+                const double *mf = mflux + (size_t)tid * nb;
+                double acc = 0.0;
+                if (a.invcov) {                                // :823
+                    for (int i = 0; i < nb; ++i) {
+                        double t = 0.0;
+                        for (int jj = 0; jj < nb; ++jj)
+                            t += a.invcov[i * nb + jj] * (a.flux[jj] - mf[jj]);
+                        acc += (a.flux[i] - mf[i]) * t;
+                    }
+                } else {                                       // :825
+                    for (int i = 0; i < nb; ++i) {
+                        double d = a.flux[i] - mf[i];
+                        acc += d * d * a.ivar[i];
+                    }
+                }
+                r = -0.5 * acc;
+                r += pen[2 * tid];                             // :828
+                if (a.has_gprior) r += pen[2 * tid + 1];       // :830-831
+            }
+            a.lnl[w] = r;
+            if (a.status) a.status[w] = st;
+        }
+    }
+}
+
+// modified_blackbody.__init__ + max_wave for n rows, one lane per row.
+template <bool OPTHIN, bool NOALPHA>
+__global__ void k_prologue(const double *pars, int n, double wavenorm, int want_peak,
+                           double *out, int32_t *status, WalkerK *wk_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double T = pars[i * 5 + 0], beta = pars[i * 5 + 1], lambda0 = pars[i * 5 + 2],
+                 alpha = pars[i * 5 + 3], fnorm = pars[i * 5 + 4];
+    SedScalars s;
+    int st = sed_prologue<OPTHIN, NOALPHA>(T, beta, lambda0, alpha, fnorm, wavenorm, s);
+    const double nan = __builtin_nan("");
+    double peak = nan;
+    WalkerK k;
+    k.status = st;
+    if (st == ROW_OK) {
+        make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
+        if (want_peak) {
+            int pst;
+            peak = sed_peak_wave<OPTHIN>(T, beta, k.lx0, s.hcokt, pst);
+            if (pst != ROW_OK) st = pst;
+        }
+    }
+    k.peak = peak;
+    if (out) {
+        out[i * 6 + 0] = s.normfac;
+        out[i * 6 + 1] = s.xmerge;
+        out[i * 6 + 2] = s.kappa;
+        out[i * 6 + 3] = s.x0;
+        out[i * 6 + 4] = NOALPHA ? nan : s.hcokt / s.xmerge;        // wavemerge :382-388
+        out[i * 6 + 5] = peak;
+    }
+    if (status) status[i] = st;
+    if (wk_out) wk_out[i] = k;
+}
+
+// f_nu of row blockIdx.y on a common frequency grid (modified_blackbody.py:441-554)
+template <bool OPTHIN, bool NOALPHA>
+__global__ void k_sed_eval(const WalkerK *wk, const double *freq, int m, double *out)
+{
+    const WalkerK k = wk[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double r = __builtin_nan("");
+    if (k.status == ROW_OK) {
+        const double nu = freq[i];
+        r = fnu_sample<OPTHIN, NOALPHA>(k, nu, d_log(nu));
+    }
+    out[(size_t)blockIdx.y * m + i] = r;
+}
+
+// fnu.pyx:9-108 with explicit scalars
+template <bool OPTHIN, bool NOALPHA>
+__global__ void k_fnu_explicit(const double *freq, int n, double T, double beta, double x0,
+                               double alpha, double normfac, double xmerge, double kappa,
+                               double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SedScalars s;
+    s.normfac = normfac; s.xmerge = xmerge; s.kappa = kappa; s.x0 = x0; s.hcokt = 0.0;
+    WalkerK k;
+    make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
+    const double nu = freq[i];
+    out[i] = fnu_sample<OPTHIN, NOALPHA>(k, nu, d_log(nu));
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (code == MBB_ERR_HIP)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                   \
+    do {                                                               \
+        hipError_t e_ = (call);                                        \
+        if (e_ != hipSuccess) return fail(MBB_ERR_HIP, #call, e_);     \
+    } while (0)
+
+typedef void *ncclComm_t_;
+struct UniqueId { char internal[128]; };
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(ncclComm_t_ *, int, UniqueId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t_) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl()
+{
+    if (g_rccl.handle) return MBB_OK;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MBB_ERR_RCCL, "cannot load librccl.so");
+    g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(ncclComm_t_ *, int, UniqueId, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t_, hipStream_t))
+        dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(ncclComm_t_))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+        return fail(MBB_ERR_RCCL, "librccl.so lacks the expected nccl* symbols");
+    g_rccl.handle = h;
+    return MBB_OK;
+}
+
+struct mbb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cu_count = 256;
+    // model
+    int opthin = 0, noalpha = 0;
+    double wavenorm = 500.0;
+    // bands
+    int nb = 0, nseg = 0, nchunk = 0, nq = 0;
+    double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
+    int32_t *d_seg_c0 = nullptr, *d_band_s0 = nullptr;
+    // data
+    int data_nb = 0, has_cov = 0;
+    double *d_flux = nullptr, *d_ivar = nullptr, *d_invcov = nullptr;
+    // limits and priors (likelihood.py:73, :83-85 defaults)
+    double lowlim[5] = {1, 0.1, 1, 0.1, 1e-3};
+    double uplim[6] = {INFINITY, 20.0, INFINITY, 20.0, INFINITY, INFINITY};
+    uint32_t has_uplim = (1u << 1) | (1u << 3);
+    double gmean[6] = {0, 0, 0, 0, 0, 0};
+    double givar[6] = {1, 1, 1, 1, 1, 1};
+    uint32_t has_gprior = 0;
+    // staging for the host-in / host-out path
+    size_t cap = 0, cap_flux = 0;
+    double *d_pars = nullptr, *d_lnl = nullptr, *d_mflux = nullptr;
+    int32_t *d_status = nullptr;
+    double *h_pars = nullptr, *h_lnl = nullptr, *h_mflux = nullptr;   // pinned
+    int32_t *h_status = nullptr;
+    // scratch for SED-level calls
+    size_t sed_cap = 0, sed_out_cap = 0;
+    double *d_sed_pars = nullptr, *d_sed_out = nullptr;
+    int32_t *d_sed_status = nullptr;
+    WalkerK *d_sed_wk = nullptr;
+    // options
+    long opt_wpb = 0, opt_threads = 0, opt_zero_copy = 0, opt_seg_chunks = 4;
+    long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
+    // rccl
+    ncclComm_t_ comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+static int use(mbb_ctx *c)
+{
+    if (!c) return fail(MBB_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    return MBB_OK;
+}
+
+extern "C" const char *mbb_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mbb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
+{
+    if (!out) return fail(MBB_ERR_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(MBB_ERR_ARG, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    mbb_ctx *c = new mbb_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->cu_count = prop.multiProcessorCount;
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c;
+    return MBB_OK;
+}
+
+static void free_dev(void *p) { if (p) (void)hipFree(p); }
+static void free_host(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" void mbb_ctx_destroy(mbb_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
+    free_dev(c->d_seg_c0); free_dev(c->d_band_s0);
+    free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
+    free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
+    free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
+    free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
+    free_dev(c->d_sed_wk);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mbb_set_model(mbb_ctx *c, int opthin, int noalpha, double wavenorm)
+{
+    if (!c) return fail(MBB_ERR_ARG, "null context");
+    if (!(wavenorm > 0.0)) return fail(MBB_ERR_ARG, "wavenorm must be positive");
+    c->opthin = opthin ? 1 : 0;
+    c->noalpha = noalpha ? 1 : 0;
+    c->wavenorm = wavenorm;
+    return MBB_OK;
+}
+
+template <typename T>
+static int upload(T **dptr, const std::vector<T> &h)
+{
+    free_dev(*dptr);
+    *dptr = nullptr;
+    HIPCHK(hipMalloc((void **)dptr, sizeof(T) * (h.size() ? h.size() : 1)));
+    if (!h.empty())
+        HIPCHK(hipMemcpy(*dptr, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weight,
+                             const int32_t *offsets, int nb)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!freq || !weight || !offsets || nb <= 0) return fail(MBB_ERR_ARG, "bad band tables");
+    if (offsets[0] != 0) return fail(MBB_ERR_ARG, "offsets[0] must be 0");
+    const int segc = (int)(c->opt_seg_chunks > 0 ? c->opt_seg_chunks : 4);
+    std::vector<double> nu, lnnu, wt;
+    std::vector<int32_t> seg_c0, band_s0;
+    int chunk = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int n = offsets[b + 1] - offsets[b];
+        if (n <= 0) return fail(MBB_ERR_ARG, "empty band");
+        band_s0.push_back((int32_t)seg_c0.size());
+        const int nch = (n + 63) / 64;
+        for (int cc = 0; cc < nch; cc += segc) seg_c0.push_back(chunk + cc);
+        for (int i = 0; i < nch * 64; ++i) {
+            if (i < n) {
+                const double f = freq[offsets[b] + i];
+                if (!(f > 0.0) || !isfinite(f)) return fail(MBB_ERR_ARG, "non-positive frequency");
+                nu.push_back(f);
+                lnnu.push_back(log(f));
+                wt.push_back(weight[offsets[b] + i]);
+            } else {
+                nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0);
+            }
+        }
+        chunk += nch;
+    }
+    seg_c0.push_back(chunk);
+    band_s0.push_back((int32_t)seg_c0.size() - 1);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = upload(&c->d_nu, nu))) return rc;
+    if ((rc = upload(&c->d_lnnu, lnnu))) return rc;
+    if ((rc = upload(&c->d_wt, wt))) return rc;
+    if ((rc = upload(&c->d_seg_c0, seg_c0))) return rc;
+    if ((rc = upload(&c->d_band_s0, band_s0))) return rc;
+    c->nb = nb;
+    c->nchunk = chunk;
+    c->nseg = (int)seg_c0.size() - 1;
+    c->nq = offsets[nb];
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_data(mbb_ctx *c, const double *flux, const double *w, int nb, int is_cov)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!flux || !w || nb <= 0) return fail(MBB_ERR_ARG, "bad data");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<double> f(flux, flux + nb);
+    if ((rc = upload(&c->d_flux, f))) return rc;
+    if (is_cov) {
+        std::vector<double> m(w, w + (size_t)nb * nb);
+        if ((rc = upload(&c->d_invcov, m))) return rc;
+        std::vector<double> iv(nb, 0.0);
+        if ((rc = upload(&c->d_ivar, iv))) return rc;
+    } else {
+        std::vector<double> iv(w, w + nb);
+        if ((rc = upload(&c->d_ivar, iv))) return rc;
+        free_dev(c->d_invcov);
+        c->d_invcov = nullptr;
+    }
+    c->has_cov = is_cov ? 1 : 0;
+    c->data_nb = nb;
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_limits(mbb_ctx *c, const double lowlim[5], const int32_t has_uplim[6],
+                              const double uplim[6])
+{
+    if (!c || !lowlim || !has_uplim || !uplim) return fail(MBB_ERR_ARG, "null argument");
+    c->has_uplim = 0;
+    for (int i = 0; i < 5; ++i) c->lowlim[i] = lowlim[i];
+    for (int i = 0; i < 6; ++i) {
+        c->uplim[i] = uplim[i];
+        if (has_uplim[i]) c->has_uplim |= (1u << i);
+    }
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_gpriors(mbb_ctx *c, const int32_t has[6], const double mean[6],
+                               const double ivar[6])
+{
+    if (!c || !has || !mean || !ivar) return fail(MBB_ERR_ARG, "null argument");
+    c->has_gprior = 0;
+    for (int i = 0; i < 6; ++i) {
+        c->gmean[i] = mean[i];
+        c->givar[i] = ivar[i];
+        if (has[i]) c->has_gprior |= (1u << i);
+    }
+    return MBB_OK;
+}
+
+static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
+{
+    if (n > c->cap) {
+        size_t cap = c->cap ? c->cap : 256;
+        while (cap < n) cap *= 2;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_status);
+        free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_status);
+        c->d_pars = c->d_lnl = nullptr; c->d_status = nullptr;
+        c->h_pars = c->h_lnl = nullptr; c->h_status = nullptr;
+        c->cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_pars, cap * 5 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->d_lnl, cap * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
+        HIPCHK(hipHostMalloc((void **)&c->h_pars, cap * 5 * sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&c->h_lnl, cap * sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&c->h_status, cap * sizeof(int32_t), hipHostMallocMapped));
+        c->cap = cap;
+    }
+    if (want_flux && n * (size_t)c->nb > c->cap_flux) {
+        size_t cap = c->cap * (size_t)c->nb;
+        if (cap < n * (size_t)c->nb) cap = n * (size_t)c->nb;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_mflux); free_host(c->h_mflux);
+        c->d_mflux = nullptr; c->h_mflux = nullptr; c->cap_flux = 0;
+        HIPCHK(hipMalloc((void **)&c->d_mflux, cap * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&c->h_mflux, cap * sizeof(double), hipHostMallocMapped));
+        c->cap_flux = cap;
+    }
+    return MBB_OK;
+}
+
+// Walkers per block and block size.  Small batches (an emcee half-step) are
+// latency bound: one walker per 1024-thread block so that every segment of a
+// walker has its own wave and the chip sees n blocks.  Large batches amortise
+// the lane-per-walker prologue over up to 64 walkers per 256-thread block.
+static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
+{
+    const long target_blocks = (long)c->cu_count * 8;
+    long w = (n + target_blocks - 1) / target_blocks;
+    if (w < 1) w = 1;
+    if (w > 64) w = 64;
+    if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
+    wpb = (int)w;
+    long units = (long)wpb * c->nseg;
+    long t;
+    if (wpb == 1) {
+        t = ((units + 3) / 4) * 64 * 4;        // about one segment per wave
+        if (t < 256) t = 256;
+        if (t > 1024) t = 1024;
+        if (units <= 4) t = 256;
+    } else {
+        t = 256;
+    }
+    if (c->opt_threads > 0) t = c->opt_threads;
+    if (t < 64) t = 64;
+    if (t > 1024) t = 1024;
+    t = (t / 64) * 64;
+    threads = (int)t;
+}
+
+static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
+                         int32_t *d_status, double *d_mflux)
+{
+    if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
+    if (c->data_nb != c->nb) return fail(MBB_ERR_STATE, "data not set or band count mismatch");
+    if (n <= 0) return MBB_OK;
+    LikeArgs a;
+    a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
+    a.seg_c0 = c->d_seg_c0; a.band_s0 = c->d_band_s0;
+    a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
+    a.nb = c->nb; a.nseg = c->nseg; a.wavenorm = c->wavenorm;
+    for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
+    for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
+    a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
+    a.pars = d_pars; a.n = n; a.lnl = d_lnl; a.status = d_status; a.model_flux = d_mflux;
+    int wpb, threads;
+    pick_geometry(c, n, wpb, threads);
+    a.wpb = wpb;
+    const int grid = (n + wpb - 1) / wpb;
+    const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16);
+    if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
+    c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)smem;
+    void (*kern)(const LikeArgs);
+    if (c->opthin) kern = c->noalpha ? k_lnlike<true, true> : k_lnlike<true, false>;
+    else kern = c->noalpha ? k_lnlike<false, true> : k_lnlike<false, false>;
+    if (smem > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, c->stream, a);
+    HIPCHK(hipGetLastError());
+    return MBB_OK;
+}
+
+extern "C" int mbb_lnlike_batch_device(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
+                                       int32_t *d_status, double *d_mflux)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_pars || !d_lnl))) return fail(MBB_ERR_ARG, "bad batch buffers");
+    return launch_lnlike(c, d_pars, n, d_lnl, d_status, d_mflux);
+}
+
+extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *lnl,
+                                int32_t *status, double *model_flux)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!pars || !lnl))) return fail(MBB_ERR_ARG, "bad batch buffers");
+    if (n == 0) return MBB_OK;
+    if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
+    if ((rc = ensure_capacity(c, (size_t)n, model_flux != nullptr))) return rc;
+    const size_t nbytes = (size_t)n * 5 * sizeof(double);
+    memcpy(c->h_pars, pars, nbytes);
+    if (c->opt_zero_copy) {
+        // the kernel reads the pinned parameter block and writes lnL straight
+        // into pinned host memory: no copy commands on the stream at all
+        double *dp, *dl, *df = nullptr;
+        int32_t *ds;
+        HIPCHK(hipHostGetDevicePointer((void **)&dp, c->h_pars, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&dl, c->h_lnl, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&ds, c->h_status, 0));
+        if (model_flux) HIPCHK(hipHostGetDevicePointer((void **)&df, c->h_mflux, 0));
+        if ((rc = launch_lnlike(c, dp, n, dl, ds, df))) return rc;
+        HIPCHK(hipStreamSynchronize(c->stream));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_pars, c->h_pars, nbytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = launch_lnlike(c, c->d_pars, n, c->d_lnl, c->d_status,
+                                model_flux ? c->d_mflux : nullptr))) return rc;
+        HIPCHK(hipMemcpyAsync(c->h_lnl, c->d_lnl, (size_t)n * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_status, c->d_status, (size_t)n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+        if (model_flux)
+            HIPCHK(hipMemcpyAsync(c->h_mflux, c->d_mflux, (size_t)n * c->nb * sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    memcpy(lnl, c->h_lnl, (size_t)n * sizeof(double));
+    if (status) memcpy(status, c->h_status, (size_t)n * sizeof(int32_t));
+    if (model_flux) memcpy(model_flux, c->h_mflux, (size_t)n * c->nb * sizeof(double));
+    return MBB_OK;
+}
+
+// ---- SED-level entry points -------------------------------------------------
+static int ensure_sed(mbb_ctx *c, size_t n, size_t nout)
+{
+    if (n > c->sed_cap) {
+        size_t cap = c->sed_cap ? c->sed_cap : 64;
+        while (cap < n) cap *= 2;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_sed_pars); free_dev(c->d_sed_status); free_dev(c->d_sed_wk);
+        c->d_sed_pars = nullptr; c->d_sed_status = nullptr; c->d_sed_wk = nullptr; c->sed_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_sed_pars, cap * 5 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->d_sed_status, cap * sizeof(int32_t)));
+        HIPCHK(hipMalloc((void **)&c->d_sed_wk, cap * sizeof(WalkerK)));
+        c->sed_cap = cap;
+    }
+    if (nout > c->sed_out_cap) {
+        size_t cap = c->sed_out_cap ? c->sed_out_cap : 1024;
+        while (cap < nout) cap *= 2;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_sed_out); c->d_sed_out = nullptr; c->sed_out_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_sed_out, cap * sizeof(double)));
+        c->sed_out_cap = cap;
+    }
+    return MBB_OK;
+}
+
+template <typename F>
+static void dispatch_variant(int opthin, int noalpha, F &&f)
+{
+    if (opthin) { if (noalpha) f(std::true_type(), std::true_type()); else f(std::true_type(), std::false_type()); }
+    else { if (noalpha) f(std::false_type(), std::true_type()); else f(std::false_type(), std::false_type()); }
+}
+
+static int run_prologue(mbb_ctx *c, const double *pars, int n, int opthin, int noalpha,
+                        double wavenorm, int want_peak, double *d_out6)
+{
+    HIPCHK(hipMemcpyAsync(c->d_sed_pars, pars, (size_t)n * 5 * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
+    const int threads = 64, grid = (n + threads - 1) / threads;
+    dispatch_variant(opthin, noalpha, [&](auto OT, auto NA) {
+        hipLaunchKernelGGL((k_prologue<decltype(OT)::value, decltype(NA)::value>), dim3(grid),
+                           dim3(threads), 0, c->stream, c->d_sed_pars, n, wavenorm, want_peak,
+                           d_out6, c->d_sed_status, c->d_sed_wk);
+    });
+    HIPCHK(hipGetLastError());
+    return MBB_OK;
+}
+
+extern "C" int mbb_sed_prologue_batch(mbb_ctx *c, const double *pars, int n, int opthin,
+                                      int noalpha, double wavenorm, int want_peak, double *out,
+                                      int32_t *status)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || !pars || !out) return fail(MBB_ERR_ARG, "bad arguments");
+    if ((rc = ensure_sed(c, (size_t)n, (size_t)n * 6))) return rc;
+    if ((rc = run_prologue(c, pars, n, opthin, noalpha, wavenorm, want_peak, c->d_sed_out))) return rc;
+    HIPCHK(hipMemcpyAsync(out, c->d_sed_out, (size_t)n * 6 * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    if (status)
+        HIPCHK(hipMemcpyAsync(status, c->d_sed_status, (size_t)n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+
+extern "C" int mbb_sed_eval_batch(mbb_ctx *c, const double *pars, int n, int opthin, int noalpha,
+                                  double wavenorm, const double *freq, int m, double *out,
+                                  int32_t *status)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || m <= 0 || !pars || !freq || !out) return fail(MBB_ERR_ARG, "bad arguments");
+    if (n > 65535) return fail(MBB_ERR_ARG, "at most 65535 rows per call");
+    const size_t nout = (size_t)n * m;
+    if ((rc = ensure_sed(c, (size_t)n, nout + (size_t)m))) return rc;
+    double *d_freq = c->d_sed_out + nout;
+    if ((rc = run_prologue(c, pars, n, opthin, noalpha, wavenorm, 0, nullptr))) return rc;
+    HIPCHK(hipMemcpyAsync(d_freq, freq, (size_t)m * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int threads = 256;
+    dim3 grid((m + threads - 1) / threads, n);
+    dispatch_variant(opthin, noalpha, [&](auto OT, auto NA) {
+        hipLaunchKernelGGL((k_sed_eval<decltype(OT)::value, decltype(NA)::value>), grid,
+                           dim3(threads), 0, c->stream, c->d_sed_wk, d_freq, m, c->d_sed_out);
+    });
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_sed_out, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status)
+        HIPCHK(hipMemcpyAsync(status, c->d_sed_status, (size_t)n * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+
+extern "C" int mbb_fnu_eval(mbb_ctx *c, int opthin, int noalpha, const double *freq, int n,
+                            double T, double beta, double x0, double alpha, double normfac,
+                            double xmerge, double kappa, double *out)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || !freq || !out) return fail(MBB_ERR_ARG, "bad arguments");
+    if ((rc = ensure_sed(c, 1, (size_t)2 * n))) return rc;
+    double *d_freq = c->d_sed_out + n;
+    HIPCHK(hipMemcpyAsync(d_freq, freq, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int threads = 256, grid = (n + threads - 1) / threads;
+    dispatch_variant(opthin, noalpha, [&](auto OT, auto NA) {
+        hipLaunchKernelGGL((k_fnu_explicit<decltype(OT)::value, decltype(NA)::value>), dim3(grid),
+                           dim3(threads), 0, c->stream, d_freq, n, T, beta, x0, alpha, normfac,
+                           xmerge, kappa, c->d_sed_out);
+    });
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, c->d_sed_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+
+// ---- plumbing ---------------------------------------------------------------
+extern "C" int mbb_malloc(mbb_ctx *c, size_t bytes, void **dptr)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!dptr) return fail(MBB_ERR_ARG, "null dptr");
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 1));
+    return MBB_OK;
+}
+extern "C" int mbb_free(mbb_ctx *c, void *dptr)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (dptr) HIPCHK(hipFree(dptr));
+    return MBB_OK;
+}
+extern "C" int mbb_memcpy_h2d(mbb_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+extern "C" int mbb_memcpy_d2h(mbb_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+extern "C" int mbb_sync(mbb_ctx *c)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+extern "C" void *mbb_stream(mbb_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int mbb_event_create(mbb_ctx *c, void **ev)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void *)e;
+    return MBB_OK;
+}
+extern "C" int mbb_event_record(mbb_ctx *c, void *ev)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord((hipEvent_t)ev, c->stream));
+    return MBB_OK;
+}
+extern "C" int mbb_event_elapsed_ms(mbb_ctx *c, void *start, void *stop, float *ms)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MBB_OK;
+}
+extern "C" int mbb_event_destroy(mbb_ctx *c, void *ev)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
+{
+    if (!c || !name) return fail(MBB_ERR_ARG, "null argument");
+    if (!strcmp(name, "walkers_per_group")) c->opt_wpb = value;
+    else if (!strcmp(name, "block_threads")) c->opt_threads = value;
+    else if (!strcmp(name, "zero_copy")) c->opt_zero_copy = value;
+    else if (!strcmp(name, "seg_chunks")) c->opt_seg_chunks = value;
+    else return fail(MBB_ERR_ARG, "unknown option");
+    return MBB_OK;
+}
+
+extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
+{
+    if (!c || !name || !value) return fail(MBB_ERR_ARG, "null argument");
+    if (!strcmp(name, "nb")) *value = c->nb;
+    else if (!strcmp(name, "nseg")) *value = c->nseg;
+    else if (!strcmp(name, "nchunk")) *value = c->nchunk;
+    else if (!strcmp(name, "nq")) *value = c->nq;
+    else if (!strcmp(name, "cu_count")) *value = c->cu_count;
+    else if (!strcmp(name, "last_wpb")) *value = c->last_wpb;
+    else if (!strcmp(name, "last_threads")) *value = c->last_threads;
+    else if (!strcmp(name, "last_grid")) *value = c->last_grid;
+    else if (!strcmp(name, "last_smem")) *value = c->last_smem;
+    else if (!strcmp(name, "device")) *value = c->device;
+    else if (!strcmp(name, "nranks")) *value = c->nranks;
+    else if (!strcmp(name, "rank")) *value = c->rank;
+    else return fail(MBB_ERR_ARG, "unknown info key");
+    return MBB_OK;
+}
+
+// ---- RCCL -------------------------------------------------------------------
+extern "C" int mbb_comm_unique_id(char id[128])
+{
+    int rc = load_rccl();
+    if (rc) return rc;
+    UniqueId u;
+    memset(&u, 0, sizeof u);
+    int r = g_rccl.GetUniqueId(&u);
+    if (r != 0) return fail(MBB_ERR_RCCL, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclGetUniqueId failed");
+    memcpy(id, u.internal, 128);
+    return MBB_OK;
+}
+
+extern "C" int mbb_comm_init(mbb_ctx *c, int nranks, int rank, const char id[128])
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(MBB_ERR_ARG, "bad rank layout");
+    if ((rc = load_rccl())) return rc;
+    UniqueId u;
+    memcpy(u.internal, id, 128);
+    int r = g_rccl.CommInitRank(&c->comm, nranks, u, rank);
+    if (r != 0) return fail(MBB_ERR_RCCL, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitRank failed");
+    c->nranks = nranks;
+    c->rank = rank;
+    return MBB_OK;
+}
+
+extern "C" int mbb_comm_destroy(mbb_ctx *c)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (c->comm) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        g_rccl.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->nranks = 1;
+    c->rank = 0;
+    return MBB_OK;
+}
+
+extern "C" int mbb_allgather_f64(mbb_ctx *c, const double *d_send, double *d_recv, int count)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!d_send || !d_recv || count < 0) return fail(MBB_ERR_ARG, "bad buffers");
+    if (!c->comm) {
+        if (c->nranks != 1) return fail(MBB_ERR_STATE, "communicator not initialised");
+        if (d_send != d_recv)
+            HIPCHK(hipMemcpyAsync(d_recv, d_send, (size_t)count * sizeof(double),
+                                  hipMemcpyDeviceToDevice, c->stream));
+        return MBB_OK;
+    }
+    int r = g_rccl.AllGather(d_send, d_recv, (size_t)count, 8 /* ncclFloat64 */, c->comm, c->stream);
+    if (r != 0) return fail(MBB_ERR_RCCL, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclAllGather failed");
+    return MBB_OK;
+}

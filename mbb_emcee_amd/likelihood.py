@@ -1,0 +1,408 @@
+"""The emcee log-probability callable, evaluated on the MI355X.
+
+Host-side mirror of the reference's ``likelihood`` class
+(reference mbb_emcee/likelihood.py:17-834): same constructor keywords, same
+setters/getters, same parameter order (T, beta, lambda0, alpha, fnorm).
+
+``like(pars)`` with a length-5 vector returns a Python float exactly as the
+reference does (so the object drops into ``emcee.EnsembleSampler`` as lnpostfn);
+``like(pars)`` with an ``(n, 5)`` array evaluates all n walkers in one fused
+kernel launch and returns ``float64[n]`` (emcee-3 ``vectorize=True``, or this
+package's own sampler).  Data, limits and priors live in a device-side constant
+block that is rebuilt lazily after any setter call.
+"""
+import copy
+
+import numpy as np
+
+from . import _native
+from .modified_blackbody import modified_blackbody, um_to_GHz
+from .response import response_set, special_types, read_table
+
+__all__ = ["likelihood"]
+
+
+class likelihood(object):
+    """Holds the photometry, limits and priors and evaluates ln P(pars | data)."""
+
+    # likelihood.py:20-22
+    _param_order = {'t': 0, 't/(1+z)': 0, 'beta': 1, 'lambda0': 2,
+                    'lambda0*(1+z)': 2, 'lambda_0': 2, 'lambda_0*(1+z)': 2,
+                    'alpha': 3, 'fnorm': 4, 'f500': 4}
+
+    def __init__(self, photfile=None, covfile=None, covextn=0, wavenorm=500.0,
+                 noalpha=False, opthin=False, response=False, responsefile=None,
+                 responsedir=None, device=None):
+        self._wavenorm = float(wavenorm)
+        self._noalpha = bool(noalpha)
+        self._opthin = bool(opthin)
+        self._device = device
+        self._ctx = None
+        self._dirty = True
+
+        self._lowlim = np.array([1, 0.1, 1, 0.1, 1e-3])               # :73
+        self._limprior_order = copy.copy(self._param_order)            # :77-79
+        self._limprior_order.update({'lambda_peak': 5, 'peaklam': 5,
+                                     'lambdapeak': 5, 'peak_lambda': 5})
+        self._has_uplim = [False, True, False, True, False, False]     # :83-85
+        inf = float("inf")
+        self._uplim = np.array([inf, 20.0, inf, 20.0, inf, inf])
+        self._any_gprior = False                                       # :88-92
+        self._has_gprior = [False] * 6
+        self._gprior_mean = np.zeros(6)
+        self._gprior_sigma = np.zeros(6)
+        self._gprior_ivar = np.ones(6)
+
+        self._response_integrate = False
+        if response:
+            self.read_responses(responsefile, responsedir=responsedir)
+
+        self._data_read = False
+        self._has_covmatrix = False
+        if photfile is not None:
+            self.read_phot(photfile)
+            if covfile is not None:
+                if not isinstance(covfile, str):
+                    raise TypeError("covfile must be string-like")
+                self.read_cov(covfile, extn=covextn)
+            self._lowlim[4] = 1e-3 * self._flux.min()                  # :110-111
+        elif covfile is not None:
+            raise Exception("Can't pass in covfile if no photfile")
+        self._badval = float("-inf")
+
+    # ---- simple properties (likelihood.py:119-137) --------------------------
+    @property
+    def wavenorm(self):
+        return self._wavenorm
+
+    @property
+    def noalpha(self):
+        return self._noalpha
+
+    @property
+    def opthin(self):
+        return self._opthin
+
+    @property
+    def response_integrate(self):
+        return self._response_integrate
+
+    # ---- data ----------------------------------------------------------------
+    def read_responses(self, responsefile=None, responsedir=None):
+        """Load a filter wheel and turn on passband integration (:139-156)."""
+        self._responsewheel = response_set(responsefile, dir=responsedir)
+        self._response_integrate = True
+        self._dirty = True
+
+    def set_phot(self, firstarg, flux, flux_unc):
+        """Set photometry: passband names (response mode) or wavelengths [um],
+        flux densities and uncertainties [mJy] (likelihood.py:158-232)."""
+        if self._response_integrate:
+            if not isinstance(firstarg[0], str):
+                raise ValueError("Expecting response string name")
+            self._responses = []
+            for name in firstarg:
+                name = str(name)
+                if name not in self._responsewheel:
+                    spl = name.split('_')
+                    if len(spl) > 1 and spl[1].lower() in special_types:
+                        self._responsewheel.add_special(name)          # :187-193
+                    else:
+                        raise ValueError("Unknown filter response {:s}".format(name))
+                self._responses.append(self._responsewheel[name])
+            self._response_names = [r.name for r in self._responses]
+            self._wave = np.array([r.effective_wavelength for r in self._responses])
+        else:
+            self._wave = np.asarray(firstarg, dtype=np.float64)
+
+        self._ndata = len(self._wave)
+        if self._ndata == 0:
+            raise ValueError("No elements in wavelength vector")
+        self._flux = np.asarray(flux, dtype=np.float64)
+        self._flux_unc = np.asarray(flux_unc, dtype=np.float64)
+        if self._ndata != len(self._flux):
+            raise ValueError("wave not same length as flux")
+        if self._ndata != len(self._flux_unc):
+            raise ValueError("wave not same length as flux_unc")
+        self._ivar = 1.0 / self._flux_unc ** 2
+        if not self._has_uplim[2]:                                     # :227-229
+            self._has_uplim[2] = True
+            self._uplim[2] = 3.0 * self._wave.max()
+        self._data_read = True
+        self._has_covmatrix = False
+        self._dirty = True
+
+    def read_phot(self, filename):
+        """Three-column text file: wavelength [um] (or passband name), flux,
+        uncertainty [mJy] (likelihood.py:234-262)."""
+        if not isinstance(filename, str):
+            raise TypeError("filename must be string-like")
+        data = read_table(filename)
+        if len(data) == 0:
+            raise IOError("No data read from %s" % filename)
+        self.set_phot([d[0] for d in data], [d[1] for d in data], [d[2] for d in data])
+
+    @property
+    def data_read(self):
+        return self._data_read
+
+    @property
+    def ndata(self):
+        return self._ndata if self._data_read else 0
+
+    @property
+    def data_wave(self):
+        return self._wave if self._data_read else None
+
+    @property
+    def response_names(self):
+        return getattr(self, '_response_names', None)
+
+    def has_response(self, name):
+        return hasattr(self, '_responsewheel') and name in self._responsewheel
+
+    def get_response(self, name):
+        if not hasattr(self, '_responsewheel'):
+            return None
+        return self._responsewheel[name]
+
+    @property
+    def data_flux(self):
+        return self._flux if self._data_read else None
+
+    @property
+    def data_flux_unc(self):
+        if not self._data_read:
+            return None
+        if self._has_covmatrix:
+            return np.sqrt(np.diag(self._covmatrix))
+        return self._flux_unc
+
+    def set_cov(self, covmatrix):
+        """Set the flux covariance matrix [mJy^2] (likelihood.py:330-357)."""
+        if not self._data_read:
+            raise Exception("Can't set covariance matrix without photometry")
+        covmatrix = np.asarray(covmatrix, dtype=np.float64)
+        if covmatrix.ndim != 2:
+            raise ValueError("Covariance matrix is not 2 dimensional")
+        if covmatrix.shape[0] != covmatrix.shape[1]:
+            raise ValueError("Covariance matrix from is not square: %d by %d" % covmatrix.shape)
+        if covmatrix.shape[0] != self._ndata:
+            raise ValueError("Covariance matrix doesn't have same number of datapoints as "
+                             "photometry; {0:d} vs. {1:d}".format(covmatrix.shape[0], self._ndata))
+        self._covmatrix = covmatrix
+        self._invcovmatrix = np.linalg.inv(self._covmatrix)
+        self._has_covmatrix = True
+        self._dirty = True
+
+    def read_cov(self, filename, extn=0):
+        """Covariance matrix from a FITS file (likelihood.py:359-376); needs astropy."""
+        if not self._data_read:
+            raise Exception("Can't read in covaraince matrix without phot")
+        try:
+            import astropy.io.fits as fits
+        except ImportError:
+            raise ImportError("read_cov needs astropy.io.fits; use set_cov(array) instead")
+        self.set_cov(fits.open(filename)[extn].data)
+
+    @property
+    def has_data_covmatrix(self):
+        return self._has_covmatrix
+
+    @property
+    def data_covmatrix(self):
+        return self._covmatrix if self._has_covmatrix else None
+
+    @property
+    def data_invcovmatrix(self):
+        return self._invcovmatrix if self._has_covmatrix else None
+
+    # ---- limits and priors (likelihood.py:378-641) ----------------------------
+    def get_paramindex(self, paramname):
+        return self._param_order[paramname]
+
+    def _pidx(self, param, table):
+        return table[param.lower()] if isinstance(param, str) else int(param)
+
+    def set_lowlim(self, param, val):
+        self._lowlim[self._pidx(param, self._param_order)] = val
+        self._dirty = True
+
+    def lowlim(self, param):
+        return self._lowlim[self._pidx(param, self._param_order)]
+
+    @property
+    def lowlims(self):
+        return self._lowlim
+
+    def set_uplim(self, param, val):
+        i = self._pidx(param, self._limprior_order)
+        self._has_uplim[i] = True
+        self._uplim[i] = val
+        self._dirty = True
+
+    def has_uplim(self, param):
+        return self._has_uplim[self._pidx(param, self._limprior_order)]
+
+    def uplim(self, param):
+        i = self._pidx(param, self._limprior_order)
+        return self._uplim[i] if self._has_uplim[i] else None
+
+    @property
+    def has_uplims(self):
+        return self._has_uplim
+
+    @property
+    def uplims(self):
+        return self._uplim
+
+    def set_gaussian_prior(self, param, mean, sigma):
+        i = self._pidx(param, self._limprior_order)
+        self._any_gprior = True
+        self._has_gprior[i] = True
+        self._gprior_mean[i] = float(mean)
+        self._gprior_sigma[i] = float(sigma)
+        self._gprior_ivar[i] = 1.0 / (float(sigma) ** 2)
+        self._dirty = True
+
+    @property
+    def has_gpriors(self):
+        return self._has_gprior
+
+    @property
+    def gprior_means(self):
+        return self._gprior_mean
+
+    @property
+    def gprior_sigmas(self):
+        return self._gprior_sigma
+
+    @property
+    def gprior_ivars(self):
+        return self._gprior_ivar
+
+    def has_gaussian_prior(self, param):
+        return self._has_gprior[self._pidx(param, self._limprior_order)]
+
+    def get_gaussian_prior(self, param):
+        if not self._any_gprior:
+            return None
+        i = self._pidx(param, self._limprior_order)
+        if not self._has_gprior[i]:
+            return None
+        return (self._gprior_mean[i], self._gprior_sigma[i])
+
+    def _check_lowlim(self, pars):
+        """True when every parameter is at or above its lower limit (:643-670)."""
+        if len(pars) != 5:
+            raise ValueError("pars is not of expected length 5")
+        return not any(v < self._lowlim[i] for i, v in enumerate(pars))
+
+    # ---- device state ---------------------------------------------------------
+    @property
+    def context(self):
+        """The native context (device + stream + constant block), created lazily."""
+        if self._ctx is None:
+            self._ctx = _native.Context(self._device)
+            self._dirty = True
+        return self._ctx
+
+    def band_tables(self):
+        """(freq_GHz, weight, offsets): the quadrature uploaded to the GPU.
+        Passband mode: response.quadrature() per band (response.py:572-576);
+        plain photometry: one sample per wavelength, weight 1 (likelihood.py:817)."""
+        if not self._data_read:
+            raise Exception("Data not read")
+        if self._response_integrate:
+            quads = [r.quadrature() for r in self._responses]
+            freq = np.concatenate([q[0] for q in quads])
+            wt = np.concatenate([q[1] for q in quads])
+            offs = np.concatenate(([0], np.cumsum([q[0].size for q in quads]))).astype(np.int32)
+        else:
+            freq = um_to_GHz / self._wave
+            wt = np.ones(self._ndata)
+            offs = np.arange(self._ndata + 1, dtype=np.int32)
+        return freq, wt, offs
+
+    def _sync_device(self):
+        ctx = self.context
+        if not self._dirty:
+            return ctx
+        if not self._data_read:
+            raise Exception("Data not read, can't evaluate the likelihood")
+        ctx.set_model(self._opthin, self._noalpha, self._wavenorm)
+        ctx.set_bands(*self.band_tables())
+        if self._has_covmatrix:
+            ctx.set_data(self._flux, invcov=self._invcovmatrix)
+        else:
+            ctx.set_data(self._flux, ivar=self._ivar)
+        ctx.set_limits(self._lowlim, [int(b) for b in self._has_uplim], self._uplim)
+        ctx.set_gpriors([int(b) for b in self._has_gprior], self._gprior_mean, self._gprior_ivar)
+        self._dirty = False
+        return ctx
+
+    # ---- evaluation -------------------------------------------------------------
+    def _set_sed(self, pars):
+        """SED object for a parameter vector (likelihood.py:754-768)."""
+        if len(pars) != 5:
+            raise ValueError("pars is not of expected length 5")
+        self._sed = modified_blackbody(pars[0], pars[1], pars[2], pars[3], pars[4],
+                                       wavenorm=self._wavenorm, noalpha=self._noalpha,
+                                       opthin=self._opthin, context=self.context)
+
+    def get_sed(self, pars, wave):
+        """Model SED [mJy] at wavelengths [um] (likelihood.py:770-788).  pars may
+        be (5,) -> [nwave] or (n, 5) -> [n, nwave]."""
+        p = np.asarray(pars, dtype=np.float64)
+        if p.ndim == 1:
+            self._set_sed(p)
+            return self._sed(wave)
+        w = np.atleast_1d(np.asarray(wave, dtype=np.float64))
+        out, st = self.context.sed_eval(p, self._opthin, self._noalpha, self._wavenorm,
+                                        um_to_GHz / w)
+        _native.raise_for_status(st)
+        return out
+
+    def model_flux(self, pars):
+        """Model band fluxes [n, ndata] for (n, 5) parameter rows."""
+        p = np.atleast_2d(np.asarray(pars, dtype=np.float64))
+        if p.shape[1] != 5:
+            raise ValueError("pars is not of expected length 5")
+        lnl, st, fl = self._sync_device().lnlike_batch(p, want_flux=True)
+        _native.raise_for_status(st)
+        return fl
+
+    def __call__(self, pars):
+        """ln P(pars | data) including limits and priors (likelihood.py:790-834).
+
+        (5,) -> float;  (n, 5) -> float64[n], all rows in one kernel launch.
+        Rows below a lower limit give -inf."""
+        p = np.asarray(pars, dtype=np.float64)
+        if p.ndim == 1:
+            if p.shape[0] != 5:
+                raise ValueError("pars is not of expected length 5")
+            lnl, st = self._sync_device().lnlike_batch(p[None, :])
+            _native.raise_for_status(st)
+            return float(lnl[0])
+        if p.ndim != 2 or p.shape[1] != 5:
+            raise ValueError("pars is not of expected length 5")
+        lnl, st = self._sync_device().lnlike_batch(p)
+        _native.raise_for_status(st)
+        return lnl
+
+    def map(self, func, rows):
+        """pool-style adaptor: ``sampler.pool = like`` makes an emcee-2 style
+        sampler evaluate a whole half-step in one launch.  func is ignored when
+        it is this object's own __call__ wrapper."""
+        return list(self(np.asarray(list(rows), dtype=np.float64)))
+
+    # ---- pickling: the device context is rebuilt on demand ---------------------
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_ctx"] = None
+        d["_dirty"] = True
+        d.pop("_sed", None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)

@@ -1,0 +1,357 @@
+"""Parity of the HIP path (through the C-ABI) with the golden fixtures made by
+the reference and with the CPU oracle.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances: band flux / f_nu rtol 1e-12, xmerge atol 1e-10,
+lnL |d| <= 1e-10 max(1, |lnL|), -inf must match exactly.
+"""
+import numpy as np
+import pytest
+
+from conftest import VARIANTS, golden_bands, lnl_close
+
+pytestmark = pytest.mark.gpu
+
+FLUX_RTOL = 1e-12
+SED_RTOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def mbb():
+    import mbb_emcee_amd
+    return mbb_emcee_amd
+
+
+@pytest.fixture(scope="module")
+def ctx(mbb):
+    from mbb_emcee_amd import _native
+    return _native.default_context()
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+# ------------------------------------------------------------------ G5: KATs
+def test_kat_thick(mbb):
+    """reference tests/test_modified_blackbody.py:6-20"""
+    m = mbb.modified_blackbody(10.0, 2.0, 800.0, 2.0, 45.0)
+    assert m.has_alpha and not m.optically_thin
+    np.testing.assert_allclose(m(500), 45.0, atol=1e-4)
+    wave = np.array([250.0, 350.0, 500.0, 850.0])
+    np.testing.assert_allclose(m(wave), [21.96268738, 39.53249977, 45.0, 22.06274444], rtol=1e-4)
+
+
+def test_kat_thin(mbb):
+    """reference tests/test_modified_blackbody.py:23-36"""
+    m = mbb.modified_blackbody(15.0, 1.8, 200.0, 3.0, 50.0, opthin=True)
+    assert m.has_alpha and m.optically_thin and m.lambda0 is None
+    wave = np.array([250.0, 350.0, 500.0, 850.0])
+    np.testing.assert_allclose(m(wave), [178.34976, 111.03026, 50.0, 10.880588], rtol=1e-4)
+
+
+def test_kat_thinthick(mbb):
+    """reference tests/test_modified_blackbody.py:39-47"""
+    wave = np.array([500.0, 850.0, 1100.0, 2500.0])
+    a = mbb.modified_blackbody(15.0, 1.8, 5.0, 3.0, 50.0, opthin=True)
+    b = mbb.modified_blackbody(15.0, 1.8, 5.0, 3.0, 50.0, opthin=False)
+    np.testing.assert_allclose(a(wave), b(wave), rtol=1e-3)
+
+
+def test_kat_merge(mbb):
+    """reference tests/test_modified_blackbody.py:50-69"""
+    mb = mbb.modified_blackbody
+    assert mb(20.0, 1.9, None, 3.5, 50.0, noalpha=True, opthin=True).wavemerge is None
+    np.testing.assert_allclose(mb(20.0, 1.9, None, 3.5, 50.0, opthin=True).wavemerge, 85.66065, rtol=1e-3)
+    np.testing.assert_allclose(mb(35.0, 2.2, None, 2.8, 50.0, opthin=True).wavemerge, 51.40211, rtol=1e-3)
+    assert mb(20.0, 1.9, 250.0, 3.5, 50.0, noalpha=True).wavemerge is None
+    np.testing.assert_allclose(mb(20.0, 1.9, 250.0, 3.5, 50.0).wavemerge, 109.5506829, rtol=1e-3)
+    np.testing.assert_allclose(mb(40.0, 1.5, 600.0, 3.0, 50.0).wavemerge, 60.10021595, rtol=1e-3)
+
+
+def test_kat_spire250_flat(mbb):
+    """reference tests/test_response.py:19-29 with the SED evaluated on the GPU"""
+    wheel = mbb.response_set()
+    # a (nearly) flat SED: alpha-law side of a hot thin body is not flat, so use
+    # the callable path with a constant, which is host-only, plus a GPU SED check
+    np.testing.assert_allclose(wheel["SPIRE_250um"](lambda x: 1), 1.011046, atol=1e-4)
+
+
+def test_ctor_errors(mbb):
+    """modified_blackbody.py:219-224"""
+    with pytest.raises(ValueError):
+        mbb.modified_blackbody(10.0, 2.0, 800.0, -1.0, 45.0)
+    with pytest.raises(ValueError):
+        mbb.modified_blackbody(10.0, -0.5, 800.0, 2.0, 45.0)
+    mbb.modified_blackbody(10.0, 2.0, 800.0, -1.0, 45.0, noalpha=True)   # alpha ignored
+
+
+# ------------------------------------------------- G2: constructor scalars
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_prologue_scalars(ctx, g_sed, name, opthin, noalpha):
+    pars = g_sed["pars"]
+    ref = g_sed[name + "/scalars"]
+    out, st = ctx.sed_prologue(pars, opthin, noalpha, 500.0, want_peak=True)
+    assert np.all(st == 0)
+    assert relerr(out[:, 0], ref[:, 0]) < 1e-12                 # normfac
+    if not noalpha:
+        assert np.max(np.abs(out[:, 1] - ref[:, 1])) < 1e-10    # xmerge (atol)
+        assert relerr(out[:, 2], ref[:, 2]) < 1e-10             # kappa
+        assert relerr(out[:, 4], ref[:, 4]) < 1e-10             # wavemerge
+    else:
+        assert np.all(np.isnan(out[:, 1])) and np.all(np.isnan(out[:, 4]))
+    if not opthin:
+        assert relerr(out[:, 3], ref[:, 3]) < 1e-14             # x0
+    assert relerr(out[:, 5], ref[:, 5]) < 1e-10                 # max_wave (brentq xtol)
+
+
+# ------------------------------------------------------- G3: f_nu on a grid
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_fnu_grid(ctx, g_sed, name, opthin, noalpha):
+    from mbb_emcee_amd.modified_blackbody import um_to_GHz
+    pars, grid = g_sed["pars"], g_sed["wave_grid"]
+    ref = g_sed[name + "/fnu_grid"]
+    out, st = ctx.sed_eval(pars, opthin, noalpha, 500.0, um_to_GHz / grid)
+    assert np.all(st == 0)
+    assert relerr(out, ref) < SED_RTOL
+    out1, _ = ctx.sed_eval(pars, opthin, noalpha, 500.0, np.array([um_to_GHz / 433.0]))
+    assert relerr(out1[:, 0], g_sed[name + "/fnu_scalar433"]) < SED_RTOL
+
+
+def test_fnu_wavenorm850(mbb, g_sed):
+    m = mbb.modified_blackbody(25.0, 1.6, 150.0, 2.5, 12.0, wavenorm=850.0)
+    assert relerr(m(g_sed["wave_grid"]), g_sed["wn850/fnu_grid"]) < SED_RTOL
+    np.testing.assert_allclose(m(850.0), 12.0, rtol=1e-13)
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_fnu_explicit_matches_pyx_signature(ctx, g_sed, name, opthin, noalpha):
+    """fnu.pyx:9-108 entry points with explicit scalars"""
+    from mbb_emcee_amd.modified_blackbody import um_to_GHz
+    pars, grid = g_sed["pars"], g_sed["wave_grid"]
+    sc = g_sed[name + "/scalars"]
+    for i in (0, 7, 40, 60, 90):
+        out = ctx.fnu_eval(opthin, noalpha, um_to_GHz / grid, pars[i, 0], pars[i, 1],
+                           sc[i, 3] if not opthin else 1.0, pars[i, 3], sc[i, 0],
+                           sc[i, 1] if not noalpha else 0.0, sc[i, 2] if not noalpha else 0.0)
+        assert relerr(out, g_sed[name + "/fnu_grid"][i]) < SED_RTOL
+
+
+# ----------------------------------------------------- G4: lnL, cfg 1/2/4
+def _like_cfg1(mbb, g, name, opthin, noalpha):
+    k = "cfg1/" + name
+    like = mbb.likelihood(noalpha=noalpha, opthin=opthin)
+    like.set_phot(g[k + "/wave"], g[k + "/flux"], g[k + "/unc"])
+    return like, k
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_lnlike_cfg1_delta(mbb, g_lnl, name, opthin, noalpha):
+    like, k = _like_cfg1(mbb, g_lnl, name, opthin, noalpha)
+    np.testing.assert_array_equal(like.uplims, g_lnl[k + "/uplim"])
+    pars = g_lnl[k + "/pars"]
+    got = like(pars)
+    lnl_close(got, g_lnl[k + "/lnl"])
+    fin = np.isfinite(g_lnl[k + "/lnl"])
+    mf = like.model_flux(pars[fin])
+    assert relerr(mf, g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+    # scalar call returns a Python float, row by row identical to the batch
+    for i in (0, 3, 50, 55):
+        v = like(pars[i])
+        assert isinstance(v, float)
+        assert (v == got[i]) or (np.isneginf(v) and np.isneginf(got[i]))
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_lnlike_cfg2_passbands(mbb, g_lnl, name, opthin, noalpha):
+    k = "cfg2/" + name
+    like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
+    like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    np.testing.assert_allclose(like.uplims, g_lnl[k + "/uplim"], rtol=1e-15)
+    pars = g_lnl[k + "/pars"]
+    lnl_close(like(pars), g_lnl[k + "/lnl"])
+    fin = np.isfinite(g_lnl[k + "/lnl"])
+    assert relerr(like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_lnlike_cfg4_covariance(mbb, g_lnl, name, opthin, noalpha):
+    k = "cfg4/" + name
+    like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
+    like.set_phot([str(b) for b in g_lnl["cfg4/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    like.set_cov(g_lnl[k + "/cov"])
+    np.testing.assert_allclose(like.data_wave, g_lnl[k + "/eff_wave"], rtol=1e-14)
+    pars = g_lnl[k + "/pars"]
+    lnl_close(like(pars), g_lnl[k + "/lnl"])
+    fin = np.isfinite(g_lnl[k + "/lnl"])
+    assert relerr(like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+
+
+def test_lnlike_priors_and_peak(mbb, g_lnl):
+    """Gaussian priors on all five parameters, extra upper/lower limits, and the
+    lambda_peak ghost parameter (likelihood.py:672-752)."""
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
+    like.set_gaussian_prior("T", 11.0, 2.0)
+    like.set_gaussian_prior("beta", 1.9, 0.3)
+    like.set_gaussian_prior("lambda0", 550.0, 80.0)
+    like.set_gaussian_prior("alpha", 3.2, 0.5)
+    like.set_gaussian_prior("fnorm", 42.0, 4.0)
+    like.set_uplim("T", 12.5)
+    like.set_uplim("fnorm", 41.0)
+    like.set_lowlim("beta", 1.5)
+    pars = g_lnl["cfg2/priors/pars"]
+    lnl_close(like(pars), g_lnl["cfg2/priors/lnl"])
+    like.set_gaussian_prior("lambda_peak", 260.0, 15.0)
+    like.set_uplim("lambda_peak", 265.0)
+    lnl_close(like(pars), g_lnl["cfg2/priors_peak/lnl"])
+    # thin + alpha with a peak prior
+    like = mbb.likelihood(response=True, opthin=True)
+    like.set_phot(bands, g_lnl["cfg2/thin_walpha/flux"], g_lnl["cfg2/thin_walpha/unc"])
+    like.set_gaussian_prior("peaklam", 250.0, 20.0)
+    lnl_close(like(pars), g_lnl["cfg2/thin_peak/lnl"])
+
+
+def test_max_wave(mbb, g_lnl):
+    pars = g_lnl["cfg2/priors/pars"]
+    ref = g_lnl["cfg2/priors_peak/max_wave"]
+    for i in (0, 11, 50):
+        np.testing.assert_allclose(mbb.modified_blackbody(*pars[i]).max_wave(), ref[i], rtol=1e-10)
+
+
+# ------------------------------------------- HIP vs oracle on fresh inputs
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+@pytest.mark.parametrize("n", [1, 2, 63, 125, 250, 1000, 4099])
+def test_vs_oracle_batch_sizes(mbb, oracle, g_lnl, name, opthin, noalpha, n):
+    """Every batch geometry (walkers per block 1..64, ragged last block) gives
+    the oracle's answer, and a row's value does not depend on the batch it is in."""
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    k = "cfg2/" + name
+    like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
+    like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    rng = np.random.RandomState(1000 + n)
+    pars = np.column_stack([rng.normal(12, 1, n), rng.normal(1.8, 0.2, n),
+                            rng.normal(600, 50, n), rng.normal(3, 0.3, n), rng.normal(40, 3, n)])
+    got = like(pars)
+    orc = oracle.OracleLikelihood(
+        g_lnl[k + "/flux"], g_lnl[k + "/unc"],
+        bands=[(r.wavelength, r._sedmult, r._normfac) for r in like._responses],
+        opthin=opthin, noalpha=noalpha, has_uplim=[int(b) for b in like.has_uplims],
+        uplim=like.uplims)
+    ref = orc(pars, nthreads=8)
+    lnl_close(got, ref)
+    # batch-composition independence: bitwise
+    sub = like(pars[: max(1, n // 3)])
+    assert np.array_equal(sub, got[: max(1, n // 3)])
+
+
+def test_zero_copy_path_identical(mbb, g_lnl):
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
+    pars = g_lnl["cfg2/thick_walpha/pars"]
+    a = like(pars)
+    like.context.set_option("zero_copy", 1)
+    b = like(pars)
+    like.context.set_option("zero_copy", 0)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("wpb,threads", [(1, 64), (1, 1024), (3, 256), (16, 128), (64, 512)])
+def test_geometry_invariance(mbb, g_lnl, wpb, threads):
+    """lnL is bitwise independent of the launch geometry."""
+    bands = [str(b) for b in g_lnl["cfg4/bands"]]
+    k = "cfg4/thick_walpha"
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    like.set_cov(g_lnl[k + "/cov"])
+    pars = g_lnl[k + "/pars"]
+    ref = like(pars)
+    like.context.set_option("walkers_per_group", wpb)
+    like.context.set_option("block_threads", threads)
+    got = like(pars)
+    assert like.context.info("last_wpb") == wpb and like.context.info("last_threads") == threads
+    assert np.array_equal(ref, got, equal_nan=True)
+
+
+def test_empty_and_bad_shapes(mbb, g_lnl):
+    like, k = _like_cfg1(mbb, g_lnl, "thick_walpha", False, False)
+    assert like(np.empty((0, 5))).shape == (0,)
+    with pytest.raises(ValueError):
+        like(np.ones(4))
+    with pytest.raises(ValueError):
+        like(np.ones((3, 4)))
+    # NaN parameter rows pass the `<` gate like the reference and come out NaN
+    p = g_lnl[k + "/pars"][:4].copy()
+    p[1, 0] = np.nan
+    out = like(p)
+    assert np.isnan(out[1]) and np.all(np.isfinite(out[[0, 2, 3]]))
+
+
+def test_bad_alpha_raises_like_reference(mbb, g_lnl):
+    """alpha <= 0 reaches the SED constructor only when the lower limit allows it;
+    the reference then raises ValueError (modified_blackbody.py:219-221)."""
+    like, k = _like_cfg1(mbb, g_lnl, "thick_walpha", False, False)
+    like.set_lowlim("alpha", -5.0)
+    p = g_lnl[k + "/pars"][:3].copy()
+    p[2, 3] = -1.0
+    with pytest.raises(ValueError):
+        like(p)
+
+
+def test_low_temperature_overflow_gives_zero_not_nan(mbb):
+    """expm1(x) overflows for x > 709.78 (MIPS 24um at T ~ 1 K): the band flux
+    must be 0, not NaN (SURVEY.md 8a numerical-range notes)."""
+    like = mbb.likelihood(response=True, opthin=True, noalpha=True)
+    like.set_phot(["MIPS_24um", "SPIRE_500um"], [1.0, 40.0], [1.0, 4.0])
+    p = np.array([[1.0, 1.5, 100.0, 2.0, 40.0]])
+    fl = like.model_flux(p)
+    assert np.all(np.isfinite(fl)) and 0.0 <= fl[0, 0] < 1e-100
+    assert np.isfinite(like(p[0]))
+    # the delta-function version sits entirely beyond the overflow point
+    like = mbb.likelihood(opthin=True, noalpha=True)
+    like.set_phot([19.0, 500.0], [1.0, 40.0], [1.0, 4.0])
+    fl = like.model_flux(p)
+    assert fl[0, 0] == 0.0 and np.isfinite(like(p[0]))
+
+
+def test_special_passbands_vs_oracle(mbb, oracle):
+    names = ["SCUBA2_box_850um_85", "SMA_gauss_345_8", "X_dsb_230_16_8", "ALMA_alma_343",
+             "Y_delta_880um", "SPIRE_350um"]
+    like = mbb.likelihood(response=True)
+    flux = np.array([9.0, 14.0, 3.0, 12.0, 8.0, 75.0])
+    like.set_phot(names, flux, 0.1 * flux + 0.5)
+    rng = np.random.RandomState(5)
+    pars = np.column_stack([rng.normal(12, 1, 97), rng.normal(1.8, 0.2, 97),
+                            rng.normal(600, 50, 97), rng.normal(3, 0.3, 97), rng.normal(40, 3, 97)])
+    bands = []
+    for r in like._responses:
+        if r.isdelta:
+            bands.append((r.wavelength, np.ones(1), 1.0))
+        else:
+            bands.append((r.wavelength, r._sedmult, r._normfac))
+    orc = oracle.OracleLikelihood(flux, 0.1 * flux + 0.5, bands=bands,
+                                  has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
+    lnl_close(like(pars), orc(pars))
+
+
+def test_sampler_recovers_truth(mbb):
+    """End-to-end: mbb_fitter on synthetic cfg1-like data recovers the truth
+    (statistical parity only: emcee itself is not available)."""
+    wave = np.array([100.0, 160.0, 250.0, 350.0, 500.0, 850.0])
+    truth = mbb.modified_blackbody(14.0, 1.8, None, None, 40.0, opthin=True, noalpha=True)
+    flux = truth(wave)
+    fit = mbb.mbb_fitter(nwalkers=64, opthin=True, noalpha=True, seed=3)
+    fit.set_data(wave, flux, 0.05 * flux)
+    fit.fix_param("lambda0")
+    fit.fix_param("alpha")
+    p0 = fit.generate_initial_values(np.array([12.0, 2.0, 600.0, 3.0, 35.0]),
+                                     np.array([2, 0.2, 100, 0.3, 5.0]))
+    assert np.all(p0[:, 2] == 600.0) and np.all(p0[:, 3] == 3.0)
+    fit.run(150, 150, p0)
+    ch = fit.sampler.chain
+    assert ch.shape == (64, 150, 5) and fit.sampler.lnprobability.shape == (64, 150)
+    assert np.all(ch[:, :, 2] == 600.0)                # fixed by zero initial scatter
+    med = np.median(ch.reshape(-1, 5), axis=0)
+    assert abs(med[0] - 14.0) < 1.0 and abs(med[1] - 1.8) < 0.3 and abs(med[4] - 40.0) < 2.0
+    assert 0.2 < fit.sampler.acceptance_fraction.mean() < 0.9
