@@ -93,6 +93,12 @@ int mbb_lnlike_batch(mbb_ctx *ctx, const double *pars, int n, double *lnl,
 int mbb_lnlike_batch_device(mbb_ctx *ctx, const double *d_pars, int n,
                             double *d_lnl, int32_t *d_status, double *d_model_flux);
 
+/* Measurement helper: the same launch enqueued `reps` times back to back from
+ * C (no host work in between), so that HIP events around the call time the
+ * kernel itself.  Asynchronous. */
+int mbb_lnlike_repeat_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
+                             int32_t *d_status, int reps);
+
 /* ---- SED-level entry points (parity + the modified_blackbody class) ----- */
 /* Replaces: modified_blackbody.__init__ (modified_blackbody.py:168-337) and
  * max_wave (:581-637) for n parameter rows.

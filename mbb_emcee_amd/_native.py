@@ -31,6 +31,7 @@ SIGNATURES = {
     "mbb_set_gpriors": (C.c_int, [_vp, _ip, _dp, _dp]),
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
     "mbb_lnlike_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "mbb_lnlike_repeat_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int]),
     "mbb_sed_prologue_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_int, _dp, _ip]),
     "mbb_sed_eval_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp,
@@ -206,6 +207,11 @@ class Context(object):
             d_lnl.ptr if hasattr(d_lnl, "ptr") else d_lnl,
             (d_status.ptr if hasattr(d_status, "ptr") else d_status),
             (d_flux.ptr if hasattr(d_flux, "ptr") else d_flux)))
+
+    def lnlike_repeat_device(self, d_pars, n, d_lnl, d_status, reps):
+        _check(self.lib.mbb_lnlike_repeat_device(
+            self.h, d_pars.ptr, int(n), d_lnl.ptr,
+            d_status.ptr if d_status is not None else None, int(reps)))
 
     # ---- SED level -------------------------------------------------------------
     def sed_prologue(self, pars, opthin, noalpha, wavenorm, want_peak=False):

@@ -83,20 +83,27 @@ __device__ __forceinline__ double merge_g(double x, double alpha, double beta,
 // every alpha, beta >= 0 because 0 <= h <= 1, and g has a single sign change, so
 // that interval brackets the same root; a safeguarded Newton iteration on it
 // converges to a few ulp (the reference stops at xtol = 2e-12).
-__device__ inline double thick_merge_root(double alpha, double beta, double lx0, int &status)
+__device__ inline double thick_merge_root(double alpha, double beta, double lx0, int &status,
+                                          int *iters = nullptr)
 {
     double lo = 2.0 + alpha, hi = 3.0 + alpha + beta;
     double x = 0.5 * (lo + hi);
     status = ROW_NOCONV;
     for (int it = 0; it < 80; ++it) {
         double dg, g = merge_g(x, alpha, beta, lx0, dg);
+        if (iters) *iters = it + 1;
         if (g == 0.0) { status = ROW_OK; break; }
         if (g < 0.0) lo = x; else hi = x;
-        double xn = x - g / dg;
-        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        double dx = fabs(xn - x);
+        const double step = -g / dg;
+        // Newton converges quadratically here (|g''/2g'| < 1): once a step is
+        // below 1e-8 x the error left after taking it is below one ulp.
+        if (fabs(step) <= 1e-8 * fabs(x)) { x += step; status = ROW_OK; break; }
+        double xn = x + step;
+        if (!(xn > lo && xn < hi)) {
+            xn = 0.5 * (lo + hi);
+            if (!(xn > lo && xn < hi)) { x = xn; status = ROW_OK; break; }  // bracket is 1 ulp
+        }
         x = xn;
-        if (dx <= 1e-15 * fabs(xn) || !(hi - lo > 0.0)) { status = ROW_OK; break; }
     }
     return x;
 }
@@ -111,10 +118,9 @@ __device__ inline double thin_fixed_point(double a)
     for (int it = 0; it < 60; ++it) {
         double e = d_exp(-x);
         double F = x - a * (1.0 - e), dF = 1.0 - a * e;
-        double xn = x - F / dF;
-        double dx = fabs(xn - x);
-        x = xn;
-        if (dx <= 1e-15 * fabs(xn)) break;
+        double step = -F / dF;
+        x += step;
+        if (fabs(step) <= 1e-8 * fabs(x)) break;       // quadratic: next error < 1 ulp
     }
     return x;
 }
@@ -122,7 +128,8 @@ __device__ inline double thin_fixed_point(double a)
 // modified_blackbody.__init__ (modified_blackbody.py:168-337).
 template <bool OPTHIN, bool NOALPHA>
 __device__ inline int sed_prologue(double T, double beta, double lambda0, double alpha,
-                                   double fnorm, double wavenorm, SedScalars &s)
+                                   double fnorm, double wavenorm, SedScalars &s,
+                                   int *iters = nullptr)
 {
     const double nan = __builtin_nan("");
     s.normfac = nan; s.xmerge = nan; s.kappa = nan; s.x0 = nan; s.hcokt = nan;
@@ -151,7 +158,7 @@ __device__ inline int sed_prologue(double T, double beta, double lambda0, double
             s.normfac = -fnorm * d_expm1(xnorm) /
                 (d_expm1(-d_pow(xnorm / x0, beta)) * (xnorm * xnorm * xnorm));
         } else {
-            s.xmerge = thick_merge_root(alpha, beta, d_log(x0), status); // :286-322
+            s.xmerge = thick_merge_root(alpha, beta, d_log(x0), status, iters); // :286-322
             s.kappa = -d_pow(s.xmerge, 3.0 + alpha) *                // :326-328
                 d_expm1(-d_pow(s.xmerge / x0, beta)) / d_expm1(s.xmerge);
             if (xnorm > s.xmerge) {                                 // :331-337

@@ -48,6 +48,7 @@ struct LikeArgs {
     const double *pars;       // [n*5]
     int n;
     int wpb;                  // walkers per block
+    int debug;                // status carries root-finder iterations << 8
     double *lnl;              // [n]
     int32_t *status;          // [n] or nullptr
     double *model_flux;       // [n*nb] or nullptr
@@ -91,8 +92,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 k.status = ROW_BELOW_LOWLIM;
             } else {
                 SedScalars s;
+                k.pad = 0;
                 k.status = sed_prologue<OPTHIN, NOALPHA>(p[0], p[1], p[2], p[3], p[4],
-                                                         a.wavenorm, s);
+                                                         a.wavenorm, s, &k.pad);
                 if (k.status == ROW_OK) {
                     make_walker_k<OPTHIN, NOALPHA>(p[0], p[1], p[3], s, k);
                     // _uplim_prior, likelihood.py:672-717
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 if (a.has_gprior) r += pen[2 * tid + 1];       // :830-831
             }
             a.lnl[w] = r;
-            if (a.status) a.status[w] = st;
+            if (a.status) a.status[w] = a.debug ? (st | (wk[tid].pad << 8)) : st;
         }
     }
 }
@@ -356,7 +358,7 @@ struct mbb_ctx {
     int32_t *d_sed_status = nullptr;
     WalkerK *d_sed_wk = nullptr;
     // options
-    long opt_wpb = 0, opt_threads = 0, opt_zero_copy = 0, opt_seg_chunks = 4;
+    long opt_wpb = 0, opt_threads = 0, opt_zero_copy = 0, opt_seg_chunks = 4, opt_debug = 0;
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     // rccl
     ncclComm_t_ comm = nullptr;
@@ -612,6 +614,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     int wpb, threads;
     pick_geometry(c, n, wpb, threads);
     a.wpb = wpb;
+    a.debug = (int)c->opt_debug;
     const int grid = (n + wpb - 1) / wpb;
     const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16);
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
@@ -634,6 +637,17 @@ extern "C" int mbb_lnlike_batch_device(mbb_ctx *c, const double *d_pars, int n, 
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!d_pars || !d_lnl))) return fail(MBB_ERR_ARG, "bad batch buffers");
     return launch_lnlike(c, d_pars, n, d_lnl, d_status, d_mflux);
+}
+
+extern "C" int mbb_lnlike_repeat_device(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
+                                        int32_t *d_status, int reps)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || reps <= 0 || !d_pars || !d_lnl) return fail(MBB_ERR_ARG, "bad batch buffers");
+    for (int r = 0; r < reps; ++r)
+        if ((rc = launch_lnlike(c, d_pars, n, d_lnl, d_status, nullptr))) return rc;
+    return MBB_OK;
 }
 
 extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *lnl,
@@ -873,6 +887,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "block_threads")) c->opt_threads = value;
     else if (!strcmp(name, "zero_copy")) c->opt_zero_copy = value;
     else if (!strcmp(name, "seg_chunks")) c->opt_seg_chunks = value;
+    else if (!strcmp(name, "debug")) c->opt_debug = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;
 }
