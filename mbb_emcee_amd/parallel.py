@@ -1,0 +1,115 @@
+"""Multi-GPU evaluation of an ensemble: walkers partitioned across ranks, one
+all-gather of log-probabilities per call (i.e. per emcee half-step).
+
+The reference's only parallelism is emcee's multiprocessing pool over walkers
+(reference mbb_emcee/mbb_fit.py:80-81).  Each walker's lnL depends only on its
+own five parameters (likelihood.py:790-834), so the ensemble shards trivially:
+one process per GPU, rank r evaluates the contiguous block
+``[r*per, (r+1)*per)`` of the rows it is given and the blocks are exchanged with
+a single collective.  Every rank runs the same sampler with the same random
+stream, so positions never have to be scattered -- the all-gather of lnprob is
+the only data-path communication.
+
+Two communicators:
+  RcclComm   -- ncclAllGather on device buffers through the C-ABI (the MI355X path)
+  TorchComm  -- torch.distributed all_gather on host tensors (gloo; used by the
+                CPU tests of the sharding logic, and usable as a slow fallback)
+"""
+import numpy as np
+
+__all__ = ["block_bounds", "RcclComm", "TorchComm", "ShardedLikelihood"]
+
+
+def block_bounds(n, world):
+    """Rows per rank (ceil) and the [lo, hi) block of every rank."""
+    per = (n + world - 1) // world
+    return per, [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+
+
+class TorchComm(object):
+    """Host-side all-gather through torch.distributed (any backend with CPU tensors)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather_host(self, x):
+        import torch
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = torch.empty(self.world * x.size, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(out, torch.from_numpy(x), group=self.group)
+        return out.numpy()
+
+
+class RcclComm(object):
+    """ncclAllGather over xGMI on the likelihood context's stream (C-ABI)."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        if self.world > 1:
+            ctx.comm_init(self.world, self.rank, unique_id)
+        self._cap = 0
+        self._bufs = None
+
+    def buffers(self, per):
+        if per > self._cap:
+            if self._bufs:
+                for b in self._bufs:
+                    b.free()
+            cap = max(256, 2 * per)
+            self._bufs = (self.ctx.alloc(cap * 40), self.ctx.alloc(cap * 8),
+                          self.ctx.alloc(cap * 4), self.ctx.alloc(self.world * cap * 8))
+            self._cap = cap
+        return self._bufs
+
+    def close(self):
+        if self.world > 1:
+            self.ctx.comm_destroy()
+
+
+class ShardedLikelihood(object):
+    """lnprob callable for an ensemble partitioned across ranks.
+
+    ``like`` is this package's likelihood when ``comm`` is an RcclComm (the
+    shard is evaluated by the fused kernel and gathered device-to-device), or
+    any callable ``(m, 5) -> float64[m]`` with a TorchComm.  Calling it with the
+    same ``(n, 5)`` array on every rank returns the same ``float64[n]`` everywhere.
+    """
+
+    def __init__(self, like, comm):
+        self.like = like
+        self.comm = comm
+
+    @property
+    def context(self):             # lets EnsembleSampler default to vectorize=True
+        return getattr(self.like, "context", None)
+
+    def __call__(self, pars):
+        p = np.ascontiguousarray(np.atleast_2d(pars), dtype=np.float64)
+        n = p.shape[0]
+        world, rank = self.comm.world, self.comm.rank
+        per, bounds = block_bounds(n, world)
+        lo, hi = bounds[rank]
+        local = np.empty((per, 5))
+        local[:hi - lo] = p[lo:hi]
+        if hi - lo < per:                       # ragged tail: pad with a valid row
+            local[hi - lo:] = p[0]
+        if isinstance(self.comm, RcclComm):
+            ctx = self.like._sync_device()
+            d_pars, d_lnl, d_st, d_all = self.comm.buffers(per)
+            d_pars.upload(local)
+            ctx.lnlike_batch_device(d_pars, per, d_lnl, d_st)
+            ctx.allgather_f64(d_lnl, d_all, per)
+            full = d_all.download(np.float64, world * per)
+            st = d_st.download(np.int32, per)
+            from . import _native
+            _native.raise_for_status(st[:hi - lo])
+        else:
+            full = self.comm.allgather_host(np.asarray(self.like(local), dtype=np.float64))
+        out = np.empty(n)
+        for r, (a, b) in enumerate(bounds):
+            out[a:b] = full[r * per:r * per + (b - a)]
+        return out

@@ -1,0 +1,322 @@
+"""CPU tests of the host logic: passband construction (against fixtures made by
+the reference), filter-wheel / photometry text formats, likelihood bookkeeping,
+initial positions, the sampler, the C-ABI symbol table, and the 2-rank (gloo)
+sharding path.  No GPU is needed and none is used."""
+import os
+import pickle
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+# ---------------------------------------------------------------- response
+def test_default_wheel_members():
+    """reference tests/test_response.py:10-17"""
+    from mbb_emcee_amd import response_set
+    wheel = response_set()
+    for nm in ("SCUBA2_850um", "SPIRE_250um", "SPIRE_350um", "SPIRE_500um", "Bolocam_1.1mm"):
+        assert nm in wheel
+    assert len(wheel) == 18 and "MAMBO2_1.2mm" in wheel
+
+
+def test_spire250_kat():
+    """reference tests/test_response.py:19-29"""
+    from mbb_emcee_amd import response_set
+    r = response_set()["SPIRE_250um"]
+    assert r.data_read and r.name == "SPIRE_250um"
+    np.testing.assert_allclose(r.normfac, 3.0796e-3, atol=1e-4)
+    np.testing.assert_allclose(r.effective_wavelength, 247.268656, atol=1e-4)
+    np.testing.assert_allclose(r(lambda x: 1), 1.011046, atol=1e-4)
+
+
+def test_add_special_kat():
+    """reference tests/test_response.py:31-43"""
+    from mbb_emcee_amd import response_set
+    wheel = response_set()
+    wheel.add_special("ZSpec_box_1050um_100")
+    r = wheel["ZSpec_box_1050um_100"]
+    assert r.data_read and r.name == "ZSpec_box_1050um_100"
+    np.testing.assert_allclose(r.effective_frequency, 286.1655, atol=1e-3)
+    np.testing.assert_allclose(r(lambda x: 1), 1.0, atol=1e-4)
+    del wheel["ZSpec_box_1050um_100"]
+    assert "ZSpec_box_1050um_100" not in wheel
+
+
+def test_passband_tables_match_reference(g_pb):
+    """G1: wave, freq, response, trapezoid weights, normalisation and effective
+    wavelength of every wheel band and every special type, as the reference
+    builds them (response.py:252-332)."""
+    from mbb_emcee_amd import response_set
+    wheel = response_set()
+    for nm in [str(n) for n in g_pb["names"]]:
+        if nm not in wheel:
+            wheel.add_special(nm)
+        r = wheel[nm]
+        sc = g_pb[nm + "/scalars"]
+        np.testing.assert_allclose(r.wavelength, g_pb[nm + "/wave"], rtol=1e-15)
+        np.testing.assert_allclose(r.frequency, g_pb[nm + "/freq"], rtol=1e-15)
+        np.testing.assert_allclose(r.response, g_pb[nm + "/resp"], rtol=1e-15)
+        if not r.isdelta:
+            np.testing.assert_allclose(r._sedmult, g_pb[nm + "/sedmult"], rtol=1e-14)
+            f, w = r.quadrature()
+            np.testing.assert_allclose(np.sum(w), sc[7], rtol=1e-13)   # flat-SED response
+        np.testing.assert_allclose([r._normfac, r.effective_wavelength, r.effective_frequency],
+                                   sc[:3], rtol=1e-14)
+        assert r._nresp == int(sc[5]) and bool(sc[6]) == r.isdelta
+
+
+@pytest.mark.parametrize("spec,sens,ntype,xn,npar", [
+    ("SPIRE_250.txt", "counts", "power", 250.0, -1.0),
+    ("MIPS_70.txt", "energy", "none", 71.44, 0.0),
+    ("PACS_100.txt", "counts", "flat", 100.0, 0.0)])
+def test_counts_and_none_normalisations(g_pb, spec, sens, ntype, xn, npar):
+    """response.py:284-301"""
+    from mbb_emcee_amd import response
+    r = response("x")
+    r.setup(spec, senstype=sens, normtype=ntype, xnorm=xn, normparam=npar, dir="!package-dir!")
+    key = "setup:%s:%s:%s" % (spec, sens, ntype)
+    np.testing.assert_allclose(r._sedmult, g_pb[key + "/sedmult"], rtol=1e-14)
+    np.testing.assert_allclose([r._normfac, r.effective_wavelength, r.effective_frequency],
+                               g_pb[key + "/scalars"], rtol=1e-14)
+
+
+def test_wheel_and_curve_text_formats(tmp_path):
+    """A user-supplied filter wheel + curve files in the reference's text format
+    (mbb_filterwheel.txt columns; two-column curves, '#' comments)."""
+    from mbb_emcee_amd import response_set
+    from mbb_emcee_amd.response import _packaged_curve
+    x, r = _packaged_curve("SPIRE_350.txt")
+    with open(tmp_path / "my350.txt", "w") as fh:
+        fh.write("# wavelength  transmission\n")
+        for a, b in zip(x, r):
+            fh.write("%.17g  %.17g\n" % (a, b))
+    with open(tmp_path / "wheel.txt", "w") as fh:
+        fh.write("#Name File Xtype Xunit Sens NormType XNorm NormPar\n")
+        fh.write("My_350 my350.txt wave microns energy power 350.0 -1.0\n")
+        fh.write("My_350A my350A.txt wave angstroms energy power 3500000.0 -1.0\n")
+    with open(tmp_path / "my350A.txt", "w") as fh:
+        for a, b in zip(x, r):
+            fh.write("%.17g %.17g\n" % (a * 1e4, b))
+    wheel = response_set("wheel.txt", dir=str(tmp_path))
+    ref = response_set()["SPIRE_350um"]
+    np.testing.assert_allclose(wheel["My_350"]._sedmult, ref._sedmult, rtol=1e-15)
+    np.testing.assert_allclose(wheel["My_350"].normfac, ref.normfac, rtol=1e-15)
+    np.testing.assert_allclose(wheel["My_350A"].normfac, ref.normfac, rtol=1e-12)
+    np.testing.assert_allclose(wheel["My_350A"].effective_wavelength, ref.effective_wavelength, rtol=1e-12)
+
+
+def test_special_spec_errors():
+    from mbb_emcee_amd import response, response_set
+    wheel = response_set()
+    for bad in ("X_blob_3", "X_box", "X_box_abc_3", "X_box_100mm_3"):
+        with pytest.raises(ValueError):
+            wheel.add_special(bad)
+    with pytest.raises(ValueError):
+        wheel.add_special("ALMA_alma_200")          # between bands 4 and 6
+    with pytest.raises(ValueError):
+        response("x").setup("box_100")
+    r = response("d")
+    r.setup("delta_300", xtype="freq", xunits="ghz")  # works here
+    np.testing.assert_allclose(r.effective_wavelength, 299792.458 / 300)
+    # dsb given in wavelength units is converted consistently
+    a, b = response("a"), response("b")
+    a.setup("dsb_230_16_8", xtype="freq", xunits="ghz", normtype="flat", xnorm=230.0)
+    lam = 299792.458 / 230.0
+    assert a._nresp == 29 and np.all(a.response[13:16] == 0)
+    np.testing.assert_allclose(a.effective_frequency, 230.0, rtol=1e-3)
+
+
+# ---------------------------------------------------------------- likelihood host logic
+def _like(**kw):
+    from mbb_emcee_amd import likelihood
+    return likelihood(**kw)
+
+
+def test_likelihood_defaults_and_setters():
+    """likelihood.py:73, :83-85, :227-229 and the accessor family :378-641"""
+    like = _like()
+    np.testing.assert_array_equal(like.lowlims, [1, 0.1, 1, 0.1, 1e-3])
+    assert like.has_uplims == [False, True, False, True, False, False]
+    assert like.uplim("beta") == 20.0 and like.uplim("T") is None
+    like.set_phot([250.0, 350.0, 500.0], [30.0, 40.0, 30.0], [3.0, 4.0, 3.0])
+    assert like.ndata == 3 and like.has_uplim("lambda0") and like.uplim(2) == 1500.0   # 3 x max wave
+    like.set_uplim("lambda_peak", 300.0)
+    assert like.has_uplim(5) and like.uplim("peaklam") == 300.0
+    like.set_gaussian_prior("T/(1+z)", 20.0, 2.0)
+    assert like.has_gaussian_prior("t") and like.get_gaussian_prior(0) == (20.0, 2.0)
+    assert like.gprior_ivars[0] == 0.25 and like.get_gaussian_prior("beta") is None
+    like.set_lowlim("F500", 0.5)
+    assert like.lowlim(4) == 0.5 and like.get_paramindex("alpha") == 3
+    assert like._check_lowlim([2, 1, 2, 1, 1]) and not like._check_lowlim([0.5, 1, 2, 1, 1])
+    with pytest.raises(ValueError):
+        like._check_lowlim([1, 2, 3])
+    f, w, o = like.band_tables()
+    np.testing.assert_allclose(f, 299792.458 / np.array([250.0, 350.0, 500.0]))
+    assert np.all(w == 1) and list(o) == [0, 1, 2, 3]
+    with pytest.raises(ValueError):
+        like.set_phot([250.0], [1.0, 2.0], [1.0])
+    like.set_phot([250.0, 350.0, 500.0], [30.0, 40.0, 30.0], [3.0, 4.0, 3.0])
+    with pytest.raises(ValueError):
+        like.set_cov(np.eye(2))                      # ValueError, not NameError
+    like.set_cov(np.diag([9.0, 16.0, 9.0]))
+    np.testing.assert_allclose(like.data_flux_unc, [3, 4, 3])
+    np.testing.assert_allclose(like.data_invcovmatrix, np.diag([1 / 9.0, 1 / 16.0, 1 / 9.0]))
+
+
+def test_likelihood_response_mode_and_files(tmp_path):
+    like = _like(response=True)
+    with pytest.raises(ValueError):
+        like.set_phot([250.0], [1.0], [1.0])          # names expected
+    with pytest.raises(ValueError):
+        like.set_phot(["NoSuch_band"], [1.0], [1.0])
+    like.set_phot(["SPIRE_250um", "ALMA_alma_343", "X_box_850um_50"], [30, 5, 8], [3, 1, 1])
+    assert like.response_names == ["SPIRE_250um", "ALMA_alma_343", "X_box_850um_50"]
+    assert like.has_response("ALMA_alma_343")
+    np.testing.assert_allclose(like.data_wave[0], 247.268656, atol=1e-4)
+    f, w, o = like.band_tables()
+    assert list(o) == [0, 189, 189 + 29, 189 + 29 + 11]
+    # photometry file; lowlim[4] follows the data only through the constructor (Q8)
+    pf = tmp_path / "phot.txt"
+    pf.write_text("# wave flux err\n250 30.0 3.0\n350 40.0 4.0\n500 20.0 3.0\n")
+    like2 = _like(photfile=str(pf))
+    assert like2.ndata == 3 and like2.lowlim("fnorm") == pytest.approx(1e-3 * 20.0)
+    like3 = _like()
+    like3.read_phot(str(pf))
+    assert like3.lowlim("fnorm") == 1e-3
+    s = pickle.dumps(like2)                            # device context is not pickled
+    like4 = pickle.loads(s)
+    assert like4._ctx is None and like4.ndata == 3
+
+
+def test_no_gpu_fails_loudly():
+    """There is no CPU fallback: without a device the call raises."""
+    from mbb_emcee_amd import _native
+    lib = _native.load()
+    if lib.mbb_device_count() > 0:
+        pytest.skip("a GPU is present")
+    like = _like()
+    like.set_phot([250.0, 350.0], [30.0, 40.0], [3.0, 4.0])
+    with pytest.raises(_native.NativeError):
+        like(np.array([10.0, 2.0, 600.0, 3.0, 40.0]))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """Every function declared in include/mbb_hip.h is exported by the in-tree
+    library and bound with a signature in _native.SIGNATURES."""
+    from mbb_emcee_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "mbb_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mbb_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = _native.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_native.SIGNATURES), declared ^ set(_native.SIGNATURES)
+    assert lib.mbb_last_error() is not None
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """The product package never imports the oracle."""
+    pkg = os.path.join(ROOT, "mbb_emcee_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+                assert "libmbb_oracle" not in src and "mbbo_" not in src, fn
+
+
+# ---------------------------------------------------------------- fit driver
+def test_generate_initial_values_respects_limits():
+    """mbb_fit.py:362-479"""
+    from mbb_emcee_amd import mbb_fitter
+    fit = mbb_fitter(nwalkers=200, seed=5)
+    fit.set_data([250.0, 350.0, 500.0], [30.0, 40.0, 30.0], [3.0, 4.0, 3.0])
+    fit.fix_param("alpha")
+    fit.set_uplim("T", 30.0)
+    p0 = fit.generate_initial_values(np.array([10.0, 2.0, 2500.0, 4.0, 40.0]),
+                                     np.array([2, 0.2, 100, 0.3, 5.0]))
+    assert p0.shape == (200, 5)
+    assert np.all(p0[:, 3] == 4.0)                       # fixed: no scatter
+    assert np.all(p0[:, 2] <= 1500.0) and np.all(p0[:, 2] >= 1)   # lambda0 pulled inside 3x500
+    assert abs(np.median(p0[:, 2]) - 1300.0) < 40        # upper limit - 2 sigma
+    assert np.all(p0[:, 0] <= 30.0) and np.all(p0[:, 0] >= 1) and np.all(p0[:, 1] >= 0.1)
+    fit.fix_param("lambda0")
+    with pytest.raises(ValueError):                      # fixed and outside limits
+        fit.generate_initial_values(np.array([10.0, 2.0, 2500.0, 4.0, 40.0]), np.ones(5))
+    fit.unfix_param(2)
+    with pytest.raises(ValueError):
+        fit.generate_initial_values(np.ones(4), np.ones(5))
+    # run() validation happens before any lnprob evaluation (mbb_fit.py:510-522)
+    bad = p0.copy(); bad[0, 1] = 25.0
+    with pytest.raises(ValueError):
+        fit.run(1, 1, bad)
+    fit2 = mbb_fitter(nwalkers=10)
+    with pytest.raises(Exception):
+        fit2.run(1, 1, p0[:10])                          # no data
+
+
+def test_ensemble_sampler_gaussian():
+    """Stretch move samples a correlated Gaussian; row-wise, vectorised and
+    pool-mapped lnprob give identical chains for the same seed."""
+    from mbb_emcee_amd import EnsembleSampler
+    icov = np.linalg.inv(np.array([[2.0, 0.6], [0.6, 0.5]]))
+
+    def lnp_row(x):
+        return -0.5 * x.dot(icov).dot(x)
+
+    def lnp_vec(x):
+        return -0.5 * np.einsum("ni,ij,nj->n", x, icov, x)
+
+    class Pool(object):
+        def map(self, f, rows):
+            return [f(r) for r in rows]
+
+    p0 = np.random.RandomState(2).normal(0, 1, (40, 2))
+    chains = []
+    for kw in (dict(), dict(vectorize=True), dict(pool=Pool())):
+        s = EnsembleSampler(40, 2, lnp_vec if kw.get("vectorize") else lnp_row, seed=9, **kw)
+        pos, lnp, state = s.run_mcmc(p0, 400)
+        chains.append(s.chain.copy())
+        assert s.chain.shape == (40, 400, 2) and s.lnprobability.shape == (40, 400)
+        assert np.allclose(lnp, lnp_vec(pos))
+    assert np.allclose(chains[0], chains[1]) and np.allclose(chains[0], chains[2])
+    flat = chains[0][:, 100:, :].reshape(-1, 2)
+    assert np.allclose(np.cov(flat.T), [[2.0, 0.6], [0.6, 0.5]], atol=0.25)
+    assert 0.3 < s.acceptance_fraction.mean() < 0.9
+    assert np.all(np.isfinite(s.acor))
+    s.reset()
+    assert s.chain.shape == (40, 0, 2)
+    with pytest.raises(ValueError):
+        EnsembleSampler(3, 2, lnp_row)
+    with pytest.raises(ValueError):
+        EnsembleSampler(40, 2, lambda x: np.nan).run_mcmc(p0, 1)
+
+
+def test_block_bounds():
+    from mbb_emcee_amd.parallel import block_bounds
+    per, b = block_bounds(2000, 8)
+    assert per == 250 and b[0] == (0, 250) and b[7] == (1750, 2000)
+    per, b = block_bounds(10, 4)
+    assert per == 3 and b == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    per, b = block_bounds(2, 4)
+    assert per == 1 and b == [(0, 1), (1, 2), (2, 2), (2, 2)]
+
+
+def test_sharded_two_ranks_gloo():
+    """world_size 2 over gloo: partition, pad, all-gather, reassemble and a whole
+    sharded sampler run equal the single-process result bit for bit."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_dist_worker.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "DIST_OK" in out.stdout

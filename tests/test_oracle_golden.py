@@ -1,0 +1,109 @@
+"""Pins the CPU oracle (oracle/mbb_oracle.c) against fixtures made by the
+reference itself (tests/golden/make_golden.py) and against the reference's own
+known-answer tests.  Runs on CPU."""
+import numpy as np
+import pytest
+
+from conftest import VARIANTS, golden_bands, lnl_close
+
+
+def relerr(a, b):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
+
+
+# reference mbb_emcee/tests/test_modified_blackbody.py:6-69
+def test_kats_modified_blackbody(oracle):
+    S = oracle.OracleSED
+    wave = np.array([250.0, 350.0, 500.0, 850.0])
+    np.testing.assert_allclose(S(10.0, 2.0, 800.0, 2.0, 45.0)(wave),
+                               [21.96268738, 39.53249977, 45.0, 22.06274444], rtol=1e-4)
+    np.testing.assert_allclose(S(15.0, 1.8, 200.0, 3.0, 50.0, opthin=True)(wave),
+                               [178.34976, 111.03026, 50.0, 10.880588], rtol=1e-4)
+    w2 = np.array([500.0, 850.0, 1100.0, 2500.0])
+    np.testing.assert_allclose(S(15.0, 1.8, 5.0, 3.0, 50.0, opthin=True)(w2),
+                               S(15.0, 1.8, 5.0, 3.0, 50.0)(w2), rtol=1e-3)
+    assert S(20.0, 1.9, None, 3.5, 50.0, noalpha=True, opthin=True).wavemerge is None
+    np.testing.assert_allclose(S(20.0, 1.9, None, 3.5, 50.0, opthin=True).wavemerge, 85.66065, rtol=1e-3)
+    np.testing.assert_allclose(S(35.0, 2.2, None, 2.8, 50.0, opthin=True).wavemerge, 51.40211, rtol=1e-3)
+    np.testing.assert_allclose(S(20.0, 1.9, 250.0, 3.5, 50.0).wavemerge, 109.5506829, rtol=1e-3)
+    np.testing.assert_allclose(S(40.0, 1.5, 600.0, 3.0, 50.0).wavemerge, 60.10021595, rtol=1e-3)
+    with pytest.raises(ValueError):
+        S(10.0, 2.0, 800.0, -2.0, 45.0)
+    with pytest.raises(ValueError):
+        S(10.0, -2.0, 800.0, 2.0, 45.0)
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_sed_scalars_and_fnu(oracle, g_sed, name, opthin, noalpha):
+    """G2 + G3.  Bit-level agreement is expected except on the Wien side of the
+    thick+alpha kernel, where Cython 3 lowers `cx**(-alpha)` to complex pow
+    (exp(b log a), ~1e-14) while the oracle uses libm pow as the source intends."""
+    pars, grid = g_sed["pars"], g_sed["wave_grid"]
+    sc, fg = g_sed[name + "/scalars"], g_sed[name + "/fnu_grid"]
+    for i, p in enumerate(pars):
+        m = oracle.OracleSED(*p, noalpha=noalpha, opthin=opthin)
+        assert abs(m.s.normfac - sc[i, 0]) <= 1e-15 * abs(sc[i, 0])
+        if not noalpha:
+            assert abs(m.s.xmerge - sc[i, 1]) <= 1e-14
+            assert abs(m.s.kappa - sc[i, 2]) <= 1e-14 * abs(sc[i, 2])
+            assert abs(m.wavemerge - sc[i, 4]) <= 1e-14 * sc[i, 4]
+        if not opthin:
+            assert m.s.x0 == sc[i, 3]
+        assert abs(m.max_wave() - sc[i, 5]) <= 1e-14 * sc[i, 5]
+        assert relerr(m(grid), fg[i]) < 5e-14
+        assert relerr(m(433.0), g_sed[name + "/fnu_scalar433"][i]) < 5e-14
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_lnlike_cfg1(oracle, g_lnl, name, opthin, noalpha):
+    k = "cfg1/" + name
+    L = oracle.OracleLikelihood(g_lnl[k + "/flux"], g_lnl[k + "/unc"], wave=g_lnl[k + "/wave"],
+                                opthin=opthin, noalpha=noalpha, has_uplim=g_lnl[k + "/has_uplim"],
+                                uplim=g_lnl[k + "/uplim"], lowlim=g_lnl[k + "/lowlim"])
+    lnl, fl = L(g_lnl[k + "/pars"], return_flux=True)
+    lnl_close(lnl, g_lnl[k + "/lnl"], rtol=1e-13)
+    fin = np.isfinite(g_lnl[k + "/lnl"])
+    assert relerr(fl[fin], g_lnl[k + "/model_flux"][fin]) < 5e-14
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_lnlike_passbands(oracle, g_lnl, g_pb, cfg, name, opthin, noalpha):
+    k = cfg + "/" + name
+    names = [str(b) for b in g_lnl[cfg + "/bands"]]
+    cov = g_lnl[k + "/cov"] if cfg == "cfg4" else None
+    L = oracle.OracleLikelihood(g_lnl[k + "/flux"], g_lnl[k + "/unc"],
+                                bands=golden_bands(g_pb, names), cov=cov, opthin=opthin,
+                                noalpha=noalpha, has_uplim=[0, 1, 1, 1, 0, 0], uplim=g_lnl[k + "/uplim"])
+    lnl, fl = L(g_lnl[k + "/pars"], return_flux=True, nthreads=4)
+    lnl_close(lnl, g_lnl[k + "/lnl"], rtol=1e-13)
+    fin = np.isfinite(g_lnl[k + "/lnl"])
+    assert relerr(fl[fin], g_lnl[k + "/model_flux"][fin]) < 5e-14
+    # threads do not change the answer
+    assert np.array_equal(L(g_lnl[k + "/pars"], nthreads=1), lnl, equal_nan=True)
+
+
+def test_lnlike_priors_and_peak(oracle, g_lnl, g_pb):
+    names = [str(b) for b in g_lnl["cfg2/bands"]]
+    bands = golden_bands(g_pb, names)
+    ul = g_lnl["cfg2/thick_walpha/uplim"].copy()
+    hu = [1, 1, 1, 1, 1, 0]
+    ul[0], ul[4] = 12.5, 41.0
+    ll = [1, 1.5, 1, 0.1, 1e-3]
+    common = dict(bands=bands, lowlim=ll, gprior_mean=[11.0, 1.9, 550.0, 3.2, 42.0, 260.0],
+                  gprior_sigma=[2.0, 0.3, 80.0, 0.5, 4.0, 15.0])
+    pars = g_lnl["cfg2/priors/pars"]
+    L = oracle.OracleLikelihood(g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"],
+                                has_uplim=hu, uplim=ul, has_gprior=[1, 1, 1, 1, 1, 0], **common)
+    lnl_close(L(pars), g_lnl["cfg2/priors/lnl"], rtol=1e-13)
+    hu[5] = 1
+    ul[5] = 265.0
+    L = oracle.OracleLikelihood(g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"],
+                                has_uplim=hu, uplim=ul, has_gprior=[1, 1, 1, 1, 1, 1], **common)
+    lnl_close(L(pars), g_lnl["cfg2/priors_peak/lnl"], rtol=1e-13)
+    L = oracle.OracleLikelihood(g_lnl["cfg2/thin_walpha/flux"], g_lnl["cfg2/thin_walpha/unc"],
+                                bands=bands, opthin=True, has_uplim=[0, 1, 1, 1, 0, 0],
+                                uplim=g_lnl["cfg2/thin_walpha/uplim"],
+                                has_gprior=[0, 0, 0, 0, 0, 1], gprior_mean=[0, 0, 0, 0, 0, 250.0],
+                                gprior_sigma=[1, 1, 1, 1, 1, 20.0])
+    lnl_close(L(pars), g_lnl["cfg2/thin_peak/lnl"], rtol=1e-13)
