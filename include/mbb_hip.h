@@ -45,7 +45,8 @@ enum mbb_row_status {
     MBB_ROW_BELOW_LOWLIM = 1, /* lnL = -inf          likelihood.py:806-807   */
     MBB_ROW_BAD_ALPHA = 2,    /* alpha <= 0          modified_blackbody.py:219 */
     MBB_ROW_BAD_BETA = 3,     /* beta < 0            modified_blackbody.py:222 */
-    MBB_ROW_NOCONV = 6        /* merge / peak root not found                 */
+    MBB_ROW_NOCONV = 6,       /* merge / peak root not found                 */
+    MBB_ROW_NONFINITE = 7     /* NaN/inf parameter: lnL = NaN, as the reference */
 };
 
 const char *mbb_last_error(void);

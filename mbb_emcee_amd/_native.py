@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmbb_hip.so")
 
-ROW_OK, ROW_BELOW_LOWLIM, ROW_BAD_ALPHA, ROW_BAD_BETA, ROW_NOCONV = 0, 1, 2, 3, 6
+ROW_OK, ROW_BELOW_LOWLIM, ROW_BAD_ALPHA, ROW_BAD_BETA, ROW_NOCONV, ROW_NONFINITE = 0, 1, 2, 3, 6, 7
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -301,7 +301,7 @@ def default_context():
 def raise_for_status(status):
     """Map per-row status codes onto the reference's exceptions
     (modified_blackbody.py:219-224, :294-316)."""
-    bad = status[status >= 2]
+    bad = status[(status >= 2) & (status != ROW_NONFINITE)]     # NaN in -> NaN out, no raise
     if bad.size:
         code = int(bad[0])
         msg = {ROW_BAD_ALPHA: "alpha must be positive",

@@ -38,6 +38,7 @@ struct LikeArgs {
     const double *invcov;     // [nb*nb] or nullptr
     int nb, nseg;
     double wavenorm;
+    double lnunorm;           // log(um_to_GHz / wavenorm)
     double lowlim[5];
     double uplim[6];
     double gmean[6];
@@ -52,6 +53,9 @@ struct LikeArgs {
     double *lnl;              // [n]
     int32_t *status;          // [n] or nullptr
     double *model_flux;       // [n*nb] or nullptr
+#ifdef MBB_STAMPS
+    unsigned long long *stamps;   // diagnostic build only: [grid*8] s_memtime values
+#endif
 };
 
 // Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
@@ -73,7 +77,39 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *partial = reinterpret_cast<double *>(wk + W);   // [W*nseg]
     double *mflux = partial + (size_t)W * nseg;             // [W*nb]
     double *pen = mflux + (size_t)W * nb;                   // [W*2]
+    double *s_flux = pen + 2 * (size_t)W;                   // [nb]
+    double *s_ivar = s_flux + nb;                           // [nb]
+    double *s_invcov = s_ivar + nb;                         // [nb*nb] when a.invcov
+    int *s_band = reinterpret_cast<int *>(s_invcov + (a.invcov ? (size_t)nb * nb : 0));  // [nb+1]
     const int w0 = blockIdx.x * W;
+#ifdef MBB_STAMPS
+#define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    STAMP(0);
+
+    // While wave 0 runs the serial prologue the other waves stage the data the
+    // epilogue needs in LDS and pull their first segment's samples and the index
+    // table into this CU's L1, so that nothing after the barrier waits on L2.
+    if (wave > 0 || nwave == 1) {
+        const int t0 = (nwave == 1) ? tid : tid - 64, nt = (nwave == 1) ? 64 : (int)blockDim.x - 64;
+        for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
+        for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
+        if (a.invcov)
+            for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
+        const int u = wave;
+        if (u < W * nseg) {
+            const int s = u % nseg;
+            const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
+            double t = 0.0;
+            for (int c = c0; c < c1; ++c) {
+                const int i = c * 64 + lane;
+                t += a.nu[i] + a.lnnu[i] + a.wt[i];
+            }
+            asm volatile("" ::"v"(t));
+        }
+    }
 
     // ---- phase 1: gate + prologue + parameter-only penalties ----------------
     if (tid < W) {
@@ -90,11 +126,15 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
             if (!ok) {
                 k.status = ROW_BELOW_LOWLIM;
+            } else if (!finite5(p)) {
+                // NaN passes the reference's `<` gate and its SED arithmetic then
+                // yields NaN; +-inf does the same.  Short-cut both to NaN.
+                k.status = ROW_NONFINITE;
             } else {
                 SedScalars s;
                 k.pad = 0;
                 k.status = sed_prologue<OPTHIN, NOALPHA>(p[0], p[1], p[2], p[3], p[4],
-                                                         a.wavenorm, s, &k.pad);
+                                                         a.wavenorm, a.lnunorm, s, &k.pad);
                 if (k.status == ROW_OK) {
                     make_walker_k<OPTHIN, NOALPHA>(p[0], p[1], p[3], s, k);
                     // _uplim_prior, likelihood.py:672-717
@@ -134,7 +174,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         pen[2 * tid] = pen_u;
         pen[2 * tid + 1] = pen_g;
     }
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     // ---- phase 2: passband quadrature (response.py:572-576) -----------------
     const int nunit = W * nseg;
@@ -144,7 +186,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         const WalkerK k = wk[j];
         const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
         double acc = 0.0;
-        for (int c = c0; c < c1; ++c) {
+        int c = c0;
+        for (; c + 2 <= c1; c += 2) {          // two independent chains in flight
+            const int i0 = c * 64 + lane, i1 = i0 + 64;
+            const double n0 = a.nu[i0], l0 = a.lnnu[i0], q0 = a.wt[i0];
+            const double n1 = a.nu[i1], l1 = a.lnnu[i1], q1 = a.wt[i1];
+            const double f0 = fnu_sample<OPTHIN, NOALPHA>(k, n0, l0);
+            const double f1 = fnu_sample<OPTHIN, NOALPHA>(k, n1, l1);
+            acc = fma(f0, q0, acc);
+            acc = fma(f1, q1, acc);
+        }
+        if (c < c1) {
             const int i = c * 64 + lane;
             const double f = fnu_sample<OPTHIN, NOALPHA>(k, a.nu[i], a.lnnu[i]);
             acc = fma(f, a.wt[i], acc);
@@ -152,70 +204,72 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         acc = wave_sum(acc);
         if (lane == 0) partial[u] = acc;
     }
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
+    STAMP(5);
 
-    // ---- phase 3a: band fluxes ---------------------------------------------
-    for (int t = tid; t < W * nb; t += blockDim.x) {
-        const int j = t / nb, b = t - j * nb;
-        double sum = 0.0;
-        if (wk[j].status == ROW_OK) {
-            const int s0 = a.band_s0[b], s1 = a.band_s0[b + 1];
-            for (int s = s0; s < s1; ++s) sum += partial[j * nseg + s];
-            if (a.model_flux) a.model_flux[(size_t)(w0 + j) * nb + b] = sum;
-        } else if (a.model_flux && wk[j].status != ROW_SKIP) {
-            a.model_flux[(size_t)(w0 + j) * nb + b] = __builtin_nan("");
-        }
-        mflux[t] = sum;
-    }
-    __syncthreads();
-
-    // ---- phase 3b: lnL (likelihood.py:821-834) ------------------------------
-    if (tid < W) {
-        const int w = w0 + tid;
-        const int st = wk[tid].status;
-        if (st != ROW_SKIP) {
-            double r;
-            if (st == ROW_BELOW_LOWLIM) {
-                r = -__builtin_inf();
-            } else if (st != ROW_OK) {
-                r = __builtin_nan("");
-            } else {
-                const double *mf = mflux + (size_t)tid * nb;
-                double acc = 0.0;
-                if (a.invcov) {                                // :823
-                    for (int i = 0; i < nb; ++i) {
-                        double t = 0.0;
-                        for (int jj = 0; jj < nb; ++jj)
-                            t += a.invcov[i * nb + jj] * (a.flux[jj] - mf[jj]);
-                        acc += (a.flux[i] - mf[i]) * t;
-                    }
-                } else {                                       // :825
-                    for (int i = 0; i < nb; ++i) {
-                        double d = a.flux[i] - mf[i];
-                        acc += d * d * a.ivar[i];
-                    }
+    // ---- phase 3: one wave per walker, one lane per band (likelihood.py:821-834)
+    for (int j = wave; j < W; j += nwave) {
+        const int st = wk[j].status;
+        if (st == ROW_SKIP) continue;                          // wave-uniform
+        const int w = w0 + j;
+        double acc = 0.0;
+        if (st == ROW_OK) {
+            double *mf = mflux + (size_t)j * nb;
+            for (int b = lane; b < nb; b += 64) {              // band fluxes, fixed order
+                double sum = 0.0;
+                for (int sg = s_band[b]; sg < s_band[b + 1]; ++sg) sum += partial[j * nseg + sg];
+                if (a.model_flux) a.model_flux[(size_t)w * nb + b] = sum;
+                const double d = s_flux[b] - sum;              // :821
+                if (a.invcov) mf[b] = d;
+                else acc = fma(d * d, s_ivar[b], acc);         // :825
+            }
+            if (a.invcov) {                                    // :823
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < nb; i += 64) {
+                    double t = 0.0;
+                    for (int jj = 0; jj < nb; ++jj) t = fma(s_invcov[i * nb + jj], mf[jj], t);
+                    acc = fma(mf[i], t, acc);
                 }
+            }
+            acc = wave_sum(acc);
+        } else if (a.model_flux) {
+            for (int b = lane; b < nb; b += 64) a.model_flux[(size_t)w * nb + b] = __builtin_nan("");
+        }
+        if (lane == 0) {
+            double r;
+            if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
+            else if (st != ROW_OK) r = __builtin_nan("");
+            else {
                 r = -0.5 * acc;
-                r += pen[2 * tid];                             // :828
-                if (a.has_gprior) r += pen[2 * tid + 1];       // :830-831
+                r += pen[2 * j];                               // :828
+                if (a.has_gprior) r += pen[2 * j + 1];         // :830-831
             }
             a.lnl[w] = r;
-            if (a.status) a.status[w] = a.debug ? (st | (wk[tid].pad << 8)) : st;
+            if (a.status) a.status[w] = a.debug ? (st | (wk[j].pad << 8)) : st;
         }
     }
+    STAMP(6);
 }
 
 // modified_blackbody.__init__ + max_wave for n rows, one lane per row.
 template <bool OPTHIN, bool NOALPHA>
-__global__ void k_prologue(const double *pars, int n, double wavenorm, int want_peak,
-                           double *out, int32_t *status, WalkerK *wk_out)
+__global__ void k_prologue(const double *pars, int n, double wavenorm, double lnunorm,
+                           int want_peak, double *out, int32_t *status, WalkerK *wk_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double T = pars[i * 5 + 0], beta = pars[i * 5 + 1], lambda0 = pars[i * 5 + 2],
                  alpha = pars[i * 5 + 3], fnorm = pars[i * 5 + 4];
     SedScalars s;
-    int st = sed_prologue<OPTHIN, NOALPHA>(T, beta, lambda0, alpha, fnorm, wavenorm, s);
+    const double p5[5] = {T, beta, lambda0, alpha, fnorm};
+    int st = ROW_NONFINITE;
+    if (finite5(p5))
+        st = sed_prologue<OPTHIN, NOALPHA>(T, beta, lambda0, alpha, fnorm, wavenorm, lnunorm, s);
+    else
+        s.normfac = s.xmerge = s.kappa = s.x0 = s.hcokt = __builtin_nan("");
     const double nan = __builtin_nan("");
     double peak = nan;
     WalkerK k;
@@ -251,7 +305,7 @@ __global__ void k_sed_eval(const WalkerK *wk, const double *freq, int m, double 
     double r = __builtin_nan("");
     if (k.status == ROW_OK) {
         const double nu = freq[i];
-        r = fnu_sample<OPTHIN, NOALPHA>(k, nu, d_log(nu));
+        r = fnu_sample<OPTHIN, NOALPHA>(k, nu, m_log(nu));
     }
     out[(size_t)blockIdx.y * m + i] = r;
 }
@@ -266,10 +320,12 @@ __global__ void k_fnu_explicit(const double *freq, int n, double T, double beta,
     if (i >= n) return;
     SedScalars s;
     s.normfac = normfac; s.xmerge = xmerge; s.kappa = kappa; s.x0 = x0; s.hcokt = 0.0;
+    s.lhokt9 = kLog1e9HoK - m_log(T);
+    s.lx0 = OPTHIN ? 0.0 : m_log(x0);
     WalkerK k;
     make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
     const double nu = freq[i];
-    out[i] = fnu_sample<OPTHIN, NOALPHA>(k, nu, d_log(nu));
+    out[i] = fnu_sample<OPTHIN, NOALPHA>(k, nu, m_log(nu));
 }
 
 // ---------------------------------------------------------------------------
@@ -360,6 +416,7 @@ struct mbb_ctx {
     // options
     long opt_wpb = 0, opt_threads = 0, opt_zero_copy = 0, opt_seg_chunks = 4, opt_debug = 0;
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
+    unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
     ncclComm_t_ comm = nullptr;
     int nranks = 1, rank = 0;
@@ -573,27 +630,27 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
 // the lane-per-walker prologue over up to 64 walkers per 256-thread block.
 static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
 {
-    const long target_blocks = (long)c->cu_count * 8;
-    long w = (n + target_blocks - 1) / target_blocks;
+    // Small batches (an emcee half-step) are latency bound: one walker per
+    // workgroup with about one segment per wave, so the chip sees n workgroups.
+    // Once there are more walkers than CUs, 256-thread workgroups; beyond
+    // 8 workgroups per CU several walkers share a workgroup (lane-per-walker
+    // prologue amortised over up to 64 walkers).
+    const long cus = c->cu_count;
+    long w = (n + cus * 8 - 1) / (cus * 8);
     if (w < 1) w = 1;
     if (w > 64) w = 64;
     if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
     wpb = (int)w;
-    long units = (long)wpb * c->nseg;
-    long t;
-    if (wpb == 1) {
-        t = ((units + 3) / 4) * 64 * 4;        // about one segment per wave
-        if (t < 256) t = 256;
+    long t = 256;
+    if (wpb == 1 && n <= cus) {
+        t = (long)((c->nseg + 3) / 4) * 256;           // ~ one segment per wave
         if (t > 1024) t = 1024;
-        if (units <= 4) t = 256;
-    } else {
-        t = 256;
+        if (c->nseg <= 4) t = 256;
     }
     if (c->opt_threads > 0) t = c->opt_threads;
     if (t < 64) t = 64;
     if (t > 1024) t = 1024;
-    t = (t / 64) * 64;
-    threads = (int)t;
+    threads = (int)((t / 64) * 64);
 }
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -607,6 +664,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     a.seg_c0 = c->d_seg_c0; a.band_s0 = c->d_band_s0;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
     a.nb = c->nb; a.nseg = c->nseg; a.wavenorm = c->wavenorm;
+    a.lnunorm = log(kUmToGHz / c->wavenorm);
     for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
     for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
     a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
@@ -615,8 +673,12 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     pick_geometry(c, n, wpb, threads);
     a.wpb = wpb;
     a.debug = (int)c->opt_debug;
+#ifdef MBB_STAMPS
+    a.stamps = c->d_stamps;
+#endif
     const int grid = (n + wpb - 1) / wpb;
-    const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16);
+    const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16) +
+                        8 * (size_t)c->nb * (2 + (c->has_cov ? c->nb : 0)) + 4 * ((size_t)c->nb + 2);
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)smem;
     void (*kern)(const LikeArgs);
@@ -731,8 +793,9 @@ static int run_prologue(mbb_ctx *c, const double *pars, int n, int opthin, int n
     const int threads = 64, grid = (n + threads - 1) / threads;
     dispatch_variant(opthin, noalpha, [&](auto OT, auto NA) {
         hipLaunchKernelGGL((k_prologue<decltype(OT)::value, decltype(NA)::value>), dim3(grid),
-                           dim3(threads), 0, c->stream, c->d_sed_pars, n, wavenorm, want_peak,
-                           d_out6, c->d_sed_status, c->d_sed_wk);
+                           dim3(threads), 0, c->stream, c->d_sed_pars, n, wavenorm,
+                           log(kUmToGHz / wavenorm), want_peak, d_out6, c->d_sed_status,
+                           c->d_sed_wk);
     });
     HIPCHK(hipGetLastError());
     return MBB_OK;
@@ -879,6 +942,23 @@ extern "C" int mbb_event_destroy(mbb_ctx *c, void *ev)
     HIPCHK(hipEventDestroy((hipEvent_t)ev));
     return MBB_OK;
 }
+
+#ifdef MBB_STAMPS
+extern "C" int mbb_stamps(mbb_ctx *c, unsigned long long *host, int nblocks)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!c->d_stamps) {
+        HIPCHK(hipMalloc((void **)&c->d_stamps, 8 * sizeof(unsigned long long) * 65536));
+        HIPCHK(hipMemset(c->d_stamps, 0, 8 * sizeof(unsigned long long) * 65536));
+    }
+    if (host) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(host, c->d_stamps, 8 * sizeof(unsigned long long) * nblocks, hipMemcpyDeviceToHost));
+    }
+    return MBB_OK;
+}
+#endif
 
 extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
 {

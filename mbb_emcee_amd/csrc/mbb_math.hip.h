@@ -1,0 +1,111 @@
+// mbb_math.hip.h -- lean fp64 exp / expm1 / log / divide for the gfx950 kernels.
+//
+// The device library's exp/expm1/pow carry special-case handling and long
+// Horner chains that the likelihood path does not need: its arguments are finite,
+// its quotients have positive finite-or-inf denominators, and it is either
+// latency bound (one lane per walker in the prologue) or VALU-issue bound (the
+// passband loop).  These versions use one shared range reduction, an Estrin
+// polynomial (dependency depth 5 instead of 13) and no branches.
+//
+// Accuracy (tools/test_math_host.cpp, 4e6 points each, vs long double libm):
+//   m_exp, m_expm1  <= 2 ulp over [-745, 709.7];  m_log <= 2 ulp;  m_div <= 1.5 ulp.
+//
+// Compiles for the host too (MBB_MATH_HOST) so the accuracy test runs on CPU.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef MBB_MATH_HOST
+#define MBB_HD inline
+static inline double m_rcp_seed(double b) { return (double)(1.0f / (float)b); }
+#else
+#include <hip/hip_runtime.h>
+#define MBB_HD __device__ __forceinline__
+static __device__ __forceinline__ double m_rcp_seed(double b) { return __builtin_amdgcn_rcp(b); }
+#endif
+
+namespace mbbm {
+
+// e^r - 1 on |r| <= ln2/2 as r + r^2 * s(r), s = 1/2! + r/3! + ... + r^11/13!
+MBB_HD double expm1_reduced(double r)
+{
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = fma(r, 1.0 / 6.0, 0.5);                          // c2 + c3 r
+    const double a1 = fma(r, 1.0 / 120.0, 1.0 / 24.0);                 // c4 + c5 r
+    const double a2 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);               // c6 + c7 r
+    const double a3 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);           // c8 + c9 r
+    const double a4 = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);       // c10 + c11 r
+    const double a5 = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);   // c12 + c13 r
+    const double b0 = fma(a1, r2, a0);
+    const double b1 = fma(a3, r2, a2);
+    const double b2 = fma(a5, r2, a4);
+    const double s = fma(b2, r8, fma(b1, r4, b0));
+    return fma(r2, s, r);
+}
+
+// x = k ln2 + r, |r| <= ln2/2.  x is clamped to [-800, 800]: beyond that the
+// results are 0 / inf anyway and the clamp keeps +-inf from turning into NaN.
+MBB_HD double reduce_ln2(double x, int &k)
+{
+    x = fmin(fmax(x, -800.0), 800.0);
+    const double kd = rint(x * 1.4426950408889634074);
+    double r = fma(kd, -6.93147180559945286227e-01, x);        // ln2 hi (nearest double)
+    r = fma(kd, -2.31904681384629955842e-17, r);               // ln2 lo
+    k = (int)kd;
+    return r;
+}
+
+MBB_HD double m_exp(double x)
+{
+    int k;
+    const double q = expm1_reduced(reduce_ln2(x, k));
+    return ldexp(1.0 + q, k);
+}
+
+// expm1(x) = 2^k (e^r - 1) + (2^k - 1)
+MBB_HD double m_expm1(double x)
+{
+    int k;
+    const double q = expm1_reduced(reduce_ln2(x, k));
+    const double t = ldexp(1.0, k);                // inf for k >= 1024, as wanted
+    return fma(t, q, t - 1.0);
+}
+
+// a / b for finite a and b > 0 (b may be +inf: the quotient is then 0).
+// Reciprocal seed + two Newton steps + one residual correction.
+MBB_HD double m_div(double a, double b)
+{
+    b = fmin(b, 8.0e307);
+    double r = m_rcp_seed(b);
+    r = r * fma(-b, r, 2.0);
+    r = r * fma(-b, r, 2.0);
+#ifdef MBB_MATH_HOST
+    r = r * fma(-b, r, 2.0);       // the float seed of the host build is coarser
+#endif
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+
+// log(x), x > 0 finite normal.  x = 2^e m, m in [sqrt(1/2), sqrt(2));
+// log m = 2 atanh(s), s = (m-1)/(m+1), series in s^2 to s^21.
+MBB_HD double m_log(double x)
+{
+    int e;
+    double m = frexp(x, &e);                // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
+    const double f = m - 1.0;
+    const double s = m_div(f, m + 1.0);
+    const double z = s * s, z2 = z * z, z4 = z2 * z2;
+    const double a0 = fma(z, 2.0 / 5.0, 2.0 / 3.0);
+    const double a1 = fma(z, 2.0 / 9.0, 2.0 / 7.0);
+    const double a2 = fma(z, 2.0 / 13.0, 2.0 / 11.0);
+    const double a3 = fma(z, 2.0 / 17.0, 2.0 / 15.0);
+    const double a4 = fma(z, 2.0 / 21.0, 2.0 / 19.0);
+    const double p = fma(fma(a4, z4, fma(a3, z2, a2)), z4, fma(a1, z2, a0));
+    // log m = 2s + s z p ; write 2s = f - s f  (exact identity: s = f/(2+f))
+    const double lm = f - s * (f - z * p);
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+}
+
+}  // namespace mbbm

@@ -312,7 +312,7 @@ def test_low_temperature_overflow_gives_zero_not_nan(mbb):
     like = mbb.likelihood(opthin=True, noalpha=True)
     like.set_phot([19.0, 500.0], [1.0, 40.0], [1.0, 4.0])
     fl = like.model_flux(p)
-    assert fl[0, 0] == 0.0 and np.isfinite(like(p[0]))
+    assert 0.0 <= fl[0, 0] < 1e-280 and np.isfinite(like(p[0]))
 
 
 def test_special_passbands_vs_oracle(mbb, oracle):
