@@ -100,6 +100,25 @@ int mbb_lnlike_batch_device(mbb_ctx *ctx, const double *d_pars, int n,
 int mbb_lnlike_repeat_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
                              int32_t *d_status, int reps);
 
+/* ---- device-resident ensemble sampler ------------------------------------- */
+/* Replaces: emcee.EnsembleSampler(nwalkers, 5, like).run_mcmc(p0, nsteps) as
+ * driven by mbb_fitter.run (mbb_fit.py:80-81, :533, :542): the affine-invariant
+ * stretch move (Goodman & Weare 2010) with the proposal, the fused likelihood
+ * and the accept/reject step of a half-ensemble in ONE kernel launch, 2 nsteps
+ * dependent launches per call and no host round trip in between.  emcee is not
+ * part of the reference tree, so parity is statistical.
+ * chain [nw][nsteps][5] and lnprob [nw][nsteps] use emcee's layout
+ * (results.py:154-155).  "Fixed" parameters work as in the reference: a column
+ * of p0 with zero scatter is preserved exactly by the stretch move
+ * (mbb_fit.py:442-443). */
+int mbb_sampler_create(mbb_ctx *ctx, int nwalkers, unsigned long long seed, void **sampler);
+int mbb_sampler_destroy(mbb_ctx *ctx, void *sampler);
+int mbb_sampler_reset(mbb_ctx *ctx, void *sampler);          /* zero the acceptance counts */
+int mbb_sampler_set_state(mbb_ctx *ctx, void *sampler, const double *pos, const double *lnprob);
+int mbb_sampler_run(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a, double *chain,
+                    double *lnprob, double *pos_out, double *lnprob_out, double *naccepted);
+int mbb_sampler_advance_async(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a);
+
 /* ---- SED-level entry points (parity + the modified_blackbody class) ----- */
 /* Replaces: modified_blackbody.__init__ (modified_blackbody.py:168-337) and
  * max_wave (:581-637) for n parameter rows.
@@ -148,6 +167,10 @@ int mbb_comm_init(mbb_ctx *ctx, int nranks, int rank, const char id[128]);
 int mbb_comm_destroy(mbb_ctx *ctx);
 /* every rank contributes count doubles; d_recv holds nranks*count, rank-major */
 int mbb_allgather_f64(mbb_ctx *ctx, const double *d_send, double *d_recv, int count);
+/* one sharded half-step: fused kernel on this rank's n rows, then the all-gather
+ * of their lnprob into d_all [nranks*n]; asynchronous on the context's stream */
+int mbb_lnlike_allgather_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
+                                int32_t *d_status, double *d_all);
 
 #ifdef __cplusplus
 }

@@ -9,8 +9,9 @@ from .response import response, response_set, special_types
 from .modified_blackbody import modified_blackbody
 from .likelihood import likelihood
 from .ensemble import EnsembleSampler
+from .device_sampler import DeviceEnsembleSampler
 from .mbb_fit import mbb_fitter
 
 __version__ = "0.1.0"
 __all__ = ["response", "response_set", "modified_blackbody", "likelihood",
-           "EnsembleSampler", "mbb_fitter"]
+           "EnsembleSampler", "DeviceEnsembleSampler", "mbb_fitter"]

@@ -32,6 +32,12 @@ SIGNATURES = {
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
     "mbb_lnlike_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "mbb_lnlike_repeat_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int]),
+    "mbb_sampler_create": (C.c_int, [_vp, C.c_int, C.c_ulonglong, C.POINTER(_vp)]),
+    "mbb_sampler_destroy": (C.c_int, [_vp, _vp]),
+    "mbb_sampler_reset": (C.c_int, [_vp, _vp]),
+    "mbb_sampler_set_state": (C.c_int, [_vp, _vp, _dp, _dp]),
+    "mbb_sampler_run": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]),
+    "mbb_sampler_advance_async": (C.c_int, [_vp, _vp, C.c_int, C.c_double]),
     "mbb_sed_prologue_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_int, _dp, _ip]),
     "mbb_sed_eval_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp,
@@ -53,6 +59,7 @@ SIGNATURES = {
     "mbb_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "mbb_comm_destroy": (C.c_int, [_vp]),
     "mbb_allgather_f64": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "mbb_lnlike_allgather_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
 }
 
 
@@ -280,6 +287,11 @@ class Context(object):
 
     def comm_destroy(self):
         _check(self.lib.mbb_comm_destroy(self.h))
+
+    def lnlike_allgather_device(self, d_pars, n, d_lnl, d_status, d_all):
+        _check(self.lib.mbb_lnlike_allgather_device(
+            self.h, d_pars.ptr, int(n), d_lnl.ptr,
+            d_status.ptr if d_status is not None else None, d_all.ptr))
 
     def allgather_f64(self, d_send, d_recv, count):
         _check(self.lib.mbb_allgather_f64(

@@ -56,7 +56,31 @@ struct LikeArgs {
 #ifdef MBB_STAMPS
     unsigned long long *stamps;   // diagnostic build only: [grid*8] s_memtime values
 #endif
+    // ---- stretch-move half-step (SAMPLER instantiation only) ----------------
+    // State rows are (T, beta, lambda0, alpha, fnorm, lnprob).  This launch moves
+    // rows [s_begin, s_begin + n) using partners drawn from [c_begin, c_begin + c_count).
+    double *pos6;             // [nw*6]
+    double *chain6;           // [nsteps*nw*6] or nullptr; written at step `step`
+    unsigned int *nacc;       // [nw] accepted moves
+    int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
+    int s_begin, c_begin, c_count, nw;
+    int step, half;
+    double stretch_a;
+    unsigned long long seed;
 };
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (row, 2 step + half), key = seed.
+__device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, unsigned int k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned int hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned int n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
 
 // Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
 //   phase 1: lane-per-walker prologue (wave 0)            -> LDS
@@ -65,7 +89,7 @@ struct LikeArgs {
 //   phase 3: band sums in fixed order, then one lane per walker forms lnL
 // Summation order depends only on the band tables, never on the batch, so a
 // walker's result is bitwise independent of which launch / GPU evaluates it.
-template <bool OPTHIN, bool NOALPHA>
+template <bool OPTHIN, bool NOALPHA, bool SAMPLER>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -81,6 +105,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_ivar = s_flux + nb;                           // [nb]
     double *s_invcov = s_ivar + nb;                         // [nb*nb] when a.invcov
     int *s_band = reinterpret_cast<int *>(s_invcov + (a.invcov ? (size_t)nb * nb : 0));  // [nb+1]
+    // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
+    double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
     const int w0 = blockIdx.x * W;
 #ifdef MBB_STAMPS
 #define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -119,8 +145,36 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         double pen_u = 0.0, pen_g = 0.0;
         if (w < a.n) {
             double p[5];
+            if (SAMPLER) {
+                // stretch move (Goodman & Weare 2010; what emcee does per half-step,
+                // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
+                // half, proposal q = c - z (c - s)
+                const int row = a.s_begin + w;
+                unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * a.step + a.half), 0u, 0u};
+                philox4x32(c4, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
+                const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) *
+                                  (1.0 / 9007199254740992.0);
+                const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
+                const double u3 = ((double)c4[3] + 0.5) * (1.0 / 4294967296.0);
+                const double sq = (a.stretch_a - 1.0) * u1 + 1.0;
+                const double zz = sq * sq / a.stretch_a;
+                int pj = (int)(u2 * (double)a.c_count);
+                if (pj >= a.c_count) pj = a.c_count - 1;
+                const double *srow = a.pos6 + (size_t)row * 6;
+                const double *crow = a.pos6 + (size_t)(a.c_begin + pj) * 6;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
+                for (int i = 0; i < 5; ++i) {
+                    const double cv = crow[i], sv = srow[i];
+                    p[i] = cv - zz * (cv - sv);
+                    prop[tid * 8 + i] = p[i];
+                }
+                prop[tid * 8 + 5] = 4.0 * m_log(zz);          // (dim - 1) ln z, dim = 5
+                prop[tid * 8 + 6] = srow[5];
+                prop[tid * 8 + 7] = m_log(u3);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
+            }
             bool ok = true;                                   // likelihood.py:643-670
 #pragma unroll
             for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
@@ -247,7 +301,29 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 r += pen[2 * j];                               // :828
                 if (a.has_gprior) r += pen[2 * j + 1];         // :830-831
             }
-            a.lnl[w] = r;
+            if (SAMPLER) {
+                // accept with probability min(1, z^(dim-1) P(q)/P(s))
+                const int row = a.s_begin + w;
+                double *srow = a.pos6 + (size_t)row * 6;
+                const double *q = prop + j * 8;
+                if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
+                const bool accept = (q[5] + r - q[6]) > q[7];
+                if (accept) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) srow[i] = q[i];
+                    srow[5] = r;
+                    a.nacc[row] += 1u;
+                }
+                if (a.chain6) {
+                    double *crow = a.chain6 + ((size_t)a.step * a.nw + row) * 6;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
+                    crow[5] = accept ? r : q[6];
+                }
+                if (a.lnl) a.lnl[w] = r;
+            } else {
+                a.lnl[w] = r;
+            }
             if (a.status) a.status[w] = a.debug ? (st | (wk[j].pad << 8)) : st;
         }
     }
@@ -653,8 +729,17 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     threads = (int)((t / 64) * 64);
 }
 
+struct SamplerLaunch {
+    double *pos6, *chain6;
+    unsigned int *nacc;
+    int *errflag;
+    int s_begin, c_begin, c_count, nw, step, half;
+    double stretch_a;
+    unsigned long long seed;
+};
+
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
-                         int32_t *d_status, double *d_mflux)
+                         int32_t *d_status, double *d_mflux, const SamplerLaunch *sl = nullptr)
 {
     if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
     if (c->data_nb != c->nb) return fail(MBB_ERR_STATE, "data not set or band count mismatch");
@@ -678,12 +763,24 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
 #endif
     const int grid = (n + wpb - 1) / wpb;
     const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16) +
-                        8 * (size_t)c->nb * (2 + (c->has_cov ? c->nb : 0)) + 4 * ((size_t)c->nb + 2);
+                        8 * (size_t)c->nb * (2 + (c->has_cov ? c->nb : 0)) + 4 * ((size_t)c->nb + 4) +
+                        64 * (size_t)wpb;
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)smem;
     void (*kern)(const LikeArgs);
-    if (c->opthin) kern = c->noalpha ? k_lnlike<true, true> : k_lnlike<true, false>;
-    else kern = c->noalpha ? k_lnlike<false, true> : k_lnlike<false, false>;
+    if (sl) {
+        a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
+        a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
+        a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
+        if (c->opthin) kern = c->noalpha ? k_lnlike<true, true, true> : k_lnlike<true, false, true>;
+        else kern = c->noalpha ? k_lnlike<false, true, true> : k_lnlike<false, false, true>;
+    } else {
+        a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
+        a.s_begin = a.c_begin = a.c_count = a.nw = a.step = a.half = 0;
+        a.stretch_a = 2.0; a.seed = 0;
+        if (c->opthin) kern = c->noalpha ? k_lnlike<true, true, false> : k_lnlike<true, false, false>;
+        else kern = c->noalpha ? k_lnlike<false, true, false> : k_lnlike<false, false, false>;
+    }
     if (smem > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)smem));
@@ -750,6 +847,178 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
     memcpy(lnl, c->h_lnl, (size_t)n * sizeof(double));
     if (status) memcpy(status, c->h_status, (size_t)n * sizeof(int32_t));
     if (model_flux) memcpy(model_flux, c->h_mflux, (size_t)n * c->nb * sizeof(double));
+    return MBB_OK;
+}
+
+// ---- device-resident ensemble sampler ----------------------------------------
+struct mbb_sampler_state {
+    int nw = 0;
+    double *d_pos6 = nullptr;
+    unsigned int *d_nacc = nullptr;
+    int *d_err = nullptr;
+    double *d_chain6 = nullptr;
+    size_t chain_cap = 0;
+    unsigned long long seed = 0, steps_done = 0;
+};
+
+extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long seed, void **out)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!out || nwalkers < 2 || (nwalkers & 1)) return fail(MBB_ERR_ARG, "nwalkers must be even");
+    mbb_sampler_state *s = new mbb_sampler_state();
+    s->nw = nwalkers;
+    s->seed = seed;
+    HIPCHK(hipMalloc((void **)&s->d_pos6, (size_t)nwalkers * 6 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&s->d_nacc, (size_t)nwalkers * sizeof(unsigned int)));
+    HIPCHK(hipMalloc((void **)&s->d_err, sizeof(int)));
+    HIPCHK(hipMemset(s->d_nacc, 0, (size_t)nwalkers * sizeof(unsigned int)));
+    HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+    *out = s;
+    return MBB_OK;
+}
+
+extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    mbb_sampler_state *s = (mbb_sampler_state *)sp;
+    if (!s) return MBB_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    free_dev(s->d_pos6); free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6);
+    delete s;
+    return MBB_OK;
+}
+
+extern "C" int mbb_sampler_reset(mbb_ctx *c, void *sp)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    mbb_sampler_state *s = (mbb_sampler_state *)sp;
+    if (!s) return fail(MBB_ERR_ARG, "null sampler");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemset(s->d_nacc, 0, (size_t)s->nw * sizeof(unsigned int)));
+    HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+    return MBB_OK;
+}
+
+// Set the ensemble: pos [nw*5]; lnprob [nw] or NULL (then evaluated on the device).
+extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, const double *lnprob)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    mbb_sampler_state *s = (mbb_sampler_state *)sp;
+    if (!s || !pos) return fail(MBB_ERR_ARG, "null argument");
+    const int nw = s->nw;
+    std::vector<double> lnp(nw);
+    if (lnprob) {
+        for (int i = 0; i < nw; ++i) lnp[i] = lnprob[i];
+    } else {
+        std::vector<int32_t> st(nw);
+        if ((rc = mbb_lnlike_batch(c, pos, nw, lnp.data(), st.data(), nullptr))) return rc;
+        for (int i = 0; i < nw; ++i)
+            if (st[i] >= 2) return fail(MBB_ERR_ARG, "initial position is not a valid SED or lnprob is NaN");
+    }
+    std::vector<double> rows((size_t)nw * 6);
+    for (int i = 0; i < nw; ++i) {
+        for (int k = 0; k < 5; ++k) rows[(size_t)i * 6 + k] = pos[(size_t)i * 5 + k];
+        rows[(size_t)i * 6 + 5] = lnp[i];
+        if (lnp[i] != lnp[i]) return fail(MBB_ERR_ARG, "initial lnprob is NaN");
+    }
+    HIPCHK(hipMemcpyAsync(s->d_pos6, rows.data(), rows.size() * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+
+// Advance nsteps stretch-move steps entirely on the device: 2 nsteps dependent
+// launches on the context's stream, no host round trip in between.
+// chain [nw][nsteps][5] and lnprob [nw][nsteps] (emcee's layout, results.py:154-155)
+// may be NULL; pos_out [nw*5], lnprob_out [nw], naccepted [nw] (running totals).
+extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_a, double *chain,
+                               double *lnprob, double *pos_out, double *lnprob_out,
+                               double *naccepted)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    mbb_sampler_state *s = (mbb_sampler_state *)sp;
+    if (!s || nsteps < 0 || !(stretch_a > 1.0)) return fail(MBB_ERR_ARG, "bad sampler arguments");
+    const int nw = s->nw, half = nw / 2;
+    const bool store = chain || lnprob;
+    if (store && (size_t)nsteps * nw * 6 > s->chain_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(s->d_chain6); s->d_chain6 = nullptr; s->chain_cap = 0;
+        HIPCHK(hipMalloc((void **)&s->d_chain6, (size_t)nsteps * nw * 6 * sizeof(double)));
+        s->chain_cap = (size_t)nsteps * nw * 6;
+    }
+    SamplerLaunch sl;
+    sl.pos6 = s->d_pos6; sl.chain6 = store ? s->d_chain6 : nullptr; sl.nacc = s->d_nacc;
+    sl.errflag = s->d_err; sl.nw = nw; sl.stretch_a = stretch_a; sl.seed = s->seed;
+    for (int t = 0; t < nsteps; ++t) {
+        for (int h = 0; h < 2; ++h) {
+            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
+            sl.step = t; sl.half = h;
+            // the RNG counter runs over the whole life of the sampler, the chain index restarts
+            SamplerLaunch q = sl;
+            q.step = t;
+            q.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+            if ((rc = launch_lnlike(c, nullptr, half, nullptr, nullptr, nullptr, &q))) return rc;
+        }
+    }
+    s->steps_done += (unsigned long long)nsteps;
+    std::vector<double> rows((size_t)nw * 6);
+    std::vector<unsigned int> nacc(nw);
+    int err = 0;
+    HIPCHK(hipMemcpyAsync(rows.data(), s->d_pos6, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(nacc.data(), s->d_nacc, nacc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> ch;
+    if (store && nsteps > 0) {
+        ch.resize((size_t)nsteps * nw * 6);
+        HIPCHK(hipMemcpyAsync(ch.data(), s->d_chain6, ch.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (err) {
+        HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+        g_err = "lnprob returned NaN or the SED constructor rejected a proposal (row status " +
+                std::to_string(err) + ")";
+        return MBB_ERR_ARG;
+    }
+    for (int i = 0; i < nw; ++i) {
+        if (pos_out) for (int k = 0; k < 5; ++k) pos_out[(size_t)i * 5 + k] = rows[(size_t)i * 6 + k];
+        if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
+        if (naccepted) naccepted[i] = (double)nacc[i];
+    }
+    if (store)
+        for (int t = 0; t < nsteps; ++t)
+            for (int i = 0; i < nw; ++i) {
+                const double *r = &ch[((size_t)t * nw + i) * 6];
+                if (chain) for (int k = 0; k < 5; ++k) chain[((size_t)i * nsteps + t) * 5 + k] = r[k];
+                if (lnprob) lnprob[(size_t)i * nsteps + t] = r[5];
+            }
+    return MBB_OK;
+}
+
+// Measurement helper: enqueue nsteps steps without storing a chain and without
+// synchronising (HIP events around the call time the dependent launch train).
+extern "C" int mbb_sampler_advance_async(mbb_ctx *c, void *sp, int nsteps, double stretch_a)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    mbb_sampler_state *s = (mbb_sampler_state *)sp;
+    if (!s || nsteps < 0) return fail(MBB_ERR_ARG, "bad sampler arguments");
+    const int nw = s->nw, half = nw / 2;
+    SamplerLaunch sl;
+    sl.pos6 = s->d_pos6; sl.chain6 = nullptr; sl.nacc = s->d_nacc; sl.errflag = s->d_err;
+    sl.nw = nw; sl.stretch_a = stretch_a;
+    for (int t = 0; t < nsteps; ++t)
+        for (int h = 0; h < 2; ++h) {
+            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
+            sl.step = t; sl.half = h;
+            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+            if ((rc = launch_lnlike(c, nullptr, half, nullptr, nullptr, nullptr, &sl))) return rc;
+        }
+    s->steps_done += (unsigned long long)nsteps;
     return MBB_OK;
 }
 
@@ -1031,6 +1300,22 @@ extern "C" int mbb_comm_destroy(mbb_ctx *c)
     c->nranks = 1;
     c->rank = 0;
     return MBB_OK;
+}
+
+extern "C" int mbb_allgather_f64(mbb_ctx *c, const double *d_send, double *d_recv, int count);
+
+// One sharded half-step in one call: this rank's n walkers through the fused
+// kernel, then the all-gather of their log-probabilities, both on the context's
+// stream.  d_all holds nranks*n doubles, rank-major; d_lnl is this rank's slice
+// of d_all (in-place all-gather) or a separate buffer.
+extern "C" int mbb_lnlike_allgather_device(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
+                                           int32_t *d_status, double *d_all)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || !d_pars || !d_lnl || !d_all) return fail(MBB_ERR_ARG, "bad batch buffers");
+    if ((rc = launch_lnlike(c, d_pars, n, d_lnl, d_status, nullptr))) return rc;
+    return mbb_allgather_f64(c, d_lnl, d_all, n);
 }
 
 extern "C" int mbb_allgather_f64(mbb_ctx *c, const double *d_send, double *d_recv, int count)

@@ -1,0 +1,148 @@
+"""Device-resident affine-invariant ensemble sampler.
+
+Plays the role of ``emcee.EnsembleSampler`` in the reference's fit driver
+(reference mbb_emcee/mbb_fit.py:80-81, :525-550; results.py:154-155) with the
+whole stretch-move step on the MI355X: for each half of the ensemble ONE kernel
+draws z and a partner for every walker (counter-based Philox RNG), forms the
+proposal, evaluates the fused likelihood and accepts or rejects in place.  A run
+of N steps is 2N dependent launches enqueued back to back; the host only sees
+the chain at the end.  emcee itself is not part of the reference tree, so parity
+with it is statistical.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from .ensemble import integrated_time
+
+__all__ = ["DeviceEnsembleSampler"]
+
+
+class DeviceEnsembleSampler(object):
+    """emcee-2.x-shaped API: run_mcmc, chain [nw, nsteps, 5], lnprobability
+    [nw, nsteps], flatchain, acceptance_fraction, acor, reset.
+
+    lnpostfn must be this package's ``likelihood`` (it owns the device context
+    and the constant block the kernel reads)."""
+
+    def __init__(self, nwalkers, dim, lnpostfn, a=2.0, threads=1, seed=None, **unused):
+        if dim != 5:
+            raise ValueError("the modified blackbody model has 5 parameters")
+        if nwalkers % 2 != 0:
+            raise ValueError("The number of walkers must be even.")
+        if nwalkers < 2 * dim:
+            raise ValueError("The number of walkers needs to be more than twice the "
+                             "dimension of your parameter space.")
+        if not hasattr(lnpostfn, "_sync_device"):
+            raise TypeError("DeviceEnsembleSampler needs a mbb_emcee_amd.likelihood")
+        self.k, self.dim, self.a = int(nwalkers), 5, float(a)
+        self.lnprobfn = lnpostfn
+        self.seed = int(np.random.SeedSequence(seed).generate_state(1, dtype=np.uint64)[0]) \
+            if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._h = None
+        self._ctx = None
+        self.reset()
+
+    def _handle(self):
+        ctx = self.lnprobfn._sync_device()
+        if self._h is None or self._ctx is not ctx:
+            h = C.c_void_p()
+            _native._check(ctx.lib.mbb_sampler_create(ctx.h, self.k, self.seed, C.byref(h)))
+            self._h, self._ctx = h, ctx
+        return ctx, self._h
+
+    def reset(self):
+        self.naccepted = np.zeros(self.k)
+        self.iterations = 0
+        self._chain = np.empty((self.k, 0, self.dim))
+        self._lnprob = np.empty((self.k, 0))
+        self._last = None
+        if self._h is not None:
+            _native._check(self._ctx.lib.mbb_sampler_reset(self._ctx.h, self._h))
+
+    @property
+    def chain(self):
+        return self._chain
+
+    @property
+    def flatchain(self):
+        s = self._chain.shape
+        return self._chain.reshape(s[0] * s[1], s[2])
+
+    @property
+    def lnprobability(self):
+        return self._lnprob
+
+    @property
+    def flatlnprobability(self):
+        return self._lnprob.flatten()
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iterations, 1)
+
+    @property
+    def acor(self):
+        return self.get_autocorr_time()
+
+    def get_autocorr_time(self, c=5.0):
+        mean_chain = self._chain.mean(axis=0)
+        return np.array([integrated_time(mean_chain[:, i], c=c) for i in range(self.dim)])
+
+    @property
+    def random_state(self):
+        return self.seed
+
+    def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, storechain=True, **unused):
+        """N stretch-move steps from pos0 [nw, 5]; returns (pos, lnprob, rstate)."""
+        ctx, h = self._handle()
+        if pos0 is None:
+            if self._last is None:
+                raise ValueError("Cannot have pos0=None if run_mcmc has never been called.")
+        else:
+            p0 = np.ascontiguousarray(pos0, dtype=np.float64)
+            if p0.shape != (self.k, 5):
+                raise ValueError("p0 must have shape (nwalkers, 5)")
+            if np.any(np.isinf(p0)):
+                raise ValueError("At least one parameter value was infinite.")
+            if np.any(np.isnan(p0)):
+                raise ValueError("At least one parameter value was NaN.")
+            l0 = None if lnprob0 is None else np.ascontiguousarray(lnprob0, dtype=np.float64)
+            try:
+                _native._check(ctx.lib.mbb_sampler_set_state(
+                    ctx.h, h, _native._d(p0), _native._d(l0) if l0 is not None else None))
+            except _native.NativeError as e:
+                raise ValueError(str(e))
+        N = int(N)
+        chain = np.empty((self.k, N, 5)) if storechain else None
+        lnp = np.empty((self.k, N)) if storechain else None
+        pos = np.empty((self.k, 5))
+        lnprob = np.empty(self.k)
+        nacc = np.empty(self.k)
+        rc = ctx.lib.mbb_sampler_run(ctx.h, h, N, self.a,
+                                     _native._d(chain) if storechain else None,
+                                     _native._d(lnp) if storechain else None,
+                                     _native._d(pos), _native._d(lnprob), _native._d(nacc))
+        if rc == -2:
+            raise ValueError(ctx.lib.mbb_last_error().decode())
+        _native._check(rc)
+        self.iterations += N
+        self.naccepted = nacc
+        if storechain:
+            self._chain = np.concatenate((self._chain, chain), axis=1)
+            self._lnprob = np.concatenate((self._lnprob, lnp), axis=1)
+        self._last = (pos, lnprob)
+        return pos, lnprob, self.seed
+
+    def advance_async(self, N):
+        """Enqueue N steps without storing or synchronising (benchmarks)."""
+        ctx, h = self._handle()
+        _native._check(ctx.lib.mbb_sampler_advance_async(ctx.h, h, int(N), self.a))
+
+    def __del__(self):
+        try:
+            if self._h is not None and self._ctx is not None and self._ctx.h:
+                self._ctx.lib.mbb_sampler_destroy(self._ctx.h, self._h)
+        except Exception:
+            pass

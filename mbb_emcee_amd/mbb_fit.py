@@ -31,8 +31,11 @@ class mbb_fitter(object):
                  sampler="native"):
         """Keywords as mbb_fit.py:26-72.  nthreads is accepted and ignored: the
         walkers of a half-step are evaluated together on the GPU.
-        sampler="emcee" uses emcee.EnsembleSampler when that package is
-        installed (vectorised when it supports it, else through like.map)."""
+        sampler="native": host stretch move, one launch per half-step;
+        sampler="device": the whole stretch-move step runs on the GPU
+        (DeviceEnsembleSampler); sampler="emcee" uses emcee.EnsembleSampler when
+        that package is installed (vectorised when it supports it, else through
+        like.map)."""
         self._noalpha = noalpha
         self._opthin = opthin
         self._wavenorm = float(wavenorm)
@@ -42,7 +45,10 @@ class mbb_fitter(object):
                                wavenorm=wavenorm, noalpha=noalpha, opthin=opthin,
                                response=response, responsefile=responsefile,
                                responsedir=responsedir, device=device)
-        if sampler == "emcee":
+        if sampler == "device":
+            from .device_sampler import DeviceEnsembleSampler
+            self.sampler = DeviceEnsembleSampler(self._nwalkers, 5, self.like, seed=seed)
+        elif sampler == "emcee":
             import emcee
             try:
                 self.sampler = emcee.EnsembleSampler(self._nwalkers, 5, self.like,

@@ -101,8 +101,7 @@ class ShardedLikelihood(object):
             ctx = self.like._sync_device()
             d_pars, d_lnl, d_st, d_all = self.comm.buffers(per)
             d_pars.upload(local)
-            ctx.lnlike_batch_device(d_pars, per, d_lnl, d_st)
-            ctx.allgather_f64(d_lnl, d_all, per)
+            ctx.lnlike_allgather_device(d_pars, per, d_lnl, d_st, d_all)
             full = d_all.download(np.float64, world * per)
             st = d_st.download(np.int32, per)
             from . import _native
