@@ -98,6 +98,24 @@ def cpu_baseline(like, flux, pars):
             "single_thread_value": rate1}, ref[:250]
 
 
+def measured_traffic(kernel_substr):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed
+    rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of this same
+    command; tools/summarize_pmc.py).  bench.py cannot run the profiler on itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        for k, v in d["kernels"].items():
+            if kernel_substr in k:
+                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,8 +214,9 @@ def main():
         alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
         # exp-class ops per sample for thick+alpha on these walkers: count on the host
+        traffic, traffic_src = measured_traffic("k_lnlike<false, false, false>")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_lnlike<thick,alpha> n=125", "kernel_avg_us": k_us,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "samples_per_s_in_kernel": half * nq / (k_us * 1e-6),

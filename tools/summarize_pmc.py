@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (two
+separate passes, MI355X_MICROARCH.md 'rocprofv3 PMC slots') into a small JSON
+summary under profiles/.  Values are KB per dispatch as rocprofv3 reports them."""
+import csv, glob, json, sys
+import numpy as np
+
+def per_kernel(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            out.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: {"n": len(v), "median_KB": float(np.median(v)), "mean_KB": float(np.mean(v))} for k, v in out.items()}
+
+def main(fetch_dir, write_dir, out):
+    f = per_kernel(glob.glob(fetch_dir + "/*/*_counter_collection.csv")[0], "FETCH_SIZE")
+    w = per_kernel(glob.glob(write_dir + "/*/*_counter_collection.csv")[0], "WRITE_SIZE")
+    res = {"units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE = TCC_EA0_RDREQ x 64 B)",
+           "note": "gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; "
+                   "this kernel reads 8 B/lane, a width the guide leaves uncalibrated, so the "
+                   "figure is quoted uncorrected. Infinity-Cache hits are counted.",
+           "kernels": {}}
+    for k in f:
+        if "lnlike" in k:
+            res["kernels"][k] = {"FETCH_SIZE": f[k], "WRITE_SIZE": w.get(k),
+                                 "traffic_bytes_per_launch": 1024.0 * (f[k]["median_KB"] + (w[k]["median_KB"] if k in w else 0.0))}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
