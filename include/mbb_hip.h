@@ -73,6 +73,14 @@ int mbb_set_bands(mbb_ctx *ctx, const double *freq, const double *weight,
  * is_cov == 0: w is ivar[nb] = 1/unc^2; is_cov != 0: w is inverse covariance [nb*nb]. */
 int mbb_set_data(mbb_ctx *ctx, const double *flux, const double *w, int nb, int is_cov);
 
+/* Batched multi-source mode (BASELINE.json configs[4]): nsrc independent SEDs
+ * observed through the same bands, flux / ivar [nsrc*nb] (diagonal errors).
+ * Afterwards a batch of n rows is read as nsrc groups of n/nsrc consecutive rows,
+ * group g being compared with source g's data.  The reference fits one source
+ * per process (likelihood.py:158-232 holds one flux vector); this is the same
+ * likelihood applied to many. */
+int mbb_set_data_multi(mbb_ctx *ctx, const double *flux, const double *ivar, int nb, int nsrc);
+
 /* Replaces: _lowlim / _has_uplim / _uplim (likelihood.py:73, :83-85, :227-229);
  * index 5 is the lambda_peak ghost parameter (likelihood.py:710-715). */
 int mbb_set_limits(mbb_ctx *ctx, const double lowlim[5], const int32_t has_uplim[6],
@@ -108,7 +116,9 @@ int mbb_lnlike_repeat_device(mbb_ctx *ctx, const double *d_pars, int n, double *
  * dependent launches per call and no host round trip in between.  emcee is not
  * part of the reference tree, so parity is statistical.
  * chain [nw][nsteps][5] and lnprob [nw][nsteps] use emcee's layout
- * (results.py:154-155).  "Fixed" parameters work as in the reference: a column
+ * (results.py:154-155).  After mbb_set_data_multi the sampler advances nsrc
+ * independent ensembles of nwalkers each in the same launches; every array then
+ * has a leading nsrc dimension.  "Fixed" parameters work as in the reference: a column
  * of p0 with zero scatter is preserved exactly by the stretch move
  * (mbb_fit.py:442-443). */
 int mbb_sampler_create(mbb_ctx *ctx, int nwalkers, unsigned long long seed, void **sampler);

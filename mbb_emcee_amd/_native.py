@@ -27,6 +27,7 @@ SIGNATURES = {
     "mbb_set_model": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double]),
     "mbb_set_bands": (C.c_int, [_vp, _dp, _dp, _ip, C.c_int]),
     "mbb_set_data": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
+    "mbb_set_data_multi": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
     "mbb_set_limits": (C.c_int, [_vp, _dp, _ip, _dp]),
     "mbb_set_gpriors": (C.c_int, [_vp, _ip, _dp, _dp]),
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
@@ -178,6 +179,11 @@ class Context(object):
             w = _f64(ivar)
             assert w.size == flux.size
             _check(self.lib.mbb_set_data(self.h, _d(flux), _d(w), flux.size, 0))
+
+    def set_data_multi(self, flux, ivar):
+        flux = _f64(flux); ivar = _f64(ivar)
+        assert flux.ndim == 2 and flux.shape == ivar.shape
+        _check(self.lib.mbb_set_data_multi(self.h, _d(flux), _d(ivar), flux.shape[1], flux.shape[0]))
 
     def set_limits(self, lowlim, has_uplim, uplim):
         ll = _f64(lowlim); hu = np.ascontiguousarray(has_uplim, dtype=np.int32); ul = _f64(uplim)

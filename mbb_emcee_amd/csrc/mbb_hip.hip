@@ -65,6 +65,10 @@ struct LikeArgs {
     int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
     int s_begin, c_begin, c_count, nw;
     int step, half;
+    // ---- independent sources sharing the band tables (cfg5): flux/ivar are
+    // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
+    // [nsrc][nw_src][6] and a launch covers nsrc * c_count walkers
+    int nsrc, rows_per_src, nw_src;
     double stretch_a;
     unsigned long long seed;
 };
@@ -149,7 +153,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // stretch move (Goodman & Weare 2010; what emcee does per half-step,
                 // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
                 // half, proposal q = c - z (c - s)
-                const int row = a.s_begin + w;
+                const int src = w / a.c_count, loc = w - src * a.c_count;
+                const int row = src * a.nw_src + a.s_begin + loc;
                 unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * a.step + a.half), 0u, 0u};
                 philox4x32(c4, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
                 const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) *
@@ -161,7 +166,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 int pj = (int)(u2 * (double)a.c_count);
                 if (pj >= a.c_count) pj = a.c_count - 1;
                 const double *srow = a.pos6 + (size_t)row * 6;
-                const double *crow = a.pos6 + (size_t)(a.c_begin + pj) * 6;
+                const double *crow = a.pos6 + (size_t)(src * a.nw_src + a.c_begin + pj) * 6;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const double cv = crow[i], sv = srow[i];
@@ -271,13 +276,20 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         double acc = 0.0;
         if (st == ROW_OK) {
             double *mf = mflux + (size_t)j * nb;
+            // data of this walker's source: LDS copy for one source, global for many
+            const double *fsrc = s_flux, *isrc = s_ivar;
+            if (a.nsrc > 1) {
+                const int src = SAMPLER ? (w / a.c_count) : (w / a.rows_per_src);
+                fsrc = a.flux + (size_t)src * nb;
+                isrc = a.ivar + (size_t)src * nb;
+            }
             for (int b = lane; b < nb; b += 64) {              // band fluxes, fixed order
                 double sum = 0.0;
                 for (int sg = s_band[b]; sg < s_band[b + 1]; ++sg) sum += partial[j * nseg + sg];
                 if (a.model_flux) a.model_flux[(size_t)w * nb + b] = sum;
-                const double d = s_flux[b] - sum;              // :821
+                const double d = fsrc[b] - sum;                // :821
                 if (a.invcov) mf[b] = d;
-                else acc = fma(d * d, s_ivar[b], acc);         // :825
+                else acc = fma(d * d, isrc[b], acc);           // :825
             }
             if (a.invcov) {                                    // :823
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -303,7 +315,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             }
             if (SAMPLER) {
                 // accept with probability min(1, z^(dim-1) P(q)/P(s))
-                const int row = a.s_begin + w;
+                const int src = w / a.c_count;
+                const int row = src * a.nw_src + a.s_begin + (w - src * a.c_count);
                 double *srow = a.pos6 + (size_t)row * 6;
                 const double *q = prop + j * 8;
                 if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
@@ -469,7 +482,7 @@ struct mbb_ctx {
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
     int32_t *d_seg_c0 = nullptr, *d_band_s0 = nullptr;
     // data
-    int data_nb = 0, has_cov = 0;
+    int data_nb = 0, has_cov = 0, nsrc = 1;
     double *d_flux = nullptr, *d_ivar = nullptr, *d_invcov = nullptr;
     // limits and priors (likelihood.py:73, :83-85 defaults)
     double lowlim[5] = {1, 0.1, 1, 0.1, 1e-3};
@@ -639,6 +652,24 @@ extern "C" int mbb_set_data(mbb_ctx *c, const double *flux, const double *w, int
     }
     c->has_cov = is_cov ? 1 : 0;
     c->data_nb = nb;
+    c->nsrc = 1;
+    return MBB_OK;
+}
+
+extern "C" int mbb_set_data_multi(mbb_ctx *c, const double *flux, const double *ivar, int nb, int nsrc)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!flux || !ivar || nb <= 0 || nsrc <= 0) return fail(MBB_ERR_ARG, "bad data");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<double> f(flux, flux + (size_t)nb * nsrc), iv(ivar, ivar + (size_t)nb * nsrc);
+    if ((rc = upload(&c->d_flux, f))) return rc;
+    if ((rc = upload(&c->d_ivar, iv))) return rc;
+    free_dev(c->d_invcov);
+    c->d_invcov = nullptr;
+    c->has_cov = 0;
+    c->data_nb = nb;
+    c->nsrc = nsrc;
     return MBB_OK;
 }
 
@@ -733,7 +764,7 @@ struct SamplerLaunch {
     double *pos6, *chain6;
     unsigned int *nacc;
     int *errflag;
-    int s_begin, c_begin, c_count, nw, step, half;
+    int s_begin, c_begin, c_count, nw, step, half, nw_src;
     double stretch_a;
     unsigned long long seed;
 };
@@ -767,8 +798,17 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                         64 * (size_t)wpb;
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)smem;
+    a.nsrc = c->nsrc;
+    a.rows_per_src = 0;
+    a.nw_src = 0;
+    if (c->nsrc > 1) {
+        if (n % c->nsrc != 0)
+            return fail(MBB_ERR_ARG, "row count must be a multiple of the number of sources");
+        a.rows_per_src = n / c->nsrc;
+    }
     void (*kern)(const LikeArgs);
     if (sl) {
+        a.nw_src = sl->nw_src;
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
@@ -852,13 +892,15 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
 
 // ---- device-resident ensemble sampler ----------------------------------------
 struct mbb_sampler_state {
-    int nw = 0;
+    int nw = 0;            // walkers per source
+    int nsrc = 1;          // independent ensembles advanced together
     double *d_pos6 = nullptr;
     unsigned int *d_nacc = nullptr;
     int *d_err = nullptr;
     double *d_chain6 = nullptr;
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
+    int rows() const { return nw * nsrc; }
 };
 
 extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long seed, void **out)
@@ -868,11 +910,13 @@ extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long s
     if (!out || nwalkers < 2 || (nwalkers & 1)) return fail(MBB_ERR_ARG, "nwalkers must be even");
     mbb_sampler_state *s = new mbb_sampler_state();
     s->nw = nwalkers;
+    s->nsrc = c->nsrc > 0 ? c->nsrc : 1;
     s->seed = seed;
-    HIPCHK(hipMalloc((void **)&s->d_pos6, (size_t)nwalkers * 6 * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&s->d_nacc, (size_t)nwalkers * sizeof(unsigned int)));
+    const size_t R = (size_t)s->rows();
+    HIPCHK(hipMalloc((void **)&s->d_pos6, R * 6 * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&s->d_nacc, R * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void **)&s->d_err, sizeof(int)));
-    HIPCHK(hipMemset(s->d_nacc, 0, (size_t)nwalkers * sizeof(unsigned int)));
+    HIPCHK(hipMemset(s->d_nacc, 0, R * sizeof(unsigned int)));
     HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
     *out = s;
     return MBB_OK;
@@ -897,30 +941,32 @@ extern "C" int mbb_sampler_reset(mbb_ctx *c, void *sp)
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s) return fail(MBB_ERR_ARG, "null sampler");
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemset(s->d_nacc, 0, (size_t)s->nw * sizeof(unsigned int)));
+    HIPCHK(hipMemset(s->d_nacc, 0, (size_t)s->rows() * sizeof(unsigned int)));
     HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
     return MBB_OK;
 }
 
-// Set the ensemble: pos [nw*5]; lnprob [nw] or NULL (then evaluated on the device).
+// Set the ensemble(s): pos [nsrc][nw][5]; lnprob [nsrc][nw] or NULL (then evaluated
+// on the device).
 extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, const double *lnprob)
 {
     int rc = use(c);
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || !pos) return fail(MBB_ERR_ARG, "null argument");
-    const int nw = s->nw;
-    std::vector<double> lnp(nw);
+    if (s->nsrc != c->nsrc) return fail(MBB_ERR_STATE, "number of sources changed since the sampler was made");
+    const int R = s->rows();
+    std::vector<double> lnp(R);
     if (lnprob) {
-        for (int i = 0; i < nw; ++i) lnp[i] = lnprob[i];
+        for (int i = 0; i < R; ++i) lnp[i] = lnprob[i];
     } else {
-        std::vector<int32_t> st(nw);
-        if ((rc = mbb_lnlike_batch(c, pos, nw, lnp.data(), st.data(), nullptr))) return rc;
-        for (int i = 0; i < nw; ++i)
+        std::vector<int32_t> st(R);
+        if ((rc = mbb_lnlike_batch(c, pos, R, lnp.data(), st.data(), nullptr))) return rc;
+        for (int i = 0; i < R; ++i)
             if (st[i] >= 2) return fail(MBB_ERR_ARG, "initial position is not a valid SED or lnprob is NaN");
     }
-    std::vector<double> rows((size_t)nw * 6);
-    for (int i = 0; i < nw; ++i) {
+    std::vector<double> rows((size_t)R * 6);
+    for (int i = 0; i < R; ++i) {
         for (int k = 0; k < 5; ++k) rows[(size_t)i * 6 + k] = pos[(size_t)i * 5 + k];
         rows[(size_t)i * 6 + 5] = lnp[i];
         if (lnp[i] != lnp[i]) return fail(MBB_ERR_ARG, "initial lnprob is NaN");
@@ -931,10 +977,30 @@ extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, co
     return MBB_OK;
 }
 
+static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store)
+{
+    const int nw = s->nw, half = nw / 2;
+    SamplerLaunch sl;
+    sl.pos6 = s->d_pos6; sl.chain6 = store ? s->d_chain6 : nullptr; sl.nacc = s->d_nacc;
+    sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw; sl.stretch_a = stretch_a;
+    for (int t = 0; t < nsteps; ++t)
+        for (int h = 0; h < 2; ++h) {
+            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
+            sl.step = t; sl.half = h;
+            // the RNG key advances over the whole life of the sampler, the chain index restarts
+            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+            int rc = launch_lnlike(c, nullptr, s->nsrc * half, nullptr, nullptr, nullptr, &sl);
+            if (rc) return rc;
+        }
+    s->steps_done += (unsigned long long)nsteps;
+    return MBB_OK;
+}
+
 // Advance nsteps stretch-move steps entirely on the device: 2 nsteps dependent
 // launches on the context's stream, no host round trip in between.
-// chain [nw][nsteps][5] and lnprob [nw][nsteps] (emcee's layout, results.py:154-155)
-// may be NULL; pos_out [nw*5], lnprob_out [nw], naccepted [nw] (running totals).
+// chain [nsrc*nw][nsteps][5] and lnprob [nsrc*nw][nsteps] (emcee's layout per
+// source, results.py:154-155) may be NULL; pos_out [nsrc*nw*5], lnprob_out,
+// naccepted [nsrc*nw] (running totals).
 extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_a, double *chain,
                                double *lnprob, double *pos_out, double *lnprob_out,
                                double *naccepted)
@@ -943,38 +1009,25 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0 || !(stretch_a > 1.0)) return fail(MBB_ERR_ARG, "bad sampler arguments");
-    const int nw = s->nw, half = nw / 2;
-    const bool store = chain || lnprob;
-    if (store && (size_t)nsteps * nw * 6 > s->chain_cap) {
+    if (s->nsrc != c->nsrc) return fail(MBB_ERR_STATE, "number of sources changed since the sampler was made");
+    const int R = s->rows();
+    const bool store = (chain || lnprob) && nsteps > 0;
+    if (store && (size_t)nsteps * R * 6 > s->chain_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         free_dev(s->d_chain6); s->d_chain6 = nullptr; s->chain_cap = 0;
-        HIPCHK(hipMalloc((void **)&s->d_chain6, (size_t)nsteps * nw * 6 * sizeof(double)));
-        s->chain_cap = (size_t)nsteps * nw * 6;
+        HIPCHK(hipMalloc((void **)&s->d_chain6, (size_t)nsteps * R * 6 * sizeof(double)));
+        s->chain_cap = (size_t)nsteps * R * 6;
     }
-    SamplerLaunch sl;
-    sl.pos6 = s->d_pos6; sl.chain6 = store ? s->d_chain6 : nullptr; sl.nacc = s->d_nacc;
-    sl.errflag = s->d_err; sl.nw = nw; sl.stretch_a = stretch_a; sl.seed = s->seed;
-    for (int t = 0; t < nsteps; ++t) {
-        for (int h = 0; h < 2; ++h) {
-            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
-            sl.step = t; sl.half = h;
-            // the RNG counter runs over the whole life of the sampler, the chain index restarts
-            SamplerLaunch q = sl;
-            q.step = t;
-            q.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
-            if ((rc = launch_lnlike(c, nullptr, half, nullptr, nullptr, nullptr, &q))) return rc;
-        }
-    }
-    s->steps_done += (unsigned long long)nsteps;
-    std::vector<double> rows((size_t)nw * 6);
-    std::vector<unsigned int> nacc(nw);
+    if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, store))) return rc;
+    std::vector<double> rows((size_t)R * 6);
+    std::vector<unsigned int> nacc(R);
     int err = 0;
     HIPCHK(hipMemcpyAsync(rows.data(), s->d_pos6, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(nacc.data(), s->d_nacc, nacc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     std::vector<double> ch;
-    if (store && nsteps > 0) {
-        ch.resize((size_t)nsteps * nw * 6);
+    if (store) {
+        ch.resize((size_t)nsteps * R * 6);
         HIPCHK(hipMemcpyAsync(ch.data(), s->d_chain6, ch.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -984,15 +1037,15 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
                 std::to_string(err) + ")";
         return MBB_ERR_ARG;
     }
-    for (int i = 0; i < nw; ++i) {
+    for (int i = 0; i < R; ++i) {
         if (pos_out) for (int k = 0; k < 5; ++k) pos_out[(size_t)i * 5 + k] = rows[(size_t)i * 6 + k];
         if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
         if (naccepted) naccepted[i] = (double)nacc[i];
     }
     if (store)
         for (int t = 0; t < nsteps; ++t)
-            for (int i = 0; i < nw; ++i) {
-                const double *r = &ch[((size_t)t * nw + i) * 6];
+            for (int i = 0; i < R; ++i) {
+                const double *r = &ch[((size_t)t * R + i) * 6];
                 if (chain) for (int k = 0; k < 5; ++k) chain[((size_t)i * nsteps + t) * 5 + k] = r[k];
                 if (lnprob) lnprob[(size_t)i * nsteps + t] = r[5];
             }
@@ -1007,19 +1060,7 @@ extern "C" int mbb_sampler_advance_async(mbb_ctx *c, void *sp, int nsteps, doubl
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0) return fail(MBB_ERR_ARG, "bad sampler arguments");
-    const int nw = s->nw, half = nw / 2;
-    SamplerLaunch sl;
-    sl.pos6 = s->d_pos6; sl.chain6 = nullptr; sl.nacc = s->d_nacc; sl.errflag = s->d_err;
-    sl.nw = nw; sl.stretch_a = stretch_a;
-    for (int t = 0; t < nsteps; ++t)
-        for (int h = 0; h < 2; ++h) {
-            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
-            sl.step = t; sl.half = h;
-            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
-            if ((rc = launch_lnlike(c, nullptr, half, nullptr, nullptr, nullptr, &sl))) return rc;
-        }
-    s->steps_done += (unsigned long long)nsteps;
-    return MBB_OK;
+    return sampler_enqueue(c, s, nsteps, stretch_a, false);
 }
 
 // ---- SED-level entry points -------------------------------------------------

@@ -42,21 +42,32 @@ class DeviceEnsembleSampler(object):
             if seed is None else int(seed) & 0xFFFFFFFFFFFFFFFF
         self._h = None
         self._ctx = None
+        self._ns = 1
         self.reset()
+
+    @property
+    def nsources(self):
+        return getattr(self.lnprobfn, "nsources", 1)
 
     def _handle(self):
         ctx = self.lnprobfn._sync_device()
+        if self._h is not None and self._ctx is ctx and self._ns != self.nsources:
+            ctx.lib.mbb_sampler_destroy(ctx.h, self._h)
+            self._h = None
         if self._h is None or self._ctx is not ctx:
+            self._ns = self.nsources
             h = C.c_void_p()
             _native._check(ctx.lib.mbb_sampler_create(ctx.h, self.k, self.seed, C.byref(h)))
             self._h, self._ctx = h, ctx
         return ctx, self._h
 
     def reset(self):
-        self.naccepted = np.zeros(self.k)
+        ns = self.nsources
+        lead = (ns, self.k) if ns > 1 else (self.k,)
+        self.naccepted = np.zeros(lead)
         self.iterations = 0
-        self._chain = np.empty((self.k, 0, self.dim))
-        self._lnprob = np.empty((self.k, 0))
+        self._chain = np.empty(lead + (0, self.dim))
+        self._lnprob = np.empty(lead + (0,))
         self._last = None
         if self._h is not None:
             _native._check(self._ctx.lib.mbb_sampler_reset(self._ctx.h, self._h))
@@ -68,6 +79,8 @@ class DeviceEnsembleSampler(object):
     @property
     def flatchain(self):
         s = self._chain.shape
+        if len(s) == 4:                       # [nsources, nw, nsteps, 5] -> [nsources, nw*nsteps, 5]
+            return self._chain.reshape(s[0], s[1] * s[2], s[3])
         return self._chain.reshape(s[0] * s[1], s[2])
 
     @property
@@ -87,7 +100,8 @@ class DeviceEnsembleSampler(object):
         return self.get_autocorr_time()
 
     def get_autocorr_time(self, c=5.0):
-        mean_chain = self._chain.mean(axis=0)
+        ch = self._chain if self._chain.ndim == 3 else self._chain[0]
+        mean_chain = ch.mean(axis=0)
         return np.array([integrated_time(mean_chain[:, i], c=c) for i in range(self.dim)])
 
     @property
@@ -102,8 +116,9 @@ class DeviceEnsembleSampler(object):
                 raise ValueError("Cannot have pos0=None if run_mcmc has never been called.")
         else:
             p0 = np.ascontiguousarray(pos0, dtype=np.float64)
-            if p0.shape != (self.k, 5):
-                raise ValueError("p0 must have shape (nwalkers, 5)")
+            want = (self.nsources, self.k, 5) if self.nsources > 1 else (self.k, 5)
+            if p0.shape != want:
+                raise ValueError("p0 must have shape {}".format(want))
             if np.any(np.isinf(p0)):
                 raise ValueError("At least one parameter value was infinite.")
             if np.any(np.isnan(p0)):
@@ -115,11 +130,12 @@ class DeviceEnsembleSampler(object):
             except _native.NativeError as e:
                 raise ValueError(str(e))
         N = int(N)
-        chain = np.empty((self.k, N, 5)) if storechain else None
-        lnp = np.empty((self.k, N)) if storechain else None
-        pos = np.empty((self.k, 5))
-        lnprob = np.empty(self.k)
-        nacc = np.empty(self.k)
+        lead = (self.nsources, self.k) if self.nsources > 1 else (self.k,)
+        chain = np.empty(lead + (N, 5)) if storechain else None
+        lnp = np.empty(lead + (N,)) if storechain else None
+        pos = np.empty(lead + (5,))
+        lnprob = np.empty(lead)
+        nacc = np.empty(lead)
         rc = ctx.lib.mbb_sampler_run(ctx.h, h, N, self.a,
                                      _native._d(chain) if storechain else None,
                                      _native._d(lnp) if storechain else None,
@@ -130,8 +146,9 @@ class DeviceEnsembleSampler(object):
         self.iterations += N
         self.naccepted = nacc
         if storechain:
-            self._chain = np.concatenate((self._chain, chain), axis=1)
-            self._lnprob = np.concatenate((self._lnprob, lnp), axis=1)
+            ax = len(lead)
+            self._chain = np.concatenate((self._chain, chain), axis=ax)
+            self._lnprob = np.concatenate((self._lnprob, lnp), axis=ax)
         self._last = (pos, lnprob)
         return pos, lnprob, self.seed
 

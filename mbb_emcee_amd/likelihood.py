@@ -59,6 +59,7 @@ class likelihood(object):
 
         self._data_read = False
         self._has_covmatrix = False
+        self._nsources = 1
         if photfile is not None:
             self.read_phot(photfile)
             if covfile is not None:
@@ -130,7 +131,28 @@ class likelihood(object):
             self._uplim[2] = 3.0 * self._wave.max()
         self._data_read = True
         self._has_covmatrix = False
+        self._nsources = 1
         self._dirty = True
+
+    def set_phot_multi(self, firstarg, flux, flux_unc):
+        """Batched multi-source mode: ``flux`` and ``flux_unc`` are [nsources, ndata]
+        arrays of independent SEDs observed through the same bands (``firstarg`` as
+        in set_phot).  Afterwards ``like(pars)`` takes [nsources, m, 5] (or the same
+        rows flattened) and returns [nsources, m]; row block g is compared with
+        source g.  Diagonal uncertainties only.  Limits and priors are shared."""
+        flux = np.asarray(flux, dtype=np.float64)
+        flux_unc = np.asarray(flux_unc, dtype=np.float64)
+        if flux.ndim != 2 or flux.shape != flux_unc.shape:
+            raise ValueError("flux and flux_unc must both be [nsources, ndata]")
+        self.set_phot(firstarg, flux[0], flux_unc[0])
+        self._flux_multi = flux
+        self._ivar_multi = 1.0 / flux_unc ** 2
+        self._nsources = flux.shape[0]
+        self._dirty = True
+
+    @property
+    def nsources(self):
+        return self._nsources
 
     def read_phot(self, filename):
         """Three-column text file: wavelength [um] (or passband name), flux,
@@ -332,7 +354,11 @@ class likelihood(object):
             raise Exception("Data not read, can't evaluate the likelihood")
         ctx.set_model(self._opthin, self._noalpha, self._wavenorm)
         ctx.set_bands(*self.band_tables())
-        if self._has_covmatrix:
+        if self._nsources > 1:
+            if self._has_covmatrix:
+                raise ValueError("multi-source mode supports diagonal uncertainties only")
+            ctx.set_data_multi(self._flux_multi, self._ivar_multi)
+        elif self._has_covmatrix:
             ctx.set_data(self._flux, invcov=self._invcovmatrix)
         else:
             ctx.set_data(self._flux, ivar=self._ivar)
@@ -384,8 +410,14 @@ class likelihood(object):
             lnl, st = self._sync_device().lnlike_batch(p[None, :])
             _native.raise_for_status(st)
             return float(lnl[0])
+        if p.ndim == 3 and p.shape[2] == 5 and p.shape[0] == self._nsources:
+            lnl, st = self._sync_device().lnlike_batch(p.reshape(-1, 5))
+            _native.raise_for_status(st)
+            return lnl.reshape(p.shape[0], p.shape[1])
         if p.ndim != 2 or p.shape[1] != 5:
             raise ValueError("pars is not of expected length 5")
+        if self._nsources > 1 and p.shape[0] % self._nsources != 0:
+            raise ValueError("in multi-source mode the rows must be nsources equal blocks")
         lnl, st = self._sync_device().lnlike_batch(p)
         _native.raise_for_status(st)
         return lnl

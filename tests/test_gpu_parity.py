@@ -521,3 +521,83 @@ def test_rccl_single_rank_allgather(mbb, g_lnl):
     sharded = ShardedLikelihood(like, comm)
     assert np.array_equal(sharded(g_lnl["cfg2/thick_walpha/pars"]), like(g_lnl["cfg2/thick_walpha/pars"]),
                           equal_nan=True)
+
+
+# --------------------------------------------- batched multi-source mode (cfg5)
+def _multi_setup(mbb, g_lnl, ns, seed=9):
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    rng = np.random.RandomState(seed)
+    truths = np.column_stack([rng.uniform(8, 20, ns), rng.uniform(1.2, 2.4, ns), rng.uniform(300, 900, ns),
+                              rng.uniform(2, 4.5, ns), rng.uniform(10, 80, ns)])
+    single = mbb.likelihood(response=True)
+    single.set_phot(bands, np.ones(8), np.ones(8))
+    flux = single.model_flux(truths)
+    unc = 0.1 * flux + 1.0
+    multi = mbb.likelihood(response=True)
+    multi.set_phot_multi(bands, flux, unc)
+    return bands, truths, flux, unc, multi
+
+
+def test_multi_source_equals_per_source_calls(mbb, g_lnl):
+    """Block g of a multi-source batch equals an ordinary single-source likelihood
+    built on source g's data, bit for bit."""
+    ns, m = 7, 33
+    bands, truths, flux, unc, multi = _multi_setup(mbb, g_lnl, ns)
+    rng = np.random.RandomState(1)
+    pars = truths[:, None, :] * (1.0 + 0.05 * rng.normal(size=(ns, m, 5)))
+    pars[2, 5, 0] = 0.3                                   # -inf row
+    got = multi(pars)
+    assert got.shape == (ns, m) and np.isneginf(got[2, 5])
+    assert np.array_equal(multi(pars.reshape(-1, 5)).reshape(ns, m), got)
+    for g in range(ns):
+        one = mbb.likelihood(response=True)
+        one.set_phot(bands, flux[g], unc[g])
+        one._uplim[2] = multi.uplims[2]; one._dirty = True     # shared limits: source 0's
+        assert np.array_equal(one(pars[g]), got[g])
+    with pytest.raises(ValueError):
+        multi(np.ones((ns * m + 1, 5)))
+
+
+def test_multi_source_device_sampler(mbb, g_lnl):
+    """Several independent ensembles advance in the same launches; each recovers
+    its own truth, and source g's chain equals the chain of a single-source
+    sampler given the same rows of the random stream."""
+    ns, nw = 6, 40
+    bands, truths, flux, unc, multi = _multi_setup(mbb, g_lnl, ns, seed=4)
+    rng = np.random.RandomState(2)
+    p0 = truths[:, None, :] * (1.0 + 0.02 * rng.normal(size=(ns, nw, 5)))
+    s = mbb.DeviceEnsembleSampler(nw, 5, multi, seed=99)
+    pos, lnp, _ = s.run_mcmc(p0, 120)
+    assert s.chain.shape == (ns, nw, 120, 5) and s.lnprobability.shape == (ns, nw, 120)
+    assert pos.shape == (ns, nw, 5) and s.naccepted.shape == (ns, nw)
+    lnl_close(multi(s.chain[:, :, -1, :]), s.lnprobability[:, :, -1])
+    acc = s.acceptance_fraction
+    assert np.all(acc.mean(axis=1) > 0.1) and np.all(acc.mean(axis=1) < 0.9)
+    # walkers of one source never mix with another's: the fnorm column stays near its truth
+    med = np.median(s.chain[:, :, 60:, 4].reshape(ns, -1), axis=1)
+    assert np.all(np.abs(med - truths[:, 4]) < 0.2 * truths[:, 4])
+    # one step against the host emulation, per source (rows are numbered src*nw + walker)
+    s2 = mbb.DeviceEnsembleSampler(nw, 5, multi, seed=5)
+    s2.run_mcmc(p0, 1)
+    half = nw // 2
+    for g in (0, ns - 1):
+        one = mbb.likelihood(response=True)
+        one.set_phot(bands, flux[g], unc[g])
+        one._uplim[2] = multi.uplims[2]; one._dirty = True
+        hp, hl = p0[g].copy(), one(p0[g])
+        key = (5 + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        for h in range(2):
+            s_begin, c_begin = (half, 0) if h else (0, half)
+            q = np.empty((half, 5)); lz = np.empty(half); lu = np.empty(half)
+            for w in range(half):
+                r = _philox4x32([g * nw + s_begin + w, h, 0, 0], key & 0xFFFFFFFF, key >> 32)
+                u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
+                zz = (u1 + 1.0) ** 2 / 2.0
+                pj = min(int(r[2] / 4294967296.0 * half), half - 1)
+                c, sv = hp[c_begin + pj], hp[s_begin + w]
+                q[w] = c - zz * (c - sv); lz[w] = 4 * np.log(zz); lu[w] = np.log((r[3] + 0.5) / 4294967296.0)
+            new = one(q)
+            for w in range(half):
+                if lz[w] + new[w] - hl[s_begin + w] > lu[w]:
+                    hp[s_begin + w] = q[w]; hl[s_begin + w] = new[w]
+        np.testing.assert_allclose(s2.chain[g, :, 0, :], hp, rtol=1e-13)
