@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--probe-reps", type=int, default=2000)
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the 250 000-walker launch")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -241,6 +242,39 @@ def main():
                    "us_per_step_stream": ctx.elapsed_ms(s0, s1) * 1e3 / ksteps, "steps": ksteps,
                    "note": "device-resident stretch move, 250 walkers, every half-step depends "
                            "on the previous one; no host round trip inside the run"}
+        # ---- cfg5 (BASELINE.json configs[4]): 1000 independent SEDs x 250 walkers in
+        # one launch -- the regime where the kernel is VALU-bound, not latency-bound
+        cfg5 = None
+        if not args.no_cfg5:
+            from tools.bench_cfg5 import setup as cfg5_setup
+            like5, _, p5 = cfg5_setup(1000, NW_PER_GPU)
+            c5 = like5._sync_device()
+            n5 = p5.shape[0] * p5.shape[1]
+            flat5 = np.ascontiguousarray(p5.reshape(-1, 5))
+            dp5 = c5.alloc(flat5.nbytes); dp5.upload(flat5)
+            dl5, ds5 = c5.alloc(n5 * 8), c5.alloc(n5 * 4)
+            c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 3); c5.sync()
+            q0, q1 = c5.event(), c5.event()
+            c5.record(q0); c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 10); c5.record(q1); c5.sync()
+            ms5 = c5.elapsed_ms(q0, q1) / 10
+            smp5 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like5, seed=3)
+            smp5.run_mcmc(p5, 3, storechain=False)
+            c5.sync(); t5 = time.perf_counter()
+            smp5.advance_async(20); c5.sync()
+            t5 = (time.perf_counter() - t5) / 20
+            flops5 = None
+            try:
+                flops5 = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_valu_cfg5.json")))["fp64_flops_per_launch"]
+            except Exception:
+                pass
+            cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
+                    "evals_per_launch": n5, "kernel_ms": ms5, "evals_per_s": n5 / ms5 * 1e3,
+                    "samples_per_s": n5 * nq / ms5 * 1e3,
+                    "sampler_ms_per_step": t5 * 1e3, "sampler_evals_per_s": n5 / t5,
+                    "fp64_tflops": (flops5 / (ms5 * 1e-3) / 1e12) if flops5 else None,
+                    "fp64_vector_peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                    "fp64_frac": (flops5 / (ms5 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if flops5 else None,
+                    "flops_source": "profiles/r01/pmc_valu_cfg5.json (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)"}
         out = {"metric": "walker-likelihood evals/sec, 250 walkers x 8 bands per GPU",
                "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -255,6 +289,7 @@ def main():
                "mcmc_steps_per_s": args.steps / elapsed,
                "stream_ms_per_step": stream_ms / args.steps,
                "device_sampler": sampler,
+               "cfg5": cfg5,
                "roofline": roof}
         if not args.no_cpu and world == 1:
             cb, ref = cpu_baseline(like, flux, pos)

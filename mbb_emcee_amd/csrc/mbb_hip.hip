@@ -745,7 +745,7 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     const long cus = c->cu_count;
     long w = (n + cus * 8 - 1) / (cus * 8);
     if (w < 1) w = 1;
-    if (w > 64) w = 64;
+    if (w > 16) w = 16;          // measured at 250 000 walkers: 16 beats 32 and 64
     if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
     wpb = (int)w;
     long t = 256;
