@@ -36,7 +36,7 @@ struct LikeArgs {
     const double *flux;       // [nb]
     const double *ivar;       // [nb]
     const double *invcov;     // [nb*nb] or nullptr
-    int nb, nseg;
+    int nb, nseg, nchunk;
     double wavenorm;
     double lnunorm;           // log(um_to_GHz / wavenorm)
     double lowlim[5];
@@ -93,7 +93,7 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 //   phase 3: band sums in fixed order, then one lane per walker forms lnL
 // Summation order depends only on the band tables, never on the batch, so a
 // walker's result is bitwise independent of which launch / GPU evaluates it.
-template <bool OPTHIN, bool NOALPHA, bool SAMPLER>
+template <bool OPTHIN, bool NOALPHA, bool SAMPLER, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -111,6 +111,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     int *s_band = reinterpret_cast<int *>(s_invcov + (a.invcov ? (size_t)nb * nb : 0));  // [nb+1]
     // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
     double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
+    // STAGE: the passband tables themselves (nu, log nu, weight), [nchunk*64] each
+    double *s_nu = reinterpret_cast<double *>(
+        (reinterpret_cast<uintptr_t>(prop + 8 * (size_t)W) + 15) & ~(uintptr_t)15);
+    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
+    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const int w0 = blockIdx.x * W;
 #ifdef MBB_STAMPS
 #define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -128,16 +133,28 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
         if (a.invcov)
             for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
-        const int u = wave;
-        if (u < W * nseg) {
-            const int s = u % nseg;
-            const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
-            double t = 0.0;
-            for (int c = c0; c < c1; ++c) {
-                const int i = c * 64 + lane;
-                t += a.nu[i] + a.lnnu[i] + a.wt[i];
+        if (STAGE) {
+            // passband tables -> LDS, 16 B per lane, while wave 0 is in the prologue
+            const int n2 = a.nchunk * 32;                      // double2 elements per array
+            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
+            const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
+            const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
+            double2 *l0 = reinterpret_cast<double2 *>(s_nu);
+            double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
+            double2 *l2 = reinterpret_cast<double2 *>(s_wt);
+            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        } else {
+            const int u = wave;
+            if (u < W * nseg) {
+                const int s = u % nseg;
+                const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
+                double t = 0.0;
+                for (int c = c0; c < c1; ++c) {
+                    const int i = c * 64 + lane;
+                    t += a.nu[i] + a.lnnu[i] + a.wt[i];
+                }
+                asm volatile("" ::"v"(t));
             }
-            asm volatile("" ::"v"(t));
         }
     }
 
@@ -239,6 +256,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 
     // ---- phase 2: passband quadrature (response.py:572-576) -----------------
     const int nunit = W * nseg;
+    auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
+    auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
+    auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     for (int u = wave; u < nunit; u += nwave) {
         const int j = u / nseg, s = u - j * nseg;
         if (wk[j].status != ROW_OK) continue;                 // wave-uniform
@@ -248,8 +268,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         int c = c0;
         for (; c + 2 <= c1; c += 2) {          // two independent chains in flight
             const int i0 = c * 64 + lane, i1 = i0 + 64;
-            const double n0 = a.nu[i0], l0 = a.lnnu[i0], q0 = a.wt[i0];
-            const double n1 = a.nu[i1], l1 = a.lnnu[i1], q1 = a.wt[i1];
+            const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+            const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
             const double f0 = fnu_sample<OPTHIN, NOALPHA>(k, n0, l0);
             const double f1 = fnu_sample<OPTHIN, NOALPHA>(k, n1, l1);
             acc = fma(f0, q0, acc);
@@ -257,8 +277,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         }
         if (c < c1) {
             const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA>(k, a.nu[i], a.lnnu[i]);
-            acc = fma(f, a.wt[i], acc);
+            const double f = fnu_sample<OPTHIN, NOALPHA>(k, T_nu(i), T_ln(i));
+            acc = fma(f, T_wt(i), acc);
         }
         acc = wave_sum(acc);
         if (lane == 0) partial[u] = acc;
@@ -504,6 +524,8 @@ struct mbb_ctx {
     WalkerK *d_sed_wk = nullptr;
     // options
     long opt_wpb = 0, opt_threads = 0, opt_zero_copy = 0, opt_seg_chunks = 4, opt_debug = 0;
+    long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
+    long last_stage = 0;
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -779,7 +801,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
     a.seg_c0 = c->d_seg_c0; a.band_s0 = c->d_band_s0;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
-    a.nb = c->nb; a.nseg = c->nseg; a.wavenorm = c->wavenorm;
+    a.nb = c->nb; a.nseg = c->nseg; a.nchunk = c->nchunk; a.wavenorm = c->wavenorm;
     a.lnunorm = log(kUmToGHz / c->wavenorm);
     for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
     for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
@@ -797,7 +819,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                         8 * (size_t)c->nb * (2 + (c->has_cov ? c->nb : 0)) + 4 * ((size_t)c->nb + 4) +
                         64 * (size_t)wpb;
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
-    c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)smem;
+    c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid;
     a.nsrc = c->nsrc;
     a.rows_per_src = 0;
     a.nw_src = 0;
@@ -806,25 +828,46 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             return fail(MBB_ERR_ARG, "row count must be a multiple of the number of sources");
         a.rows_per_src = n / c->nsrc;
     }
+    // LDS staging of the passband tables.  Measured (profiles/r01/ab_stage.txt,
+    // interleaved A/B): in the latency regime (one walker per workgroup, the copy
+    // hides under the serial prologue) it is 1.5 % faster; with many walkers per
+    // workgroup it is 4-5 % slower than reading the tables through L2, because
+    // 60 KB of LDS per workgroup caps residency at two workgroups per CU.
+    const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);
+    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= 160 * 1024;
+    if (c->opt_stage == 0) stage = false;
+    if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= 160 * 1024;
+    const size_t smem_total = smem + (stage ? table_bytes + 16 : 0);
+    c->last_smem = (long)smem_total;
+    c->last_stage = stage ? 1 : 0;
     void (*kern)(const LikeArgs);
     if (sl) {
-        a.nw_src = sl->nw_src;
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
-        if (c->opthin) kern = c->noalpha ? k_lnlike<true, true, true> : k_lnlike<true, false, true>;
-        else kern = c->noalpha ? k_lnlike<false, true, true> : k_lnlike<false, false, true>;
+        a.nw_src = sl->nw_src;
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
         a.s_begin = a.c_begin = a.c_count = a.nw = a.step = a.half = 0;
         a.stretch_a = 2.0; a.seed = 0;
-        if (c->opthin) kern = c->noalpha ? k_lnlike<true, true, false> : k_lnlike<true, false, false>;
-        else kern = c->noalpha ? k_lnlike<false, true, false> : k_lnlike<false, false, false>;
     }
-    if (smem > 64 * 1024)
+    {
+        const int vi = (c->opthin ? 8 : 0) | (c->noalpha ? 4 : 0) | (sl ? 2 : 0) | (stage ? 1 : 0);
+        static void (*const table[16])(const LikeArgs) = {
+            k_lnlike<false, false, false, false>, k_lnlike<false, false, false, true>,
+            k_lnlike<false, false, true, false>,  k_lnlike<false, false, true, true>,
+            k_lnlike<false, true, false, false>,  k_lnlike<false, true, false, true>,
+            k_lnlike<false, true, true, false>,   k_lnlike<false, true, true, true>,
+            k_lnlike<true, false, false, false>,  k_lnlike<true, false, false, true>,
+            k_lnlike<true, false, true, false>,   k_lnlike<true, false, true, true>,
+            k_lnlike<true, true, false, false>,   k_lnlike<true, true, false, true>,
+            k_lnlike<true, true, true, false>,    k_lnlike<true, true, true, true>};
+        kern = table[vi];
+    }
+    if (smem_total > 64 * 1024)
         HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, c->stream, a);
+                                   (int)smem_total));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_total, c->stream, a);
     HIPCHK(hipGetLastError());
     return MBB_OK;
 }
@@ -1278,6 +1321,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "zero_copy")) c->opt_zero_copy = value;
     else if (!strcmp(name, "seg_chunks")) c->opt_seg_chunks = value;
     else if (!strcmp(name, "debug")) c->opt_debug = value;
+    else if (!strcmp(name, "stage_tables")) c->opt_stage = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;
 }
@@ -1294,6 +1338,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_threads")) *value = c->last_threads;
     else if (!strcmp(name, "last_grid")) *value = c->last_grid;
     else if (!strcmp(name, "last_smem")) *value = c->last_smem;
+    else if (!strcmp(name, "last_stage")) *value = c->last_stage;
     else if (!strcmp(name, "device")) *value = c->device;
     else if (!strcmp(name, "nranks")) *value = c->nranks;
     else if (!strcmp(name, "rank")) *value = c->rank;

@@ -601,3 +601,29 @@ def test_multi_source_device_sampler(mbb, g_lnl):
                 if lz[w] + new[w] - hl[s_begin + w] > lu[w]:
                     hp[s_begin + w] = q[w]; hl[s_begin + w] = new[w]
         np.testing.assert_allclose(s2.chain[g, :, 0, :], hp, rtol=1e-13)
+
+
+def test_lds_staged_tables_identical(mbb, g_lnl):
+    """The LDS-staged variant of the kernel gives bitwise the same lnL as the
+    variant that reads the passband tables through L2, at every geometry."""
+    bands = [str(b) for b in g_lnl["cfg4/bands"]]
+    k = "cfg4/thick_walpha"
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    like.set_cov(g_lnl[k + "/cov"])
+    pars = g_lnl[k + "/pars"]
+    ctx = like.context
+    ctx.set_option("stage_tables", 0)
+    ref = like(pars)
+    assert ctx.info("last_stage") == 0
+    for wpb, thr in [(1, 1024), (1, 256), (4, 512), (32, 512)]:
+        ctx.set_option("walkers_per_group", wpb); ctx.set_option("block_threads", thr)
+        ctx.set_option("stage_tables", 1)
+        got = like(pars)
+        assert ctx.info("last_stage") == 1
+        assert np.array_equal(ref, got, equal_nan=True)
+    ctx.set_option("stage_tables", -1); ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0)
+    like(pars[:100])
+    assert ctx.info("last_stage") == 1           # auto: staged in the latency regime
+    like(np.tile(pars, (8, 1)))
+    assert ctx.info("last_stage") == 0           # auto: L2 path for big batches

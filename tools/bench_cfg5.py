@@ -32,17 +32,22 @@ def main():
     nq = ctx.info("nq")
     best = None
     sweep = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (4, 256), (8, 256), (16, 256), (32, 256), (64, 256), (16, 512), (32, 512), (8, 128), (16, 128)]
-    for wpb, thr in sweep:
+    if "--stage" in sys.argv:
+        sweep = [(16, 256, 0), (16, 256, 1), (16, 512, 1), (32, 512, 1), (32, 1024, 1), (64, 1024, 1), (64, 512, 1), (32, 256, 1), (8, 256, 1)]
+    for item in sweep:
+        wpb, thr = item[0], item[1]
+        ctx.set_option("stage_tables", item[2] if len(item) > 2 else -1)
         ctx.set_option("walkers_per_group", wpb); ctx.set_option("block_threads", thr)
         ctx.lnlike_repeat_device(d_pars, n, d_lnl, d_st, 2); ctx.sync()
         e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0); ctx.lnlike_repeat_device(d_pars, n, d_lnl, d_st, 5); ctx.record(e1); ctx.sync()
         ms = ctx.elapsed_ms(e0, e1) / 5
+        print("stage=%d " % ctx.info("last_stage"), end="")
         print("lnlike n=%d wpb=%d thr=%d: %.3f ms  %.3g evals/s  %.3g samples/s" %
               (n, ctx.info("last_wpb"), ctx.info("last_threads"), ms, n / ms * 1e3, n * nq / ms * 1e3), flush=True)
         if best is None or ms < best[0]:
             best = (ms, ctx.info("last_wpb"), ctx.info("last_threads"))
-    ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0)
+    ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0); ctx.set_option("stage_tables", -1)
     s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=3)
     s.run_mcmc(p0, 5, storechain=False)
     e0, e1 = ctx.event(), ctx.event()
