@@ -146,11 +146,35 @@ def main():
     ctx = like._sync_device()
     nq, nb = ctx.info("nq"), ctx.info("nb")
 
-    # RCCL communicator through the C-ABI; the unique id travels over gloo
+    # RCCL communicator through the C-ABI; the unique id travels over gloo.
+    # If RCCL cannot be brought up on every rank the gather degrades to a host
+    # all-gather over gloo (said so in config.collective) rather than no number.
+    collective = "none"
     if world > 1:
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        import torch
+        ok = 1
+        try:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                      # librccl missing
+            uid, ok = [None], 0
+            print("rank %d: RCCL unavailable: %s" % (rank, e), file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
+        if uid[0] is None:
+            ok = 0
+        if ok:
+            try:
+                ctx.comm_init(world, rank, uid[0])
+            except Exception as e:
+                ok = 0
+                print("rank %d: ncclCommInitRank failed: %s" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            collective = "ncclAllGather f64[125] per half-step (RCCL via C-ABI)"
+        else:
+            if ok:
+                ctx.comm_destroy()
+            collective = "HOST FALLBACK: gloo all_gather of f64[125] per half-step (RCCL init failed)"
 
     allw = walkers(world)
     pos = allw[rank * NW_PER_GPU:(rank + 1) * NW_PER_GPU]
@@ -164,11 +188,20 @@ def main():
     d_status = ctx.alloc(half * 4)
     d_all = [ctx.alloc(world * half * 8) for _ in range(2)]
 
+    use_rccl = world > 1 and collective.startswith("nccl")
+
     def step(i):
         for h in range(2):
-            if world > 1:     # fused kernel + ncclAllGather of the 125 new lnprob, one C call
+            if use_rccl:      # fused kernel + ncclAllGather of the 125 new lnprob, one C call
                 ctx.lnlike_allgather_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h],
                                             d_status, d_all[h])
+            elif world > 1:
+                import torch
+                ctx.lnlike_batch_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h], d_status)
+                loc = torch.from_numpy(d_lnl[h].download(np.float64, half))
+                full = torch.empty(world * half, dtype=torch.float64)
+                dist.all_gather_into_tensor(full, loc)
+                d_all[h].upload(full.numpy())
             else:
                 ctx.lnlike_batch_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h], d_status)
 
@@ -285,7 +318,7 @@ def main():
                                       "emcee half-steps of 125",
                           "walkers_per_gpu": NW_PER_GPU, "bands": nb, "nq": nq,
                           "launches_per_step": 2,
-                          "collective": "ncclAllGather f64[125] per half-step" if world > 1 else "none"},
+                          "collective": collective},
                "mcmc_steps_per_s": args.steps / elapsed,
                "stream_ms_per_step": stream_ms / args.steps,
                "device_sampler": sampler,
@@ -304,7 +337,8 @@ def main():
         print(json.dumps(out))
     barrier()
     if world > 1:
-        ctx.comm_destroy()
+        if use_rccl:
+            ctx.comm_destroy()
         dist.destroy_process_group()
 
 
