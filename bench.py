@@ -142,7 +142,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    like, flux = make_likelihood(local_rank)
+    from mbb_emcee_amd import _native
+    ndev = max(1, _native.load().mbb_device_count())
+    like, flux = make_likelihood(local_rank % ndev)     # one GPU per rank on a real node
     ctx = like._sync_device()
     nq, nb = ctx.info("nq"), ctx.info("nb")
 

@@ -10,9 +10,9 @@ def main():
     like, flux = make_likelihood(0)
     ctx = like._sync_device()
     allw = np.tile(walkers(1), (16, 1))
-    for zc in (0, 1):
-        ctx.set_option("zero_copy", zc)
-        for n in (1, 125, 250, 1000, 2000, 32000):
+    for zc, spin in ((0, 0), (0, 1), (1, 0), (1, 1)):
+        ctx.set_option("zero_copy", zc); ctx.set_option("spin_wait", spin)
+        for n in (125, 250, 2000):
             p = allw[:n]
             for _ in range(50): like(p)
             t0 = time.perf_counter(); reps = 500 if n <= 2000 else 50
@@ -21,7 +21,7 @@ def main():
             t0 = time.perf_counter()
             for _ in range(reps): ctx.lnlike_batch(p)
             dt2 = (time.perf_counter() - t0) / reps
-            print("zero_copy=%d n=%6d  likelihood.__call__ %.1f us/call %.3g evals/s | C-ABI only %.1f us/call %.3g evals/s"
+            print("spin=%d " % spin, end=""); print("zero_copy=%d n=%6d  likelihood.__call__ %.1f us/call %.3g evals/s | C-ABI only %.1f us/call %.3g evals/s"
                   % (zc, n, dt * 1e6, n / dt, dt2 * 1e6, n / dt2), flush=True)
 
 if __name__ == "__main__":
