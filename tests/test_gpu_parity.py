@@ -627,3 +627,69 @@ def test_lds_staged_tables_identical(mbb, g_lnl):
     assert ctx.info("last_stage") == 1           # auto: staged in the latency regime
     like(np.tile(pars, (8, 1)))
     assert ctx.info("last_stage") == 0           # auto: L2 path for big batches
+
+
+# ------------------------------------------------------ shapes beyond the configs
+def test_many_bands_and_covariance_vs_oracle(mbb, oracle):
+    """100 plain wavelengths (more bands than lanes in a wave), diagonal and full
+    covariance, wavenorm != 500, against the oracle."""
+    rng = np.random.RandomState(3)
+    wave = np.sort(rng.uniform(60.0, 2500.0, 100))
+    for opthin, noalpha in ((False, False), (True, True)):
+        like = mbb.likelihood(opthin=opthin, noalpha=noalpha, wavenorm=850.0)
+        like.set_phot(wave, np.ones(100), np.ones(100))
+        truth = np.array([18.0, 1.7, 300.0, 2.5, 12.0])
+        flux = like.model_flux(truth)[0]
+        unc = 0.05 * flux + 0.01
+        like.set_phot(wave, flux, unc)
+        pars = truth * (1.0 + 0.05 * rng.normal(size=(300, 5)))
+        kw = dict(wave=wave, opthin=opthin, noalpha=noalpha, wavenorm=850.0,
+                  has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
+        lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, **kw)(pars, nthreads=4))
+        A = rng.normal(0, 1, (100, 100))
+        cov = np.diag(unc ** 2) + 1e-4 * np.median(unc) ** 2 * A.dot(A.T)
+        like.set_cov(cov)
+        lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, cov=cov, **kw)(pars, nthreads=4), rtol=1e-9)
+        np.testing.assert_allclose(like.get_sed(pars[:7], wave), like.model_flux(pars[:7]), rtol=1e-13)
+        np.testing.assert_allclose(like.get_sed(pars[3], wave), like.model_flux(pars[3])[0], rtol=1e-13)
+
+
+def test_long_passbands_and_segment_length(mbb, oracle, tmp_path):
+    """Passbands far longer than the wheel's (5000 and 12000 samples; tables too
+    big for LDS) and every segment length give the oracle's answer; a given
+    segment length is bitwise reproducible across geometries."""
+    from mbb_emcee_amd import response
+    rng = np.random.RandomState(8)
+    bands = []
+    for k, (n, lo, hi) in enumerate([(5000, 180.0, 320.0), (12000, 300.0, 700.0), (77, 60.0, 90.0)]):
+        x = np.linspace(lo, hi, n)
+        t = np.exp(-0.5 * ((x - 0.5 * (lo + hi)) / (0.2 * (hi - lo))) ** 2) * (1 + 0.1 * rng.rand(n))
+        fn = tmp_path / ("band%d.txt" % k)
+        np.savetxt(fn, np.column_stack([x, t]))
+        r = response("B%d" % k)
+        r.setup(str(fn), xtype="wave", xunits="microns", senstype="energy", normtype="power",
+                xnorm=0.5 * (lo + hi), normparam=-1.0)
+        bands.append(r)
+    like = mbb.likelihood(response=True)
+    for r in bands:
+        like._responsewheel._responses[r.name] = r
+    names = [r.name for r in bands]
+    like.set_phot(names, np.ones(3), np.ones(3))
+    truth = np.array([14.0, 1.9, 500.0, 3.2, 30.0])
+    flux = like.model_flux(truth)[0]
+    like.set_phot(names, flux, 0.1 * flux)
+    pars = truth * (1.0 + 0.05 * rng.normal(size=(200, 5)))
+    ref = oracle.OracleLikelihood(flux, 0.1 * flux, bands=[(r.wavelength, r._sedmult, r._normfac) for r in bands],
+                                  has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)(pars, nthreads=8)
+    base = like(pars)
+    lnl_close(base, ref)
+    assert like.context.info("nchunk") == 79 + 188 + 2
+    for seg in (1, 2, 8, 64):
+        like.context.set_option("seg_chunks", seg)
+        like._dirty = True
+        got = like(pars)
+        lnl_close(got, ref)
+        like.context.set_option("walkers_per_group", 7); like.context.set_option("block_threads", 192)
+        assert np.array_equal(got, like(pars))
+        like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
+    like.context.set_option("seg_chunks", 4)
