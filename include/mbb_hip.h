@@ -144,6 +144,14 @@ int mbb_sed_eval_batch(mbb_ctx *ctx, const double *pars, int n, int opthin,
                        int noalpha, double wavenorm, const double *freq, int m,
                        double *out, int32_t *status);
 
+/* Replaces: modified_blackbody.freq_integrate (modified_blackbody.py:639-674, scipy
+ * quad of f_nu) for n rows: out[n] = integral of f_nu d nu over [numin, numax] GHz,
+ * in mJy GHz (the reference multiplies by 1e-17 to get erg/s/cm^2).  Used by the
+ * chain post-processing (results.py:627-674, L_IR). */
+int mbb_sed_integrate_batch(mbb_ctx *ctx, const double *pars, int n, int opthin, int noalpha,
+                            double wavenorm, double numin, double numax, double *out,
+                            int32_t *status);
+
 /* Replaces: fnu.fnueval_{thin,thick}_{noalpha,walpha} (fnu.pyx:9-108) with the
  * same explicit scalars; unused ones are ignored. */
 int mbb_fnu_eval(mbb_ctx *ctx, int opthin, int noalpha, const double *freq, int n,

@@ -43,6 +43,8 @@ SIGNATURES = {
                                          C.c_int, _dp, _ip]),
     "mbb_sed_eval_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp,
                                      C.c_int, _dp, _ip]),
+    "mbb_sed_integrate_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, _dp, _ip]),
     "mbb_fnu_eval": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int] + [C.c_double] * 7 + [_dp]),
     "mbb_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "mbb_free": (C.c_int, [_vp, _vp]),
@@ -248,6 +250,16 @@ class Context(object):
             _check(self.lib.mbb_sed_eval_batch(self.h, _d(p[i0:i1]), i1 - i0, int(bool(opthin)),
                                                int(bool(noalpha)), float(wavenorm), _d(f), m,
                                                _d(out[i0:i1]), _i(st[i0:i1])))
+        return out, st
+
+    def sed_integrate(self, pars, opthin, noalpha, wavenorm, numin, numax):
+        p = _f64(pars).reshape(-1, 5)
+        n = p.shape[0]
+        out = np.empty(n)
+        st = np.zeros(n, dtype=np.int32)
+        _check(self.lib.mbb_sed_integrate_batch(self.h, _d(p), n, int(bool(opthin)), int(bool(noalpha)),
+                                                float(wavenorm), float(numin), float(numax),
+                                                _d(out), _i(st)))
         return out, st
 
     def fnu_eval(self, opthin, noalpha, freq, T, beta, x0, alpha, normfac, xmerge, kappa):

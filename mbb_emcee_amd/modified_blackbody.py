@@ -155,6 +155,19 @@ class modified_blackbody(object):
         _native.raise_for_status(st)
         return float(out[0, 5])
 
+    def freq_integrate(self, minwave, maxwave):
+        """Integral of f_nu over [minwave, maxwave] microns, in erg/s/cm^2
+        (modified_blackbody.py:639-674)."""
+        minwave, maxwave = float(minwave), float(maxwave)
+        if minwave <= 0.0:
+            raise ValueError("Minimum wavelength must be > 0.0")
+        if minwave > maxwave:
+            minwave, maxwave = maxwave, minwave
+        out, st = self._ctx.sed_integrate(self._pars, self._opthin, not self._hasalpha,
+                                          self._wavenorm, um_to_GHz / maxwave, um_to_GHz / minwave)
+        _native.raise_for_status(st)
+        return 1e-17 * float(out[0])
+
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_ctx"] = None

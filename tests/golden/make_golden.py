@@ -235,6 +235,7 @@ def g2_g3_sed(mb):
         scal = np.full((len(pars), 6), np.nan)
         fnu_grid = np.full((len(pars), len(grid)), np.nan)
         fnu_scalar = np.full(len(pars), np.nan)
+        fint = np.full((len(pars), 2), np.nan)
         for i, p in enumerate(pars):
             m = mb.modified_blackbody(p[0], p[1], p[2], p[3], p[4],
                                       wavenorm=500.0, noalpha=noalpha, opthin=opthin)
@@ -246,9 +247,13 @@ def g2_g3_sed(mb):
             scal[i, 5] = m.max_wave()
             fnu_grid[i] = m(grid)
             fnu_scalar[i] = float(m(433.0)[0])     # numpy f_nu path (:441-491)
+            if i % 3 == 0:                         # scipy quad of f_nu (:639-674)
+                fint[i, 0] = m.freq_integrate(24.0, 3000.0)
+                fint[i, 1] = m.freq_integrate(42.5, 122.5)
         out[nm + "/scalars"] = scal
         out[nm + "/fnu_grid"] = fnu_grid
         out[nm + "/fnu_scalar433"] = fnu_scalar
+        out[nm + "/freq_integrate"] = fint
     # wavenorm != 500
     m = mb.modified_blackbody(25.0, 1.6, 150.0, 2.5, 12.0, wavenorm=850.0)
     out["wn850/fnu_grid"] = m(grid)

@@ -693,3 +693,45 @@ def test_long_passbands_and_segment_length(mbb, oracle, tmp_path):
         assert np.array_equal(got, like(pars))
         like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
     like.context.set_option("seg_chunks", 4)
+
+
+# ----------------------------------------------- chain post-processing kernels
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_freq_integrate_vs_reference_quad(mbb, ctx, g_sed, name, opthin, noalpha):
+    """modified_blackbody.freq_integrate (scipy quad, epsrel 1.5e-8 in the
+    reference) against the split Gauss-Legendre kernel."""
+    from mbb_emcee_amd.modified_blackbody import um_to_GHz
+    pars = g_sed["pars"]
+    ref = g_sed[name + "/freq_integrate"]
+    sel = np.nonzero(np.isfinite(ref[:, 0]))[0]
+    for col, (lo, hi) in enumerate(((24.0, 3000.0), (42.5, 122.5))):
+        out, st = ctx.sed_integrate(pars[sel], opthin, noalpha, 500.0, um_to_GHz / hi, um_to_GHz / lo)
+        assert np.all(st == 0)
+        np.testing.assert_allclose(1e-17 * out, ref[sel, col], rtol=2e-7)
+    m = mbb.modified_blackbody(*pars[sel[3]], opthin=opthin, noalpha=noalpha)
+    np.testing.assert_allclose(m.freq_integrate(3000.0, 24.0), ref[sel[3], 0], rtol=2e-7)
+    with pytest.raises(ValueError):
+        m.freq_integrate(0.0, 10.0)
+
+
+def test_postprocess_chain(mbb, g_lnl, oracle):
+    from mbb_emcee_amd import postprocess as pp
+    like = _cfg2_like(mbb, g_lnl)
+    chain = g_lnl["cfg2/thick_walpha/pars"][:60].reshape(6, 10, 5)
+    pk = pp.peak_wavelength(like, chain)
+    assert pk.shape == (6, 10)
+    for i, j in ((0, 0), (3, 7), (5, 9)):
+        np.testing.assert_allclose(pk[i, j], oracle.OracleSED(*chain[i, j]).max_wave(), rtol=1e-10)
+    L = pp.lir(like, chain, redshift=2.0, lumdist_mpc=15000.0)
+    fi = pp.freq_integral(like, chain, 24.0, 3000.0)
+    np.testing.assert_allclose(L, 3.11749657e4 * 15000.0 ** 2 * fi, rtol=1e-14)
+    # against a direct high-accuracy quadrature of the oracle SED
+    from scipy.integrate import quad
+    sed = oracle.OracleSED(*chain[2, 4])
+    wm = sed.wavemerge
+    nu0, nu1, num = 299792.458 / 3000.0, 299792.458 / 24.0, 299792.458 / wm
+    val = sum(quad(lambda f: float(sed.f_nu(f)[0]), a, b, epsrel=1e-12, limit=200)[0]
+              for a, b in ((nu0, num), (num, nu1)))
+    np.testing.assert_allclose(fi[2, 4], 1e-17 * val, rtol=1e-10)
+    md = pp.dustmass(like, chain, redshift=2.0, lumdist_mpc=15000.0)
+    assert md.shape == (6, 10) and np.all(md > 0)
