@@ -735,3 +735,28 @@ def test_postprocess_chain(mbb, g_lnl, oracle):
     np.testing.assert_allclose(fi[2, 4], 1e-17 * val, rtol=1e-10)
     md = pp.dustmass(like, chain, redshift=2.0, lumdist_mpc=15000.0)
     assert md.shape == (6, 10) and np.all(md > 0)
+
+
+def test_cli_config1(mbb, tmp_path):
+    """Config 1 end to end through the command-line harness: 5 plain wavelengths,
+    optically thin, 50 walkers."""
+    from mbb_emcee_amd import run_mbb_emcee
+    wave = np.array([100.0, 160.0, 250.0, 350.0, 500.0])
+    truth = mbb.modified_blackbody(12.0, 1.8, None, 3.0, 40.0, opthin=True)
+    flux = truth(wave)
+    pf = tmp_path / "phot.txt"
+    with open(pf, "w") as fh:
+        fh.write("# wave flux unc\n")
+        for w, f in zip(wave, flux):
+            fh.write("%g %.8g %.8g\n" % (w, f, 0.1 * f + 1.0))
+    out = tmp_path / "fit.npz"
+    rc = run_mbb_emcee.main([str(pf), str(out), "--opthin", "-n", "50", "-b", "100", "-N", "200",
+                             "--initT", "12", "--initBeta", "1.8", "--initAlpha", "3", "--fixLambda0",
+                             "--initLambda0", "600",
+                             "--seed", "5", "--get_peaklambda"])
+    assert rc == 0
+    d = np.load(out)
+    assert d["chain"].shape == (50, 200, 5) and d["peaklambda"].shape == (50, 200)
+    med = np.median(d["chain"].reshape(-1, 5), axis=0)
+    assert abs(med[0] - 12.0) < 2.0 and abs(med[4] - 40.0) < 6.0
+    assert np.all(d["chain"][:, :, 2] == d["chain"][0, 0, 2])
