@@ -92,8 +92,7 @@ __device__ __forceinline__ void h_and_dh(double y, double &h, double &dh)
 //   dg/du = x (1 - e^-x A) - (1 - e^-x) beta^2 h'(y) y
 // converges quadratically; a bracket keeps it safe.  Working in u makes the two
 // exps of an evaluation independent (x = e^u, y = e^(beta (u - log x0))) and
-// leaves log(xmerge) = u for the caller.  Stops when the step is below 1e-8:
-// the error after taking it is then below one ulp (brentq stops at 2e-12).
+// leaves log(xmerge) = u for the caller.
 // fp32 pre-solve of the same equation: a few Newton steps with the hardware
 // exp/log (microseconds matter here: the prologue is one lane per walker and
 // nothing else in the workgroup can start before it).  Good to ~1e-6 in u.
@@ -143,12 +142,15 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
         if (g == 0.0) { xroot = x; yroot = y; status = ROW_OK; break; }
         if (g < 0.0) ulo = u; else uhi = u;
         const double step = -g / dg;
-        if (fabs(step) <= 1e-8) {
-            // x e^step and y e^(beta step) to second order: exact to 1e-24
+        if (fabs(step) <= 1e-6) {
+            // Newton is quadratic with |g''/2g'| < 1: the error left after a step
+            // of 1e-6 is below 1e-12 (the fp32 pre-solve normally leaves ~1e-7, so
+            // ~1e-14; brentq in the reference stops at 2e-12).  One fp64 evaluation.
+            // x e^step and y e^(beta step) to third order: exact to 1e-24
             u += step;
-            xroot = x * (1.0 + step * (1.0 + 0.5 * step));
+            xroot = x * (1.0 + step * (1.0 + step * (0.5 + step * (1.0 / 6.0))));
             const double bs = beta * step;
-            yroot = y * (1.0 + bs * (1.0 + 0.5 * bs));
+            yroot = y * (1.0 + bs * (1.0 + bs * (0.5 + bs * (1.0 / 6.0))));
             status = ROW_OK;
             break;
         }
