@@ -762,3 +762,49 @@ def test_cli_config1(mbb, tmp_path):
     assert 6.0 < med[0] < 20.0 and abs(med[4] - 40.0) < 8.0
     assert d["lnprobability"].max() > -1.0
     assert np.all(d["chain"][:, :, 2] == d["chain"][0, 0, 2])
+
+
+# ------------------------------------ full BASELINE sizes: size-independent properties
+def test_full_size_cfg3_and_cfg5_properties(mbb, g_lnl, oracle):
+    """At the full sizes of configs 3 and 5 (2000 walkers; 1000 sources x 250
+    walkers = 250 000 evaluations in one launch) the oracle is too slow to check
+    every row, so: (i) a random sample of rows against the oracle, (ii) properties
+    that hold for any size -- idempotence, row-permutation equivariance (bitwise),
+    band fluxes linear in fnorm, lnL = -chi^2/2 rebuilt from the returned band
+    fluxes, the soft-wall penalty added exactly once."""
+    from tools.bench_cfg5 import setup
+    rng = np.random.RandomState(77)
+    # ---- cfg3: 2000 walkers, single source -------------------------------------
+    like = _cfg2_like(mbb, g_lnl)
+    w = np.column_stack([rng.normal(12, 1, 2000), rng.normal(1.8, 0.2, 2000), rng.normal(600, 50, 2000),
+                         rng.normal(3, 0.3, 2000), rng.normal(40, 3, 2000)])
+    l0 = like(w)
+    assert np.array_equal(l0, like(w))                               # idempotent
+    perm = rng.permutation(2000)
+    assert np.array_equal(like(w[perm]), l0[perm])                   # equivariant, bitwise
+    mf = like.model_flux(w)
+    w3 = w.copy(); w3[:, 4] *= 3.0
+    np.testing.assert_allclose(like.model_flux(w3), 3.0 * mf, rtol=3e-15)       # linear in fnorm
+    chi = -0.5 * np.sum((like.data_flux - mf) ** 2 / like.data_flux_unc ** 2, axis=1)
+    np.testing.assert_allclose(l0, chi, rtol=1e-12, atol=1e-12)      # no wall is hit by these rows
+    wb = w.copy(); wb[:, 1] = 20.5                                   # beta above its soft wall
+    pen = -0.5 * (20.5 - 20.0) ** 2 / (0.02 * (20.0 - 0.1)) ** 2
+    mfb = like.model_flux(wb)
+    chib = -0.5 * np.sum((like.data_flux - mfb) ** 2 / like.data_flux_unc ** 2, axis=1)
+    np.testing.assert_allclose(like(wb), chib + pen, rtol=1e-12)
+    # ---- cfg5: 1000 sources x 250 walkers ----------------------------------------
+    like5, truths, p0 = setup(1000, 250)
+    big = like5(p0)
+    assert big.shape == (1000, 250) and np.all(np.isfinite(big))
+    assert np.array_equal(big, like5(p0))
+    sp = rng.permutation(250)
+    assert np.array_equal(like5(p0[:, sp, :]), big[:, sp])           # within-source permutation
+    bands = [(r.wavelength, r._sedmult, r._normfac) for r in like5._responses]
+    for g in rng.choice(1000, 6, replace=False):                     # sampled sources vs the oracle
+        orc = oracle.OracleLikelihood(like5._flux_multi[g], 1.0 / np.sqrt(like5._ivar_multi[g]),
+                                      bands=bands, has_uplim=[int(b) for b in like5.has_uplims],
+                                      uplim=like5.uplims)
+        lnl_close(big[g], orc(p0[g], nthreads=8))
+    # the truth row of every source has lnL = 0 up to rounding (data were made from it)
+    lt = like5(truths[:, None, :])
+    assert np.all(np.abs(lt) < 1e-18)
