@@ -250,7 +250,7 @@ def main():
         alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
         # exp-class ops per sample for thick+alpha on these walkers: count on the host
-        traffic, traffic_src = measured_traffic("k_lnlike<false, false, false>")
+        traffic, traffic_src = measured_traffic("k_lnlike<false, false, false")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "k_lnlike<thick,alpha> n=125", "kernel_avg_us": k_us,
