@@ -28,6 +28,10 @@ using mbbm::m_div;
 using mbbm::m_exp;
 using mbbm::m_expm1;
 using mbbm::m_log;
+using mbbm::m_exp_t;
+using mbbm::m_expm1_t;
+using mbbm::Exp2Entry;
+using mbbm::kExp2Tab;
 
 // modified_blackbody.py:15-18
 constexpr double kH = 6.6260693e-34;      // J s
@@ -278,20 +282,25 @@ __device__ inline void make_walker_k(double T, double beta, double alpha,
 }
 
 // One quadrature sample: f_nu at frequency nu (GHz), lnnu = log(nu).
-// fnu.pyx:9-108, the four kernels.
-template <bool OPTHIN, bool NOALPHA>
-__device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu)
+// fnu.pyx:9-108, the four kernels.  tab != nullptr selects the table-driven
+// exp/expm1 (the table sits in LDS; the passband loop), nullptr the polynomial
+// ones (one-off evaluations).
+template <bool OPTHIN, bool NOALPHA, bool TAB = false>
+__device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
+                                             const Exp2Entry *tab = nullptr)
 {
+    auto ex = [&](double v) { if constexpr (TAB) return m_exp_t(v, tab); else return m_exp(v); };
+    auto em1 = [&](double v) { if constexpr (TAB) return m_expm1_t(v, tab); else return m_expm1(v); };
     const double x = w.hokt9 * nu;
     const double lx = w.lhokt9 + lnnu;
     if (!NOALPHA) {
-        if (x > w.xmerge) return w.cpl * m_exp(-w.alpha * lx);      // :48-49, :102-103
+        if (x > w.xmerge) return w.cpl * ex(-w.alpha * lx);         // :48-49, :102-103
     }
     if (OPTHIN) {
-        return w.cbb * m_div(m_exp(w.bp3 * lx), m_expm1(x));        // :24-25, :51
+        return w.cbb * m_div(ex(w.bp3 * lx), em1(x));               // :24-25, :51
     } else {
-        const double y = m_exp(w.beta * (lx - w.lx0));              // :74, :105
-        return w.cbb * m_div(-m_expm1(-y) * (x * x * x), m_expm1(x));   // :75-76, :106
+        const double y = ex(w.beta * (lx - w.lx0));                 // :74, :105
+        return w.cbb * m_div(-em1(-y) * (x * x * x), em1(x));       // :75-76, :106
     }
 }
 

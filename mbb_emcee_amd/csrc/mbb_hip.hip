@@ -23,6 +23,14 @@
 
 using namespace mbbd;
 
+// Table-driven exp/expm1 in the sample loop (mbb_math.hip.h); -DMBB_NO_EXP_TABLE
+// builds the polynomial-only variant for A/B measurements.
+#ifdef MBB_NO_EXP_TABLE
+constexpr bool kUseExpTable = false;
+#else
+constexpr bool kUseExpTable = true;
+#endif
+
 // ---------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------
@@ -97,6 +105,7 @@ template <bool OPTHIN, bool NOALPHA, bool SAMPLER, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ Exp2Entry s_tab[128];                        // 2^(j/128) for the sample loop
     const int W = a.wpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
@@ -129,6 +138,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // table into this CU's L1, so that nothing after the barrier waits on L2.
     if (wave > 0 || nwave == 1) {
         const int t0 = (nwave == 1) ? tid : tid - 64, nt = (nwave == 1) ? 64 : (int)blockDim.x - 64;
+        for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
         for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
         for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
         if (a.invcov)
@@ -270,14 +280,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const int i0 = c * 64 + lane, i1 = i0 + 64;
             const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
             const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-            const double f0 = fnu_sample<OPTHIN, NOALPHA>(k, n0, l0);
-            const double f1 = fnu_sample<OPTHIN, NOALPHA>(k, n1, l1);
+            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n0, l0, s_tab);
+            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n1, l1, s_tab);
             acc = fma(f0, q0, acc);
             acc = fma(f1, q1, acc);
         }
         if (c < c1) {
             const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA>(k, T_nu(i), T_ln(i));
+            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, T_nu(i), T_ln(i), s_tab);
             acc = fma(f, T_wt(i), acc);
         }
         acc = wave_sum(acc);
