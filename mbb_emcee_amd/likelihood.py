@@ -71,23 +71,6 @@ class likelihood(object):
             raise Exception("Can't pass in covfile if no photfile")
         self._badval = float("-inf")
 
-    # ---- simple properties (likelihood.py:119-137) --------------------------
-    @property
-    def wavenorm(self):
-        return self._wavenorm
-
-    @property
-    def noalpha(self):
-        return self._noalpha
-
-    @property
-    def opthin(self):
-        return self._opthin
-
-    @property
-    def response_integrate(self):
-        return self._response_integrate
-
     # ---- data ----------------------------------------------------------------
     def read_responses(self, responsefile=None, responsedir=None):
         """Load a filter wheel and turn on passband integration (:139-156)."""
@@ -150,10 +133,6 @@ class likelihood(object):
         self._nsources = flux.shape[0]
         self._dirty = True
 
-    @property
-    def nsources(self):
-        return self._nsources
-
     def read_phot(self, filename):
         """Three-column text file: wavelength [um] (or passband name), flux,
         uncertainty [mJy] (likelihood.py:234-262)."""
@@ -164,22 +143,6 @@ class likelihood(object):
             raise IOError("No data read from %s" % filename)
         self.set_phot([d[0] for d in data], [d[1] for d in data], [d[2] for d in data])
 
-    @property
-    def data_read(self):
-        return self._data_read
-
-    @property
-    def ndata(self):
-        return self._ndata if self._data_read else 0
-
-    @property
-    def data_wave(self):
-        return self._wave if self._data_read else None
-
-    @property
-    def response_names(self):
-        return getattr(self, '_response_names', None)
-
     def has_response(self, name):
         return hasattr(self, '_responsewheel') and name in self._responsewheel
 
@@ -187,10 +150,6 @@ class likelihood(object):
         if not hasattr(self, '_responsewheel'):
             return None
         return self._responsewheel[name]
-
-    @property
-    def data_flux(self):
-        return self._flux if self._data_read else None
 
     @property
     def data_flux_unc(self):
@@ -227,18 +186,6 @@ class likelihood(object):
             raise ImportError("read_cov needs astropy.io.fits; use set_cov(array) instead")
         self.set_cov(fits.open(filename)[extn].data)
 
-    @property
-    def has_data_covmatrix(self):
-        return self._has_covmatrix
-
-    @property
-    def data_covmatrix(self):
-        return self._covmatrix if self._has_covmatrix else None
-
-    @property
-    def data_invcovmatrix(self):
-        return self._invcovmatrix if self._has_covmatrix else None
-
     # ---- limits and priors (likelihood.py:378-641) ----------------------------
     def get_paramindex(self, paramname):
         return self._param_order[paramname]
@@ -253,10 +200,6 @@ class likelihood(object):
     def lowlim(self, param):
         return self._lowlim[self._pidx(param, self._param_order)]
 
-    @property
-    def lowlims(self):
-        return self._lowlim
-
     def set_uplim(self, param, val):
         i = self._pidx(param, self._limprior_order)
         self._has_uplim[i] = True
@@ -270,14 +213,6 @@ class likelihood(object):
         i = self._pidx(param, self._limprior_order)
         return self._uplim[i] if self._has_uplim[i] else None
 
-    @property
-    def has_uplims(self):
-        return self._has_uplim
-
-    @property
-    def uplims(self):
-        return self._uplim
-
     def set_gaussian_prior(self, param, mean, sigma):
         i = self._pidx(param, self._limprior_order)
         self._any_gprior = True
@@ -286,22 +221,6 @@ class likelihood(object):
         self._gprior_sigma[i] = float(sigma)
         self._gprior_ivar[i] = 1.0 / (float(sigma) ** 2)
         self._dirty = True
-
-    @property
-    def has_gpriors(self):
-        return self._has_gprior
-
-    @property
-    def gprior_means(self):
-        return self._gprior_mean
-
-    @property
-    def gprior_sigmas(self):
-        return self._gprior_sigma
-
-    @property
-    def gprior_ivars(self):
-        return self._gprior_ivar
 
     def has_gaussian_prior(self, param):
         return self._has_gprior[self._pidx(param, self._limprior_order)]
@@ -438,3 +357,37 @@ class likelihood(object):
 
     def __setstate__(self, d):
         self.__dict__.update(d)
+
+
+def _ro(attr, doc, needs=None, default=None):
+    """Read-only view of an attribute, optionally gated on a flag attribute
+    (the reference returns None / 0 before data are set, likelihood.py:264-397)."""
+    def get(self):
+        if needs is not None and not getattr(self, needs, False):
+            return default
+        return getattr(self, attr, default)
+    return property(get, doc=doc)
+
+
+for _n, _a, _d, _needs, _dflt in (
+        ("wavenorm", "_wavenorm", "Normalisation wavelength [um]", None, None),
+        ("noalpha", "_noalpha", "Not including a blue side power law?", None, None),
+        ("opthin", "_opthin", "Assuming an optically thin model?", None, None),
+        ("response_integrate", "_response_integrate", "Is passband integration in use?", None, None),
+        ("nsources", "_nsources", "Number of sources (multi-source mode)", None, 1),
+        ("data_read", "_data_read", "Has the photometry been set?", None, False),
+        ("ndata", "_ndata", "Number of data points", "_data_read", 0),
+        ("data_wave", "_wave", "Data (effective) wavelengths [um]", "_data_read", None),
+        ("data_flux", "_flux", "Flux densities [mJy]", "_data_read", None),
+        ("response_names", "_response_names", "Passband names of the data", None, None),
+        ("has_data_covmatrix", "_has_covmatrix", "Is there a flux covariance matrix?", None, False),
+        ("data_covmatrix", "_covmatrix", "Flux covariance matrix [mJy^2]", "_has_covmatrix", None),
+        ("data_invcovmatrix", "_invcovmatrix", "Inverse covariance matrix", "_has_covmatrix", None),
+        ("lowlims", "_lowlim", "Lower limits: T, beta, lambda0, alpha, fnorm", None, None),
+        ("has_uplims", "_has_uplim", "Which upper limits are set (6th: lambda_peak)", None, None),
+        ("uplims", "_uplim", "Upper limits", None, None),
+        ("has_gpriors", "_has_gprior", "Which Gaussian priors are set", None, None),
+        ("gprior_means", "_gprior_mean", "Gaussian prior means", None, None),
+        ("gprior_sigmas", "_gprior_sigma", "Gaussian prior sigmas", None, None),
+        ("gprior_ivars", "_gprior_ivar", "Gaussian prior inverse variances", None, None)):
+    setattr(likelihood, _n, _ro(_a, _d, _needs, _dflt))

@@ -63,38 +63,7 @@ class mbb_fitter(object):
         self._sampled = False
         self._fixed = [False, False, False, False, False]
 
-    # ---- properties (mbb_fit.py:87-125) --------------------------------------
-    @property
-    def noalpha(self):
-        return self._noalpha
-
-    @property
-    def opthin(self):
-        return self._opthin
-
-    @property
-    def wavenorm(self):
-        return self._wavenorm
-
-    @property
-    def nwalkers(self):
-        return self._nwalkers
-
-    @property
-    def nthreads(self):
-        return self._nthreads
-
-    @property
-    def sampled(self):
-        return self._sampled
-
-    @property
-    def fixed(self):
-        return self._fixed
-
-    @property
-    def response_integrate(self):
-        return self.like.response_integrate
+    # ---- read-only views (mbb_fit.py:87-125) are attached below the class -----
 
     # ---- data (mbb_fit.py:127-185) --------------------------------------------
     def read_data(self, photfile, covfile=None, covextn=0, responsefile=None,
@@ -110,39 +79,17 @@ class mbb_fitter(object):
         if covmatrix is not None:
             self.like.set_cov(covmatrix)
 
-    # ---- fixed parameters, limits, priors (mbb_fit.py:187-360) -----------------
+    # ---- fixed parameters (mbb_fit.py:187-219); the limit / prior calls of
+    # mbb_fit.py:221-360 are forwarded to the likelihood, see _FORWARDED below ----
     def _pidx(self, param):
         return self._param_order[param.lower()] if isinstance(param, str) else int(param)
 
     def fix_param(self, param):
+        """Hold a parameter (index or name) at its initial value."""
         self._fixed[self._pidx(param)] = True
 
     def unfix_param(self, param):
         self._fixed[self._pidx(param)] = False
-
-    def set_lowlim(self, param, val):
-        self.like.set_lowlim(param, val)
-
-    def lowlim(self, param):
-        return self.like.lowlim(param)
-
-    def set_uplim(self, param, val):
-        self.like.set_uplim(param, val)
-
-    def has_uplim(self, param):
-        return self.like.has_uplim(param)
-
-    def uplim(self, param):
-        return self.like.uplim(param)
-
-    def set_gaussian_prior(self, param, mean, sigma):
-        self.like.set_gaussian_prior(param, mean, sigma)
-
-    def has_gaussian_prior(self, param):
-        return self.like.has_gaussian_prior(param)
-
-    def get_gaussian_prior(self, param):
-        return self.like.get_gaussian_prior(param)
 
     # ---- initial positions (mbb_fit.py:362-479) ---------------------------------
     def generate_initial_values(self, initvals, initsigma):
@@ -256,3 +203,34 @@ class mbb_fitter(object):
                 print("\tfnorm:    {:f}".format(acor[4]))
             except Exception:
                 pass
+
+
+def _view(attr, doc):
+    return property(lambda self: getattr(self, attr), doc=doc)
+
+
+for _name, _attr, _doc in (("noalpha", "_noalpha", "Not using the blue side power law?"),
+                           ("opthin", "_opthin", "Assuming an optically thin model?"),
+                           ("wavenorm", "_wavenorm", "Normalisation wavelength [um]"),
+                           ("nwalkers", "_nwalkers", "Number of walkers"),
+                           ("nthreads", "_nthreads", "Accepted for compatibility, unused"),
+                           ("sampled", "_sampled", "Has the distribution been sampled?"),
+                           ("fixed", "_fixed", "Which parameters are held fixed")):
+    setattr(mbb_fitter, _name, _view(_attr, _doc))
+mbb_fitter.response_integrate = property(lambda self: self.like.response_integrate,
+                                         doc="Is passband integration in use?")
+
+
+def _forward(name):
+    def call(self, *args):
+        return getattr(self.like, name)(*args)
+    call.__name__ = name
+    call.__doc__ = "Forwards to likelihood.%s (param: index or name, incl. 'lambda_peak')." % name
+    return call
+
+
+# mbb_fit.py:221-360: the fitter exposes the likelihood's limit and prior calls
+_FORWARDED = ("set_lowlim", "lowlim", "set_uplim", "has_uplim", "uplim",
+              "set_gaussian_prior", "has_gaussian_prior", "get_gaussian_prior")
+for _name in _FORWARDED:
+    setattr(mbb_fitter, _name, _forward(_name))
