@@ -297,9 +297,12 @@ def main():
             c5.sync(); t5 = time.perf_counter()
             smp5.advance_async(20); c5.sync()
             t5 = (time.perf_counter() - t5) / 20
-            flops5 = None
+            flops5, flops_src = None, None
             try:
-                flops5 = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_valu_cfg5.json")))["fp64_flops_per_launch"]
+                import glob
+                ff = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_valu_cfg5*.json")))[-1]
+                flops5 = json.load(open(ff))["fp64_flops_per_launch"]
+                flops_src = os.path.relpath(ff, ROOT)
             except Exception:
                 pass
             cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
@@ -309,7 +312,7 @@ def main():
                     "fp64_tflops": (flops5 / (ms5 * 1e-3) / 1e12) if flops5 else None,
                     "fp64_vector_peak_tflops": FP64_VALU_PEAK_TFLOPS,
                     "fp64_frac": (flops5 / (ms5 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if flops5 else None,
-                    "flops_source": "profiles/r01/pmc_valu_cfg5.json (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)"}
+                    "flops_source": "%s (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)" % flops_src}
         out = {"metric": "walker-likelihood evals/sec, 250 walkers x 8 bands per GPU",
                "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
