@@ -215,10 +215,18 @@ __device__ const Exp2Entry kExp2Tab[128] = {
 MBB_HD double reduce_ln2_128(double x, int &n)
 {
     x = fmin(fmax(x, -800.0), 800.0);
-    const double nd = rint(x * 184.66496523378731);            // 128 / ln2
+    // round(x 128/ln2) by adding 1.5 2^52: the integer lands in the low mantissa
+    // bits (read as an int) and the subtraction gives it back as a double -- one
+    // add instead of a round and a convert
+    const double shifted = fma(x, 184.66496523378731, 6755399441055744.0);
+#ifdef MBB_MATH_HOST
+    union { double d; int64_t i; } u; u.d = shifted; n = (int)(u.i & 0xffffffff);
+#else
+    n = __double2loint(shifted);
+#endif
+    const double nd = shifted - 6755399441055744.0;
     double r = fma(nd, -5.41521234812457272e-03, x);           // ln2/128 hi
     r = fma(nd, -1.81175532330184346e-19, r);                  // ln2/128 lo
-    n = (int)nd;
     return r;
 }
 
