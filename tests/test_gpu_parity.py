@@ -808,3 +808,60 @@ def test_full_size_cfg3_and_cfg5_properties(mbb, g_lnl, oracle):
     # the truth row of every source has lnL = 0 up to rounding (data were made from it)
     lt = like5(truths[:, None, :])
     assert np.all(np.abs(lt) < 1e-18)
+
+
+# --------------------------------------------------------------- randomised configurations
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations_vs_oracle(mbb, oracle, seed):
+    """Random band subsets (wheel bands, specials, repeats, a single band), random
+    model variant, random limits / priors / lambda_peak terms, diagonal or full
+    covariance, random batch size and launch geometry -- always the oracle's answer."""
+    rng = np.random.RandomState(1000 + seed)
+    pool = ["PACS_70um", "PACS_100um", "PACS_160um", "SPIRE_250um", "SPIRE_350um", "SPIRE_500um",
+            "SCUBA2_450um", "SCUBA2_850um", "Bolocam_1.1mm", "MAMBO2_1.2mm", "GISMO_2mm",
+            "LABOCA_870um", "MIPS_160um", "X_box_850um_60", "ALMA_alma_343", "ALMA_alma_230",
+            "S_gauss_345_10", "D_dsb_300_20_6", "Y_delta_1300um"]
+    nb = int(rng.choice([1, 2, 3, 5, 8, 13]))
+    names = [str(x) for x in rng.choice(pool, nb, replace=(nb > 8))]
+    opthin, noalpha = bool(rng.randint(2)), bool(rng.randint(2))
+    wavenorm = float(rng.choice([500.0, 350.0, 850.0]))
+    like = mbb.likelihood(opthin=opthin, noalpha=noalpha, response=True, wavenorm=wavenorm)
+    like.set_phot(names, np.ones(nb), np.ones(nb))
+    truth = np.array([rng.uniform(8, 40), rng.uniform(1.0, 2.6), rng.uniform(80, 900),
+                      rng.uniform(1.5, 5.0), rng.uniform(5, 90)])
+    flux = like.model_flux(truth)[0]
+    unc = 0.08 * flux + 0.3
+    like.set_phot(names, flux, unc)
+    cov = None
+    if nb > 1 and rng.rand() < 0.5:
+        A = rng.normal(0, 1, (nb, nb))
+        cov = np.diag(unc ** 2) + 0.02 * np.median(unc) ** 2 * A.dot(A.T)
+        like.set_cov(cov)
+    has_g, gm, gs = [0] * 6, [0.0] * 6, [1.0] * 6
+    for i in range(6):
+        if rng.rand() < 0.35:
+            centre = truth[i] if i < 5 else 200.0
+            has_g[i], gm[i], gs[i] = 1, centre * rng.uniform(0.9, 1.1), abs(centre) * rng.uniform(0.05, 0.3)
+            like.set_gaussian_prior(i, gm[i], gs[i])
+    if rng.rand() < 0.4:
+        like.set_uplim("T", truth[0] * 1.02)
+    if rng.rand() < 0.3:
+        like.set_uplim("lambda_peak", 180.0)
+    if rng.rand() < 0.3:
+        like.set_lowlim("beta", truth[1] * 0.97)
+    n = int(rng.choice([1, 3, 64, 65, 257, 900]))
+    pars = truth * (1.0 + 0.06 * rng.normal(size=(n, 5)))
+    bands = []
+    for r in like._responses:
+        bands.append((r.wavelength, np.ones(1), 1.0) if r.isdelta else (r.wavelength, r._sedmult, r._normfac))
+    orc = oracle.OracleLikelihood(flux, unc, bands=bands, cov=cov, opthin=opthin, noalpha=noalpha,
+                                  wavenorm=wavenorm, lowlim=like.lowlims,
+                                  has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims,
+                                  has_gprior=has_g, gprior_mean=gm, gprior_sigma=gs)
+    ref = orc(pars, nthreads=4)
+    like.context.set_option("walkers_per_group", int(rng.choice([0, 1, 2, 5, 16])))
+    like.context.set_option("block_threads", int(rng.choice([0, 64, 256, 640, 1024])))
+    got = like(pars)
+    like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
+    lnl_close(got, ref, rtol=1e-9 if cov is not None else 1e-10)
+    assert np.array_equal(got, like(pars), equal_nan=True)
