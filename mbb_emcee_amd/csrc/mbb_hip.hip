@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) srow[i] = q[i];
                     srow[5] = r;
-                    a.nacc[row] += 1u;
+                    atomicAdd(&a.nacc[row], 1u);               // no-return atomic: nothing waits on it
                 }
                 if (a.chain6) {
                     double *crow = a.chain6 + ((size_t)a.step * a.nw + row) * 6;
