@@ -228,6 +228,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    # ---- cfg3 as a complete MCMC: one ensemble of 250*N walkers sharded over the N
+    # GPUs, device-resident sampler, in-place ncclAllGather of the moved state rows
+    # per half-step.  Every rank takes part; guarded by a timeout so that a stuck
+    # collective cannot cost the main result.
+    sharded = None
+    if use_rccl:
+        import threading
+        import mbb_emcee_amd as mbb
+        res = {}
+
+        def leg():
+            try:
+                nwt = NW_PER_GPU * world
+                smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
+                smp.run_mcmc(allw[:nwt], 20, storechain=False)
+                ks = max(100, min(args.steps, 2000))
+                ctx.sync(); dist.barrier()
+                t0s = time.perf_counter()
+                smp.advance_async(ks)
+                ctx.sync(); dist.barrier()
+                dts = time.perf_counter() - t0s
+                res.update({"walkers": nwt, "steps": ks, "steps_per_s": ks / dts,
+                            "evals_per_s": nwt * ks / dts, "us_per_step": dts / ks * 1e6,
+                            "collective": "in-place ncclAllGather of %d state rows x 6 f64 per half-step"
+                                          % (nwt // 2)})
+            except Exception as e:           # noqa
+                res["error"] = repr(e)
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        sharded = res if res else {"error": "timed out after 120 s"}
+
     # parity spot check of what was just timed (rank-local, not in the timed region)
     got = d_lnl[1].download(np.float64, half)
     last = props[(2 * (args.steps - 1) + 1) % (2 * NSETS)]
@@ -335,6 +368,7 @@ def main():
                "mcmc_steps_per_s": args.steps / elapsed,
                "stream_ms_per_step": stream_ms / args.steps,
                "device_sampler": sampler,
+               "sharded_sampler": sharded,
                "cfg5": cfg5,
                "roofline": roof}
         if not args.no_cpu and world == 1:

@@ -66,12 +66,15 @@ struct LikeArgs {
 #endif
     // ---- stretch-move half-step (SAMPLER instantiation only) ----------------
     // State rows are (T, beta, lambda0, alpha, fnorm, lnprob).  This launch moves
-    // rows [s_begin, s_begin + n) using partners drawn from [c_begin, c_begin + c_count).
+    // m_count rows per source starting at s_begin, using partners drawn from
+    // [c_begin, c_begin + c_count).  chain6 / nacc are launch-local: entry w belongs to
+    // the w-th walker of this launch (the host keeps the map back to rows), so that a
+    // rank of a sharded run owns one contiguous block it can all-gather in place.
     double *pos6;             // [nw*6]
-    double *chain6;           // [nsteps*nw*6] or nullptr; written at step `step`
-    unsigned int *nacc;       // [nw] accepted moves
+    double *chain6;           // [n*6] or nullptr: this launch's slot of the chain
+    unsigned int *nacc;       // [n] accepted moves of this launch's walkers
     int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
-    int s_begin, c_begin, c_count, nw;
+    int s_begin, c_begin, c_count, m_count, nw;
     int step, half;
     // ---- independent sources sharing the band tables (cfg5): flux/ivar are
     // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // stretch move (Goodman & Weare 2010; what emcee does per half-step,
                 // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
                 // half, proposal q = c - z (c - s)
-                const int src = w / a.c_count, loc = w - src * a.c_count;
+                const int src = w / a.m_count, loc = w - src * a.m_count;
                 const int row = src * a.nw_src + a.s_begin + loc;
                 unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * a.step + a.half), 0u, 0u};
                 philox4x32(c4, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             // data of this walker's source: LDS copy for one source, global for many
             const double *fsrc = s_flux, *isrc = s_ivar;
             if (a.nsrc > 1) {
-                const int src = SAMPLER ? (w / a.c_count) : (w / a.rows_per_src);
+                const int src = SAMPLER ? (w / a.m_count) : (w / a.rows_per_src);
                 fsrc = a.flux + (size_t)src * nb;
                 isrc = a.ivar + (size_t)src * nb;
             }
@@ -345,8 +348,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             }
             if (SAMPLER) {
                 // accept with probability min(1, z^(dim-1) P(q)/P(s))
-                const int src = w / a.c_count;
-                const int row = src * a.nw_src + a.s_begin + (w - src * a.c_count);
+                const int src = w / a.m_count;
+                const int row = src * a.nw_src + a.s_begin + (w - src * a.m_count);
                 double *srow = a.pos6 + (size_t)row * 6;
                 const double *q = prop + j * 8;
                 if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
@@ -355,10 +358,10 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) srow[i] = q[i];
                     srow[5] = r;
-                    atomicAdd(&a.nacc[row], 1u);               // no-return atomic: nothing waits on it
+                    atomicAdd(&a.nacc[w], 1u);                 // no-return atomic: nothing waits on it
                 }
                 if (a.chain6) {
-                    double *crow = a.chain6 + ((size_t)a.step * a.nw + row) * 6;
+                    double *crow = a.chain6 + (size_t)w * 6;
 #pragma unroll
                     for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
                     crow[5] = accept ? r : q[6];
@@ -579,6 +582,7 @@ struct mbb_ctx {
     long opt_wpb = 0, opt_threads = 0, opt_seg_chunks = 4, opt_debug = 0;
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
+    long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
     long opt_spin = 0;        // poll the stream instead of blocking (measured: no gain)
     long last_stage = 0;
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
@@ -856,7 +860,7 @@ struct SamplerLaunch {
     double *pos6, *chain6;
     unsigned int *nacc;
     int *errflag;
-    int s_begin, c_begin, c_count, nw, step, half, nw_src;
+    int s_begin, c_begin, c_count, m_count, nw, step, half, nw_src;
     double stretch_a;
     unsigned long long seed;
 };
@@ -914,11 +918,12 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (sl) {
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
+        a.m_count = sl->m_count;
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
         a.nw_src = sl->nw_src;
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
-        a.s_begin = a.c_begin = a.c_count = a.nw = a.step = a.half = 0;
+        a.s_begin = a.c_begin = a.c_count = a.m_count = a.nw = a.step = a.half = 0;
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
@@ -1008,9 +1013,9 @@ struct mbb_sampler_state {
     int nw = 0;            // walkers per source
     int nsrc = 1;          // independent ensembles advanced together
     double *d_pos6 = nullptr;
-    unsigned int *d_nacc = nullptr;
+    unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
-    double *d_chain6 = nullptr;
+    double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
     int rows() const { return nw * nsrc; }
@@ -1060,7 +1065,7 @@ extern "C" int mbb_sampler_reset(mbb_ctx *c, void *sp)
 }
 
 // Set the ensemble(s): pos [nsrc][nw][5]; lnprob [nsrc][nw] or NULL (then evaluated
-// on the device).
+// on the device).  In a sharded run every rank sets the same, complete state.
 extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, const double *lnprob)
 {
     int rc = use(c);
@@ -1090,22 +1095,70 @@ extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, co
     return MBB_OK;
 }
 
+// How a run is cut into shards.  One shard = the whole half-ensemble (one GPU).
+// With an RCCL communicator of G ranks the moving half is cut into G contiguous
+// blocks; rank r moves block r and the blocks are exchanged by an in-place
+// all-gather of the state rows, so every rank holds the whole, identical ensemble
+// before the next half-step.  Option "virtual_ranks" runs the G
+// shards one after another on this GPU without any collective -- the same result
+// by construction, used to test the sharded launch arithmetic on one device.
+struct ShardPlan { int shards, first, last, per; bool collective; };
+
+static int shard_plan(const mbb_ctx *c, const mbb_sampler_state *s, ShardPlan &p)
+{
+    const int half = s->nw / 2;
+    p.collective = c->comm != nullptr && c->nranks > 1;
+    p.shards = p.collective ? c->nranks : (int)(c->opt_vranks > 1 ? c->opt_vranks : 1);
+    if (p.shards > 1 && s->nsrc > 1)
+        return fail(MBB_ERR_ARG, "a sharded sampler run needs a single source");
+    if (half % p.shards != 0)
+        return fail(MBB_ERR_ARG, "nwalkers/2 must be a multiple of the number of ranks");
+    p.per = half / p.shards;
+    p.first = p.collective ? c->rank : 0;
+    p.last = p.collective ? c->rank : p.shards - 1;
+    return MBB_OK;
+}
+
+static int allgather_bytes(mbb_ctx *c, void *base, size_t bytes_per_rank)
+{
+    // in place: rank r's block already sits at base + r * bytes_per_rank
+    int r = g_rccl.AllGather((const char *)base + (size_t)c->rank * bytes_per_rank, base,
+                             bytes_per_rank, 0 /* ncclInt8 */, c->comm, c->stream);
+    if (r != 0) return fail(MBB_ERR_RCCL, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclAllGather failed");
+    return MBB_OK;
+}
+
 static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store)
 {
+    ShardPlan p;
+    int rc = shard_plan(c, s, p);
+    if (rc) return rc;
     const int nw = s->nw, half = nw / 2;
+    const size_t nl = (size_t)s->nsrc * p.per;              // walkers per launch
     SamplerLaunch sl;
-    sl.pos6 = s->d_pos6; sl.chain6 = store ? s->d_chain6 : nullptr; sl.nacc = s->d_nacc;
-    sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw; sl.stretch_a = stretch_a;
+    sl.pos6 = s->d_pos6; sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw;
+    sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
     for (int t = 0; t < nsteps; ++t)
         for (int h = 0; h < 2; ++h) {
-            sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half; sl.c_count = half;
-            sl.step = t; sl.half = h;
-            // the RNG key advances over the whole life of the sampler, the chain index restarts
-            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
-            int rc = launch_lnlike(c, nullptr, s->nsrc * half, nullptr, nullptr, nullptr, &sl);
-            if (rc) return rc;
+            const int hb = h ? half : 0;
+            for (int r = p.first; r <= p.last; ++r) {
+                sl.s_begin = hb + r * p.per; sl.c_begin = h ? 0 : half;
+                sl.step = t; sl.half = h;
+                sl.chain6 = store ? s->d_chain6 + ((((size_t)r * nsteps + t) * 2 + h) * nl) * 6 : nullptr;
+                sl.nacc = s->d_nacc + ((size_t)r * 2 + h) * nl;
+                // the RNG key advances over the whole life of the sampler, the chain index restarts
+                sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+            }
+            if (p.collective &&
+                (rc = allgather_bytes(c, s->d_pos6 + (size_t)hb * 6, (size_t)p.per * 6 * sizeof(double))))
+                return rc;
         }
     s->steps_done += (unsigned long long)nsteps;
+    if (p.collective) {          // every rank ends up with the whole chain and all counts
+        if (store && (rc = allgather_bytes(c, s->d_chain6, (size_t)nsteps * 2 * nl * 6 * sizeof(double)))) return rc;
+        if ((rc = allgather_bytes(c, s->d_nacc, 2 * nl * sizeof(unsigned int)))) return rc;
+    }
     return MBB_OK;
 }
 
@@ -1123,7 +1176,10 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0 || !(stretch_a > 1.0)) return fail(MBB_ERR_ARG, "bad sampler arguments");
     if (s->nsrc != c->nsrc) return fail(MBB_ERR_STATE, "number of sources changed since the sampler was made");
-    const int R = s->rows();
+    ShardPlan p;
+    if ((rc = shard_plan(c, s, p))) return rc;
+    const int R = s->rows(), nw = s->nw, half = nw / 2;
+    const size_t nl = (size_t)s->nsrc * p.per;
     const bool store = (chain || lnprob) && nsteps > 0;
     if (store && (size_t)nsteps * R * 6 > s->chain_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1153,14 +1209,20 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     for (int i = 0; i < R; ++i) {
         if (pos_out) for (int k = 0; k < 5; ++k) pos_out[(size_t)i * 5 + k] = rows[(size_t)i * 6 + k];
         if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
-        if (naccepted) naccepted[i] = (double)nacc[i];
     }
-    if (store)
-        for (int t = 0; t < nsteps; ++t)
-            for (int i = 0; i < R; ++i) {
-                const double *r = &ch[((size_t)t * R + i) * 6];
-                if (chain) for (int k = 0; k < 5; ++k) chain[((size_t)i * nsteps + t) * 5 + k] = r[k];
-                if (lnprob) lnprob[(size_t)i * nsteps + t] = r[5];
+    // launch-local order -> rows: shard r, half h, launch index w = src * per + loc
+    for (int r = 0; r < p.shards; ++r)
+        for (int h = 0; h < 2; ++h)
+            for (size_t w = 0; w < nl; ++w) {
+                const int src = (int)(w / p.per), loc = (int)(w - (size_t)src * p.per);
+                const int row = src * nw + (h ? half : 0) + r * p.per + loc;
+                if (naccepted) naccepted[row] = (double)nacc[((size_t)r * 2 + h) * nl + w];
+                if (!store) continue;
+                for (int t = 0; t < nsteps; ++t) {
+                    const double *q = &ch[((((size_t)r * nsteps + t) * 2 + h) * nl + w) * 6];
+                    if (chain) for (int k = 0; k < 5; ++k) chain[((size_t)row * nsteps + t) * 5 + k] = q[k];
+                    if (lnprob) lnprob[(size_t)row * nsteps + t] = q[5];
+                }
             }
     return MBB_OK;
 }
@@ -1436,6 +1498,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "debug")) c->opt_debug = value;
     else if (!strcmp(name, "stage_tables")) c->opt_stage = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin = value;
+    else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;
 }

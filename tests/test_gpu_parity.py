@@ -865,3 +865,35 @@ def test_random_configurations_vs_oracle(mbb, oracle, seed):
     like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
     lnl_close(got, ref, rtol=1e-9 if cov is not None else 1e-10)
     assert np.array_equal(got, like(pars), equal_nan=True)
+
+
+def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
+    """The sharded form of the device sampler (each rank moves a contiguous block of
+    the half-ensemble, in-place all-gather of the state rows) is exercised on one
+    GPU by running the G shards one after another ('virtual_ranks'): chain, lnprob,
+    acceptance counts and final state are bitwise those of the unsharded run."""
+    like = _cfg2_like(mbb, g_lnl)
+    p0 = g_lnl["cfg2/thick_walpha/pars"][:64].copy()
+    ref = mbb.DeviceEnsembleSampler(64, 5, like, seed=77)
+    rp, rl, _ = ref.run_mcmc(p0, 12)
+    rp2, _, _ = ref.run_mcmc(None, 5)
+    ctx = like.context
+    for g in (2, 4, 8):
+        ctx.set_option("virtual_ranks", g)
+        s = mbb.DeviceEnsembleSampler(64, 5, like, seed=77)
+        sp, slp, _ = s.run_mcmc(p0, 12)
+        assert np.array_equal(s.chain, ref.chain[:, :12]) and np.array_equal(s.lnprobability, ref.lnprobability[:, :12])
+        assert np.array_equal(sp, rp) and np.array_equal(slp, rl)
+        sp2, _, _ = s.run_mcmc(None, 5)
+        assert np.array_equal(sp2, rp2) and np.array_equal(s.naccepted, ref.naccepted)
+        assert np.array_equal(s.chain, ref.chain)
+    ctx.set_option("virtual_ranks", 3)                     # 32 is not a multiple of 3
+    with pytest.raises(Exception):
+        mbb.DeviceEnsembleSampler(64, 5, like, seed=1).run_mcmc(p0, 1)
+    ctx.set_option("virtual_ranks", 0)
+    # a real 1-rank communicator takes the ordinary path
+    ctx.comm_init(1, 0, ctx.comm_unique_id())
+    s = mbb.DeviceEnsembleSampler(64, 5, like, seed=77)
+    s.run_mcmc(p0, 12)
+    assert np.array_equal(s.chain, ref.chain[:, :12])
+    ctx.comm_destroy()
