@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "mbb_device.hip.h"),
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),
+        os.path.join(HERE, "csrc", "mbb_kernels.hip.h"),
         os.path.join(os.path.dirname(HERE), "include", "mbb_hip.h")]
 LIB = os.path.join(HERE, "libmbb_hip.so")
 ARCH = "gfx950"

@@ -1,11 +1,12 @@
-// mbb_hip.hip -- kernels and C-ABI of the MI355X likelihood hot path (gfx950).
+// mbb_hip.hip -- host side and C-ABI of the MI355X likelihood hot path (gfx950).
 //
-// One fused kernel per model variant evaluates, for a batch of walkers,
-//   prologue (per walker) -> f_nu on every passband sample -> band fluxes ->
-//   chi-square / covariance form -> soft limits and Gaussian priors -> lnL
-// i.e. n calls of the reference's likelihood.__call__ (likelihood.py:790-834)
-// in one launch.  See include/mbb_hip.h for the boundary and DESIGN.md for the
-// data layout.
+// The kernels are in mbb_kernels.hip.h (one fused kernel per model variant
+// evaluates, for a batch of walkers, prologue -> f_nu on every passband sample ->
+// band fluxes -> chi-square / covariance form -> limits and priors -> lnL, i.e. n
+// calls of the reference's likelihood.__call__, likelihood.py:790-834, in one
+// launch).  This file owns contexts, device buffers, launch geometry, the sampler
+// driver and the RCCL plumbing.  See include/mbb_hip.h for the boundary and
+// DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <math.h>
@@ -20,478 +21,8 @@
 
 #include "../../include/mbb_hip.h"
 #include "mbb_device.hip.h"
+#include "mbb_kernels.hip.h"
 
-using namespace mbbd;
-
-// Table-driven exp/expm1 in the sample loop (mbb_math.hip.h); -DMBB_NO_EXP_TABLE
-// builds the polynomial-only variant for A/B measurements.
-#ifdef MBB_NO_EXP_TABLE
-constexpr bool kUseExpTable = false;
-#else
-constexpr bool kUseExpTable = true;
-#endif
-
-// ---------------------------------------------------------------------------
-// kernel arguments
-// ---------------------------------------------------------------------------
-struct LikeArgs {
-    // passband tables, chunk-padded: band b owns chunks; every chunk is 64 samples
-    const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
-    const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
-    const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
-    const int32_t *seg_c0;    // [nseg+1] first chunk of each segment
-    const int32_t *band_s0;   // [nb+1]   first segment of each band
-    const double *flux;       // [nb]
-    const double *ivar;       // [nb]
-    const double *invcov;     // [nb*nb] or nullptr
-    int nb, nseg, nchunk;
-    double wavenorm;
-    double lnunorm;           // log(um_to_GHz / wavenorm)
-    double lowlim[5];
-    double uplim[6];
-    double gmean[6];
-    double givar[6];
-    uint32_t has_uplim;       // bit i
-    uint32_t has_gprior;      // bit i
-    // batch
-    const double *pars;       // [n*5]
-    int n;
-    int wpb;                  // walkers per block
-    int debug;                // status carries root-finder iterations << 8
-    double *lnl;              // [n]
-    int32_t *status;          // [n] or nullptr
-    double *model_flux;       // [n*nb] or nullptr
-#ifdef MBB_STAMPS
-    unsigned long long *stamps;   // diagnostic build only: [grid*8] s_memtime values
-#endif
-    // ---- stretch-move half-step (SAMPLER instantiation only) ----------------
-    // State rows are (T, beta, lambda0, alpha, fnorm, lnprob).  This launch moves
-    // m_count rows per source starting at s_begin, using partners drawn from
-    // [c_begin, c_begin + c_count).  chain6 / nacc are launch-local: entry w belongs to
-    // the w-th walker of this launch (the host keeps the map back to rows), so that a
-    // rank of a sharded run owns one contiguous block it can all-gather in place.
-    double *pos6;             // [nw*6]
-    double *chain6;           // [n*6] or nullptr: this launch's slot of the chain
-    unsigned int *nacc;       // [n] accepted moves of this launch's walkers
-    int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
-    int s_begin, c_begin, c_count, m_count, nw;
-    int step, half;
-    // ---- independent sources sharing the band tables (cfg5): flux/ivar are
-    // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
-    // [nsrc][nw_src][6] and a launch covers nsrc * c_count walkers
-    int nsrc, rows_per_src, nw_src;
-    double stretch_a;
-    unsigned long long seed;
-};
-
-// Philox4x32-10 (Salmon et al. 2011), counter = (row, 2 step + half), key = seed.
-__device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, unsigned int k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned int hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
-        const unsigned int n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
-// Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
-//   phase 1: lane-per-walker prologue (wave 0)            -> LDS
-//   phase 2: (walker, segment) units dealt round-robin to waves; a lane strides
-//            over the segment's samples, then one wave64 shuffle reduction
-//   phase 3: band sums in fixed order, then one lane per walker forms lnL
-// Summation order depends only on the band tables, never on the batch, so a
-// walker's result is bitwise independent of which launch / GPU evaluates it.
-template <bool OPTHIN, bool NOALPHA, bool SAMPLER, bool STAGE>
-__global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
-{
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[128];                        // 2^(j/128) for the sample loop
-    const int W = a.wpb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwave = blockDim.x >> 6;
-    const int nseg = a.nseg, nb = a.nb;
-    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);
-    double *partial = reinterpret_cast<double *>(wk + W);   // [W*nseg]
-    double *mflux = partial + (size_t)W * nseg;             // [W*nb]
-    double *pen = mflux + (size_t)W * nb;                   // [W*2]
-    double *s_flux = pen + 2 * (size_t)W;                   // [nb]
-    double *s_ivar = s_flux + nb;                           // [nb]
-    double *s_invcov = s_ivar + nb;                         // [nb*nb] when a.invcov
-    int *s_band = reinterpret_cast<int *>(s_invcov + (a.invcov ? (size_t)nb * nb : 0));  // [nb+1]
-    // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
-    double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
-    // STAGE: the passband tables themselves (nu, log nu, weight), [nchunk*64] each
-    double *s_nu = reinterpret_cast<double *>(
-        (reinterpret_cast<uintptr_t>(prop + 8 * (size_t)W) + 15) & ~(uintptr_t)15);
-    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
-    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
-    const int w0 = blockIdx.x * W;
-#ifdef MBB_STAMPS
-#define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-    STAMP(0);
-
-    // While wave 0 runs the serial prologue the other waves stage the data the
-    // epilogue needs in LDS and pull their first segment's samples and the index
-    // table into this CU's L1, so that nothing after the barrier waits on L2.
-    if (wave > 0 || nwave == 1) {
-        const int t0 = (nwave == 1) ? tid : tid - 64, nt = (nwave == 1) ? 64 : (int)blockDim.x - 64;
-        for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
-        for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
-        for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
-        if (a.invcov)
-            for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
-        if (STAGE) {
-            // passband tables -> LDS, 16 B per lane, while wave 0 is in the prologue
-            const int n2 = a.nchunk * 32;                      // double2 elements per array
-            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
-            const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
-            const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
-            double2 *l0 = reinterpret_cast<double2 *>(s_nu);
-            double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
-            double2 *l2 = reinterpret_cast<double2 *>(s_wt);
-            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-        } else {
-            const int u = wave;
-            if (u < W * nseg) {
-                const int s = u % nseg;
-                const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
-                double t = 0.0;
-                for (int c = c0; c < c1; ++c) {
-                    const int i = c * 64 + lane;
-                    t += a.nu[i] + a.lnnu[i] + a.wt[i];
-                }
-                asm volatile("" ::"v"(t));
-            }
-        }
-    }
-
-    // ---- phase 1: gate + prologue + parameter-only penalties ----------------
-    if (tid < W) {
-        const int w = w0 + tid;
-        WalkerK k;
-        k.status = ROW_SKIP;
-        double pen_u = 0.0, pen_g = 0.0;
-        if (w < a.n) {
-            double p[5];
-            if (SAMPLER) {
-                // stretch move (Goodman & Weare 2010; what emcee does per half-step,
-                // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
-                // half, proposal q = c - z (c - s)
-                const int src = w / a.m_count, loc = w - src * a.m_count;
-                const int row = src * a.nw_src + a.s_begin + loc;
-                unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * a.step + a.half), 0u, 0u};
-                philox4x32(c4, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
-                const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) *
-                                  (1.0 / 9007199254740992.0);
-                const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
-                const double u3 = ((double)c4[3] + 0.5) * (1.0 / 4294967296.0);
-                const double sq = (a.stretch_a - 1.0) * u1 + 1.0;
-                const double zz = sq * sq / a.stretch_a;
-                int pj = (int)(u2 * (double)a.c_count);
-                if (pj >= a.c_count) pj = a.c_count - 1;
-                const double *srow = a.pos6 + (size_t)row * 6;
-                const double *crow = a.pos6 + (size_t)(src * a.nw_src + a.c_begin + pj) * 6;
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const double cv = crow[i], sv = srow[i];
-                    p[i] = cv - zz * (cv - sv);
-                    prop[tid * 8 + i] = p[i];
-                }
-                prop[tid * 8 + 5] = 4.0 * m_log(zz);          // (dim - 1) ln z, dim = 5
-                prop[tid * 8 + 6] = srow[5];
-                prop[tid * 8 + 7] = m_log(u3);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
-            }
-            bool ok = true;                                   // likelihood.py:643-670
-#pragma unroll
-            for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
-            if (!ok) {
-                k.status = ROW_BELOW_LOWLIM;
-            } else if (!finite5(p)) {
-                // NaN passes the reference's `<` gate and its SED arithmetic then
-                // yields NaN; +-inf does the same.  Short-cut both to NaN.
-                k.status = ROW_NONFINITE;
-            } else {
-                SedScalars s;
-                k.pad = 0;
-                k.status = sed_prologue<OPTHIN, NOALPHA>(p[0], p[1], p[2], p[3], p[4],
-                                                         a.wavenorm, a.lnunorm, s, &k.pad);
-                if (k.status == ROW_OK) {
-                    make_walker_k<OPTHIN, NOALPHA>(p[0], p[1], p[3], s, k);
-                    // _uplim_prior, likelihood.py:672-717
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (((a.has_uplim >> i) & 1u) && p[i] > a.uplim[i]) {
-                            double lw = 0.02 * (a.uplim[i] - a.lowlim[i]);
-                            double d = p[i] - a.uplim[i];
-                            pen_u -= 0.5 * d * d / (lw * lw);
-                        }
-                    double peak = 0.0;
-                    if (((a.has_uplim | a.has_gprior) >> 5) & 1u) {
-                        int pst;
-                        peak = sed_peak_wave<OPTHIN>(p[0], p[1], k.lx0, s.hcokt, pst);
-                        if (pst != ROW_OK) k.status = pst;
-                        k.peak = peak;
-                    }
-                    if (((a.has_uplim >> 5) & 1u) && peak > a.uplim[5]) {  // :710-715
-                        double lw = 0.02 * a.uplim[5], d = peak - a.uplim[5];
-                        pen_u -= 0.5 * d * d / (lw * lw);
-                    }
-                    // _gprior, likelihood.py:719-752
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if ((a.has_gprior >> i) & 1u) {
-                            double d = p[i] - a.gmean[i];
-                            pen_g -= 0.5 * a.givar[i] * d * d;
-                        }
-                    if ((a.has_gprior >> 5) & 1u) {
-                        double d = peak - a.gmean[5];
-                        pen_g -= 0.5 * a.givar[5] * d * d;
-                    }
-                }
-            }
-        }
-        wk[tid] = k;
-        pen[2 * tid] = pen_u;
-        pen[2 * tid + 1] = pen_g;
-    }
-    STAMP(1);
-    __syncthreads();
-    STAMP(2);
-
-    // ---- phase 2: passband quadrature (response.py:572-576) -----------------
-    const int nunit = W * nseg;
-    auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
-    auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
-    auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
-    for (int u = wave; u < nunit; u += nwave) {
-        const int j = u / nseg, s = u - j * nseg;
-        if (wk[j].status != ROW_OK) continue;                 // wave-uniform
-        const WalkerK k = wk[j];
-        const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
-        double acc = 0.0;
-        int c = c0;
-        for (; c + 2 <= c1; c += 2) {          // two independent chains in flight
-            const int i0 = c * 64 + lane, i1 = i0 + 64;
-            const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
-            const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n0, l0, s_tab);
-            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n1, l1, s_tab);
-            acc = fma(f0, q0, acc);
-            acc = fma(f1, q1, acc);
-        }
-        if (c < c1) {
-            const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, T_nu(i), T_ln(i), s_tab);
-            acc = fma(f, T_wt(i), acc);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) partial[u] = acc;
-    }
-    STAMP(3);
-    __syncthreads();
-    STAMP(4);
-    STAMP(5);
-
-    // ---- phase 3: one wave per walker, one lane per band (likelihood.py:821-834)
-    for (int j = wave; j < W; j += nwave) {
-        const int st = wk[j].status;
-        if (st == ROW_SKIP) continue;                          // wave-uniform
-        const int w = w0 + j;
-        double acc = 0.0;
-        if (st == ROW_OK) {
-            double *mf = mflux + (size_t)j * nb;
-            // data of this walker's source: LDS copy for one source, global for many
-            const double *fsrc = s_flux, *isrc = s_ivar;
-            if (a.nsrc > 1) {
-                const int src = SAMPLER ? (w / a.m_count) : (w / a.rows_per_src);
-                fsrc = a.flux + (size_t)src * nb;
-                isrc = a.ivar + (size_t)src * nb;
-            }
-            for (int b = lane; b < nb; b += 64) {              // band fluxes, fixed order
-                double sum = 0.0;
-                for (int sg = s_band[b]; sg < s_band[b + 1]; ++sg) sum += partial[j * nseg + sg];
-                if (a.model_flux) a.model_flux[(size_t)w * nb + b] = sum;
-                const double d = fsrc[b] - sum;                // :821
-                if (a.invcov) mf[b] = d;
-                else acc = fma(d * d, isrc[b], acc);           // :825
-            }
-            if (a.invcov) {                                    // :823
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < nb; i += 64) {
-                    double t = 0.0;
-                    for (int jj = 0; jj < nb; ++jj) t = fma(s_invcov[i * nb + jj], mf[jj], t);
-                    acc = fma(mf[i], t, acc);
-                }
-            }
-            acc = wave_sum(acc);
-        } else if (a.model_flux) {
-            for (int b = lane; b < nb; b += 64) a.model_flux[(size_t)w * nb + b] = __builtin_nan("");
-        }
-        if (lane == 0) {
-            double r;
-            if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
-            else if (st != ROW_OK) r = __builtin_nan("");
-            else {
-                r = -0.5 * acc;
-                r += pen[2 * j];                               // :828
-                if (a.has_gprior) r += pen[2 * j + 1];         // :830-831
-            }
-            if (SAMPLER) {
-                // accept with probability min(1, z^(dim-1) P(q)/P(s))
-                const int src = w / a.m_count;
-                const int row = src * a.nw_src + a.s_begin + (w - src * a.m_count);
-                double *srow = a.pos6 + (size_t)row * 6;
-                const double *q = prop + j * 8;
-                if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
-                const bool accept = (q[5] + r - q[6]) > q[7];
-                if (accept) {
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) srow[i] = q[i];
-                    srow[5] = r;
-                    atomicAdd(&a.nacc[w], 1u);                 // no-return atomic: nothing waits on it
-                }
-                if (a.chain6) {
-                    double *crow = a.chain6 + (size_t)w * 6;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
-                    crow[5] = accept ? r : q[6];
-                }
-                if (a.lnl) a.lnl[w] = r;
-            } else {
-                a.lnl[w] = r;
-            }
-            if (a.status) a.status[w] = a.debug ? (st | (wk[j].pad << 8)) : st;
-        }
-    }
-    STAMP(6);
-}
-
-// modified_blackbody.__init__ + max_wave for n rows, one lane per row.
-template <bool OPTHIN, bool NOALPHA>
-__global__ void k_prologue(const double *pars, int n, double wavenorm, double lnunorm,
-                           int want_peak, double *out, int32_t *status, WalkerK *wk_out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double T = pars[i * 5 + 0], beta = pars[i * 5 + 1], lambda0 = pars[i * 5 + 2],
-                 alpha = pars[i * 5 + 3], fnorm = pars[i * 5 + 4];
-    SedScalars s;
-    const double p5[5] = {T, beta, lambda0, alpha, fnorm};
-    int st = ROW_NONFINITE;
-    if (finite5(p5))
-        st = sed_prologue<OPTHIN, NOALPHA>(T, beta, lambda0, alpha, fnorm, wavenorm, lnunorm, s);
-    else
-        s.normfac = s.xmerge = s.kappa = s.x0 = s.hcokt = __builtin_nan("");
-    const double nan = __builtin_nan("");
-    double peak = nan;
-    WalkerK k;
-    k.status = st;
-    if (st == ROW_OK) {
-        make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
-        if (want_peak) {
-            int pst;
-            peak = sed_peak_wave<OPTHIN>(T, beta, k.lx0, s.hcokt, pst);
-            if (pst != ROW_OK) st = pst;
-        }
-    }
-    k.peak = peak;
-    if (out) {
-        out[i * 6 + 0] = s.normfac;
-        out[i * 6 + 1] = s.xmerge;
-        out[i * 6 + 2] = s.kappa;
-        out[i * 6 + 3] = s.x0;
-        out[i * 6 + 4] = NOALPHA ? nan : s.hcokt / s.xmerge;        // wavemerge :382-388
-        out[i * 6 + 5] = peak;
-    }
-    if (status) status[i] = st;
-    if (wk_out) wk_out[i] = k;
-}
-
-// f_nu of row blockIdx.y on a common frequency grid (modified_blackbody.py:441-554)
-template <bool OPTHIN, bool NOALPHA>
-__global__ void k_sed_eval(const WalkerK *wk, const double *freq, int m, double *out)
-{
-    const WalkerK k = wk[blockIdx.y];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    double r = __builtin_nan("");
-    if (k.status == ROW_OK) {
-        const double nu = freq[i];
-        r = fnu_sample<OPTHIN, NOALPHA>(k, nu, m_log(nu));
-    }
-    out[(size_t)blockIdx.y * m + i] = r;
-}
-
-// freq_integrate (modified_blackbody.py:639-674) for row blockIdx.x: the integral of
-// f_nu over [numin, numax] (GHz), in mJy GHz.  The reference calls scipy's adaptive
-// quad; here the integral is taken in t = log(nu), split at the merge frequency
-// and at nu0, each piece cut into npanel panels with an ngl-point Gauss-Legendre
-// rule: one node per lane, one wave per row.
-template <bool OPTHIN, bool NOALPHA>
-__global__ void k_sed_integrate(const WalkerK *wk, double numin, double numax, const double *glx,
-                                const double *glw, int ngl, int npanel, double *out)
-{
-    const WalkerK k = wk[blockIdx.x];
-    const int lane = threadIdx.x;
-    double total = __builtin_nan("");
-    if (k.status == ROW_OK) {
-        const double t0 = m_log(numin), t1 = m_log(numax);
-        // break points in t = log nu: the merge frequency (f_nu is only C1 there) and,
-        // for the optically thick model, nu0 (for large beta the optical-depth factor
-        // is nearly a step there)
-        double tm = t1, tz = t0;
-        if (!NOALPHA) tm = fmin(fmax(m_log(k.xmerge) - k.lhokt9, t0), t1);
-        if (!OPTHIN) tz = fmin(fmax(k.lx0 - k.lhokt9, t0), tm);
-        const double edge[4] = {t0, tz, tm, t1};
-        double acc = 0.0;
-        for (int piece = 0; piece < 3; ++piece) {
-            const double a = edge[piece], b = edge[piece + 1];
-            if (!(b > a)) continue;
-            // keep a node that rounds across the merge point on its own side
-            WalkerK kk = k;
-            if (!NOALPHA) kk.xmerge = (piece == 2) ? 0.0 : __builtin_inf();
-            const double pw = (b - a) / npanel, half = 0.5 * pw;
-            for (int pn = 0; pn < npanel; ++pn) {
-                const double mid = a + (pn + 0.5) * pw;
-                for (int i = lane; i < ngl; i += 64) {
-                    const double t = fma(half, glx[i], mid);
-                    const double nu = m_exp(t);
-                    acc = fma(fnu_sample<OPTHIN, NOALPHA>(kk, nu, t) * nu, half * glw[i], acc);
-                }
-            }
-        }
-        total = wave_sum(acc);
-    }
-    if (lane == 0) out[blockIdx.x] = total;
-}
-
-// fnu.pyx:9-108 with explicit scalars
-template <bool OPTHIN, bool NOALPHA>
-__global__ void k_fnu_explicit(const double *freq, int n, double T, double beta, double x0,
-                               double alpha, double normfac, double xmerge, double kappa,
-                               double *out)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    SedScalars s;
-    s.normfac = normfac; s.xmerge = xmerge; s.kappa = kappa; s.x0 = x0; s.hcokt = 0.0;
-    s.lhokt9 = kLog1e9HoK - m_log(T);
-    s.lx0 = OPTHIN ? 0.0 : m_log(x0);
-    WalkerK k;
-    make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
-    const double nu = freq[i];
-    out[i] = fnu_sample<OPTHIN, NOALPHA>(k, nu, m_log(nu));
-}
 
 // ---------------------------------------------------------------------------
 // host side
