@@ -420,9 +420,12 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     a.stamps = c->d_stamps;
 #endif
     const int grid = (n + wpb - 1) / wpb;
-    const size_t smem = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16) +
-                        8 * (size_t)c->nb * (2 + (c->has_cov ? c->nb : 0)) + 4 * ((size_t)c->nb + 4) +
-                        64 * (size_t)wpb;
+    const size_t cov_bytes = c->has_cov ? 8 * (size_t)c->nb * c->nb : 0;
+    const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16) +
+                             16 * (size_t)c->nb + 4 * ((size_t)c->nb + 4) + 64 * (size_t)wpb;
+    // the inverse covariance goes to LDS when it fits beside everything else
+    a.cov_in_lds = (c->has_cov && smem_base + cov_bytes <= 96 * 1024) ? 1 : 0;
+    const size_t smem = smem_base + (a.cov_in_lds ? cov_bytes : 0);
     if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid;
     a.nsrc = c->nsrc;

@@ -37,6 +37,7 @@ struct LikeArgs {
     const double *flux;       // [nb]
     const double *ivar;       // [nb]
     const double *invcov;     // [nb*nb] or nullptr
+    int cov_in_lds;           // C^-1 copied to LDS (it fits) or read from global
     int nb, nseg, nchunk;
     double wavenorm;
     double lnunorm;           // log(um_to_GHz / wavenorm)
@@ -113,7 +114,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_flux = pen + 2 * (size_t)W;                   // [nb]
     double *s_ivar = s_flux + nb;                           // [nb]
     double *s_invcov = s_ivar + nb;                         // [nb*nb] when a.invcov
-    int *s_band = reinterpret_cast<int *>(s_invcov + (a.invcov ? (size_t)nb * nb : 0));  // [nb+1]
+    int *s_band = reinterpret_cast<int *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));  // [nb+1]
     // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
     double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
     // STAGE: the passband tables themselves (nu, log nu, weight), [nchunk*64] each
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
         for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
         for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
-        if (a.invcov)
+        if (a.cov_in_lds)
             for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
         if (STAGE) {
             // passband tables -> LDS, 16 B per lane, while wave 0 is in the prologue
@@ -322,7 +323,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < nb; i += 64) {
                     double t = 0.0;
-                    for (int jj = 0; jj < nb; ++jj) t = fma(s_invcov[i * nb + jj], mf[jj], t);
+                    const double *row = (a.cov_in_lds ? s_invcov : a.invcov) + (size_t)i * nb;
+                    for (int jj = 0; jj < nb; ++jj) t = fma(row[jj], mf[jj], t);
                     acc = fma(mf[i], t, acc);
                 }
             }

@@ -630,14 +630,16 @@ def test_lds_staged_tables_identical(mbb, g_lnl):
 
 
 # ------------------------------------------------------ shapes beyond the configs
-def test_many_bands_and_covariance_vs_oracle(mbb, oracle):
-    """100 plain wavelengths (more bands than lanes in a wave), diagonal and full
-    covariance, wavenorm != 500, against the oracle."""
+@pytest.mark.parametrize("nbands", [100, 150])
+def test_many_bands_and_covariance_vs_oracle(mbb, oracle, nbands):
+    """100 / 150 plain wavelengths (more bands than lanes in a wave), diagonal and
+    full covariance (80 KB: held in LDS; 180 KB: read from global), wavenorm != 500,
+    against the oracle."""
     rng = np.random.RandomState(3)
-    wave = np.sort(rng.uniform(60.0, 2500.0, 100))
+    wave = np.sort(rng.uniform(60.0, 2500.0, nbands))
     for opthin, noalpha in ((False, False), (True, True)):
         like = mbb.likelihood(opthin=opthin, noalpha=noalpha, wavenorm=850.0)
-        like.set_phot(wave, np.ones(100), np.ones(100))
+        like.set_phot(wave, np.ones(nbands), np.ones(nbands))
         truth = np.array([18.0, 1.7, 300.0, 2.5, 12.0])
         flux = like.model_flux(truth)[0]
         unc = 0.05 * flux + 0.01
@@ -646,7 +648,7 @@ def test_many_bands_and_covariance_vs_oracle(mbb, oracle):
         kw = dict(wave=wave, opthin=opthin, noalpha=noalpha, wavenorm=850.0,
                   has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
         lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, **kw)(pars, nthreads=4))
-        A = rng.normal(0, 1, (100, 100))
+        A = rng.normal(0, 1, (nbands, nbands))
         cov = np.diag(unc ** 2) + 1e-4 * np.median(unc) ** 2 * A.dot(A.T)
         like.set_cov(cov)
         lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, cov=cov, **kw)(pars, nthreads=4), rtol=1e-9)
