@@ -449,6 +449,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     c->last_smem = (long)smem_total;
     c->last_stage = stage ? 1 : 0;
     void (*kern)(const LikeArgs);
+    int vi_of_kernel = 0;
     if (sl) {
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
@@ -462,6 +463,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     }
     {
         const int vi = (c->opthin ? 8 : 0) | (c->noalpha ? 4 : 0) | (sl ? 2 : 0) | (stage ? 1 : 0);
+        vi_of_kernel = vi;
         static void (*const table[16])(const LikeArgs) = {
             k_lnlike<false, false, false, false>, k_lnlike<false, false, false, true>,
             k_lnlike<false, false, true, false>,  k_lnlike<false, false, true, true>,
@@ -473,9 +475,16 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             k_lnlike<true, true, true, false>,    k_lnlike<true, true, true, true>};
         kern = table[vi];
     }
-    if (smem_total > 64 * 1024)
-        HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)smem_total));
+    if (smem_total > 64 * 1024) {
+        // raise the kernel's dynamic-LDS ceiling once per variant and size, not per launch
+        static size_t granted[16][16] = {};       // [device][variant]
+        size_t &g = granted[c->device & 15][vi_of_kernel];
+        if (smem_total > g) {
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+            g = 160 * 1024;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_total, c->stream, a);
     HIPCHK(hipGetLastError());
     return MBB_OK;
