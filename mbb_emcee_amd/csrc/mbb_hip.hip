@@ -442,9 +442,9 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     // workgroup it is 4-5 % slower than reading the tables through L2, because
     // 60 KB of LDS per workgroup caps residency at two workgroups per CU.
     const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);
-    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= 160 * 1024;
+    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= 156 * 1024;
     if (c->opt_stage == 0) stage = false;
-    if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= 160 * 1024;
+    if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= 156 * 1024;
     const size_t smem_total = smem + (stage ? table_bytes + 16 : 0);
     c->last_smem = (long)smem_total;
     c->last_stage = stage ? 1 : 0;
@@ -480,9 +480,14 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         static size_t granted[16][16] = {};       // [device][variant]
         size_t &g = granted[c->device & 15][vi_of_kernel];
         if (smem_total > g) {
+            // 160 KB per CU, minus the kernel's static 2 KB table and some slack
+            const size_t ceiling = 160 * 1024 - 4096;
+            if (smem_total > ceiling) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
+            size_t want = (smem_total + 32767) & ~(size_t)32767;
+            if (want > ceiling) want = ceiling;
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
-            g = 160 * 1024;
+                                       (int)want));
+            g = want;
         }
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_total, c->stream, a);
