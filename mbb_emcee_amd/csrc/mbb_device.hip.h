@@ -41,6 +41,15 @@ constexpr double kUmToGHz = 299792458e-3;
 constexpr double kLog1e9HoK = -3.036713188283967;     // log(1e9 h / k)
 constexpr double kLogUmToGHz = 12.610845707563017;    // log(299792.458)
 
+// diagnostic build only: s_memtime stamps from inside the prologue (tools/probe_stamps.py)
+#ifdef MBB_STAMPS
+__device__ unsigned long long *g_pstamps;
+#define PSTAMP(i, dep) do { if (threadIdx.x == 0 && blockIdx.x < 65536 && g_pstamps) { \
+    asm volatile("" ::"v"(dep)); g_pstamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PSTAMP(i, dep) do { } while (0)
+#endif
+
 enum RowStatus : int { ROW_OK = 0, ROW_BELOW_LOWLIM = 1, ROW_BAD_ALPHA = 2,
                        ROW_BAD_BETA = 3, ROW_NOCONV = 6, ROW_NONFINITE = 7, ROW_SKIP = -1 };
 
@@ -62,7 +71,7 @@ struct WalkerK {
 };
 
 // SED scalars in the reference's own terms (for parity of the constructor).
-struct SedScalars { double normfac, xmerge, kappa, x0, hcokt, lhokt9, lx0; };
+struct SedScalars { double normfac, xmerge, kappa, hcokt, hokt9, lhokt9, lx0; };
 
 __device__ __forceinline__ bool finite5(const double *p)
 {
@@ -72,18 +81,84 @@ __device__ __forceinline__ bool finite5(const double *p)
     return ok;
 }
 
-// h(y) = y / expm1(y) and its derivative; y = (x/x0)^beta >= 0.
+// ---- rows ---------------------------------------------------------------------
+// In the fused kernel a walker's prologue is latency: nothing else in its workgroup
+// can start before it, and a lone lane issues one dependent fp64 operation every
+// ~9 cycles.  So the prologue runs on a *row* of 16 lanes (one DPP row) per walker.
+// All lanes of a row hold the same scalars and execute the same instructions;
+// where the algebra has several independent exp / expm1 / log evaluations they are
+// dealt to the lanes of the row (lane i takes argument i) and one call does them
+// all, the results coming back through DPP row broadcasts.  ROW = false is the same
+// arithmetic, value for value, on a single lane (one-off kernels).
+template <int N>
+__device__ __forceinline__ double row_bcast(double v)      // lane N of each row -> its row
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + N, 0xf, 0xf, false);   // row_newbcast:N
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K, int I = 0>
+__device__ __forceinline__ void row_scatter(double res, double (&out)[K])
+{
+    if constexpr (I < K) {
+        out[I] = row_bcast<I>(res);
+        row_scatter<K, I + 1>(res, out);
+    }
+}
+
+// lane i of the row takes the i-th argument (scalars, not an array: an indexable
+// array would be spilled to scratch and fetched back by lane number)
+template <int I = 0, typename... Rest>
+__device__ __forceinline__ double row_pick(double first, Rest... rest)
+{
+    if constexpr (sizeof...(rest) == 0) return first;
+    else return ((int)(threadIdx.x & 15) == I) ? first : row_pick<I + 1>(rest...);
+}
+
+// out[i] = expm1(arg_i) where bit i of M1 is set, exp(arg_i) elsewhere
+template <bool ROW, unsigned M1, int K, typename... A>
+__device__ __forceinline__ void vexp(double (&out)[K], A... arg)
+{
+    static_assert(sizeof...(arg) == K, "one output per argument");
+    if constexpr (ROW) {
+        int k;
+        const double q = mbbm::expm1_reduced(mbbm::reduce_ln2(row_pick(arg...), k));
+        const double e = ldexp(1.0 + q, k);                     // m_exp
+        const double t = ldexp(1.0, k);
+        const double m = fma(t, q, t - 1.0);                    // m_expm1
+        row_scatter<K>(((M1 >> (threadIdx.x & 15)) & 1u) ? m : e, out);
+    } else {
+        const double a[K] = {arg...};
+#pragma unroll
+        for (int i = 0; i < K; ++i) out[i] = ((M1 >> i) & 1u) ? m_expm1(a[i]) : m_exp(a[i]);
+    }
+}
+
+template <bool ROW, int K, typename... A>
+__device__ __forceinline__ void vlog(double (&out)[K], A... arg)
+{
+    static_assert(sizeof...(arg) == K, "one output per argument");
+    if constexpr (ROW) {
+        row_scatter<K>(m_log(row_pick(arg...)), out);
+    } else {
+        const double a[K] = {arg...};
+#pragma unroll
+        for (int i = 0; i < K; ++i) out[i] = m_log(a[i]);
+    }
+}
+
+// h(y) = y / expm1(y) and its derivative, E = expm1(y); y = (x/x0)^beta >= 0.
 // Large y: the reference catches OverflowError and uses 0
 // (modified_blackbody.py:144-150).
-__device__ __forceinline__ void h_and_dh(double y, double &h, double &dh)
+__device__ __forceinline__ void h_and_dh(double y, double E, double &h, double &dh)
 {
-    if (!(y < 700.0)) { h = 0.0; dh = 0.0; }
-    else if (y < 1e-4) { h = 1.0 - 0.5 * y + y * y * (1.0 / 12.0); dh = -0.5 + y * (1.0 / 6.0); }
-    else {
-        const double rE = m_div(1.0, m_expm1(y));
-        h = y * rE;
-        dh = (1.0 - h - y) * rE;
-    }
+    const double rE = m_div(1.0, E);
+    const double hh = y * rE, dd = (1.0 - hh - y) * rE;
+    const bool tiny = y < 1e-4, big = !(y < 700.0);
+    h = big ? 0.0 : (tiny ? 1.0 - 0.5 * y + y * y * (1.0 / 12.0) : hh);
+    dh = big ? 0.0 : (tiny ? -0.5 + y * (1.0 / 6.0) : dd);
 }
 
 // Root of alpha_merge_eqn (modified_blackbody.py:122-151)
@@ -92,64 +167,123 @@ __device__ __forceinline__ void h_and_dh(double y, double &h, double &dh)
 // halving from 0.1 and doubling from 15 and then calls brentq (:286-322).
 // g(2+alpha) < 0 < g(3+alpha+beta) holds for every alpha, beta >= 0 because
 // 0 <= h <= 1, and g has a single sign change, so that interval brackets the same
-// root.  Newton in u with the analytic derivative
-//   dg/du = x (1 - e^-x A) - (1 - e^-x) beta^2 h'(y) y
-// converges quadratically; a bracket keeps it safe.  Working in u makes the two
-// exps of an evaluation independent (x = e^u, y = e^(beta (u - log x0))) and
-// leaves log(xmerge) = u for the caller.
-// fp32 pre-solve of the same equation: a few Newton steps with the hardware
-// exp/log (microseconds matter here: the prologue is one lane per walker and
-// nothing else in the workgroup can start before it).  Good to ~1e-6 in u.
-__device__ inline float thick_merge_root_f32(float alpha, float beta, float lx0,
-                                             float ulo, float uhi, float u)
+// root.  Working in u makes the two exps of an evaluation independent
+// (x = e^u, y = e^(beta (u - log x0))) and leaves log(xmerge) = u for the caller.
+//
+// Stage 1, fp32 with the hardware exp/rcp: the 16 lanes of the row evaluate g at 16
+// equispaced points of the bracket, the count of negative values names the
+// sub-interval holding the root, three rounds shrink the bracket 3375-fold and a
+// secant step through its ends leaves ~1e-7 in u.  No derivative, no data-dependent
+// branch.
+// (raw v_exp_f32 / v_rcp_f32: 1 ulp, no denormal or division fix-up code)
+__device__ __forceinline__ float merge_eqn_f32(float u, float alpha3, float beta, float betal2,
+                                               float lx0)
 {
-    // four plain Newton steps, clamped to the bracket: from the midpoint that is
-    // float precision for every (alpha, beta, x0); no convergence test, so all
-    // lanes take the same path and rounding noise cannot trigger a slow fallback
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const float x = __expf(u);
-        const float y = __expf(beta * (u - lx0));
-        float h, dh;
-        if (!(y < 80.0f)) { h = 0.0f; dh = 0.0f; }
-        else if (y < 0.02f) { h = 1.0f - 0.5f * y + y * y * (1.0f / 12.0f); dh = -0.5f + y * (1.0f / 6.0f); }
-        else { const float rE = __frcp_rn(__expf(y) - 1.0f); h = y * rE; dh = (1.0f - h - y) * rE; }
-        const float em = __expf(-x), om = 1.0f - em;
-        const float A = 3.0f + alpha + beta * h;
-        const float g = x - om * A;
-        const float dg = x * (1.0f - em * A) - om * beta * beta * dh * y;
-        u = fminf(fmaxf(u - g * __frcp_rn(dg), ulo), uhi);
-    }
-    return u;
+    const float kL2e = 1.44269504088896341f;
+    const float x = __builtin_amdgcn_exp2f(u * kL2e);
+    const float y = __builtin_amdgcn_exp2f((u - lx0) * betal2);
+    const float rE = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y * kL2e) - 1.0f);
+    float h = (y < 0.02f) ? fmaf(y, fmaf(y, 1.0f / 12.0f, -0.5f), 1.0f) : y * rE;
+    h = (y < 80.0f) ? h : 0.0f;
+    const float om = 1.0f - __builtin_amdgcn_exp2f(x * -kL2e);
+    return fmaf(-om, fmaf(beta, h, alpha3), x);              // x - (1 - e^-x)(3 + alpha + beta h)
 }
 
+template <bool ROW>
+__device__ inline float thick_merge_root_f32(float alpha, float beta, float lx0, float ulo, float uhi)
+{
+    const float alpha3 = 3.0f + alpha, betal2 = beta * 1.44269504088896341f;
+    float glo = -1.0f, ghi = 1.0f;
+#pragma unroll
+    for (int round = 0; round < 3; ++round) {
+        const float du = (uhi - ulo) * (1.0f / 15.0f);
+        int j;
+        if constexpr (ROW) {
+            const int lane = threadIdx.x & 63;
+            const float g = merge_eqn_f32(fmaf((float)(lane & 15), du, ulo), alpha3, beta, betal2, lx0);
+            const unsigned long long neg = __builtin_amdgcn_ballot_w64(g < 0.0f);
+            j = __popc((unsigned)(neg >> (lane & 48)) & 0xffffu);
+            j = min(max(j, 1), 15);
+            if (round == 2) {
+                glo = __shfl(g, (lane & 48) + j - 1);
+                ghi = __shfl(g, (lane & 48) + j);
+            }
+        } else {
+            float g[16];
+            j = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                g[i] = merge_eqn_f32(fmaf((float)i, du, ulo), alpha3, beta, betal2, lx0);
+                j += (g[i] < 0.0f) ? 1 : 0;
+            }
+            j = min(max(j, 1), 15);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                glo = (i == j - 1) ? g[i] : glo;
+                ghi = (i == j) ? g[i] : ghi;
+            }
+        }
+        const float nlo = fmaf((float)(j - 1), du, ulo), nhi = fmaf((float)j, du, ulo);
+        ulo = nlo; uhi = nhi;
+    }
+    const float u = ulo - glo * (uhi - ulo) * __builtin_amdgcn_rcpf(ghi - glo);
+    return (u >= ulo && u <= uhi) ? u : 0.5f * (ulo + uhi);
+}
+
+// Stage 2, fp64 Newton in u with the analytic derivative
+//   dg/du = x (1 - e^-x A) - (1 - e^-x) beta^2 h'(y) y,   A = 3 + alpha + beta h
+// inside the analytic bracket, accepted when a step is below 1e-6 (quadratic
+// convergence: < 1e-12 left; brentq in the reference stops at 2e-12).  Normally one
+// evaluation.  An evaluation is two rounds of independent exps -- (x, y), then
+// (e^-x, expm1(y)) -- so each round is one row call.  PB: the prologue's own
+// normalisation exps ride in the idle lanes of the first evaluation:
+//   round 1 also gives  pb[0] = exp(pb[0]),  pb[1] = expm1(pb[1]),  pb[2] = exp(pb[2])
+//   round 2 also gives  pb[3] = expm1(-pb[0])
+template <bool ROW, bool PB>
 __device__ inline double thick_merge_root(double alpha, double beta, double lx0, int &status,
-                                          double &xroot, double &yroot, int *iters = nullptr)
+                                          double &xroot, double &yroot, double (&pb)[4],
+                                          int *iters = nullptr)
 {
     const double xlo = 2.0 + alpha, xhi = 3.0 + alpha + beta;
-    const float fulo = __logf((float)xlo) - 1e-5f, fuhi = __logf((float)xhi) + 1e-5f;
+    const float kLn2 = 0.693147180559945309f;
+    const float fulo = __builtin_amdgcn_logf((float)xlo) * kLn2 - 1e-5f;
+    const float fuhi = __builtin_amdgcn_logf((float)xhi) * kLn2 + 1e-5f;
     double ulo = (double)fulo, uhi = (double)fuhi;
-    double u = (double)thick_merge_root_f32((float)alpha, (float)beta, (float)lx0, fulo, fuhi,
-                                            __logf((float)(0.5 * (xlo + xhi))));
+    double u = (double)thick_merge_root_f32<ROW>((float)alpha, (float)beta, (float)lx0, fulo, fuhi);
+    if (!(u >= ulo && u <= uhi)) u = 0.5 * (ulo + uhi);
+    PSTAMP(11, u);
     status = ROW_NOCONV;
     xroot = 0.0; yroot = 0.0;
     for (int it = 0; it < 80; ++it) {
-        const double x = m_exp(u);
-        const double y = m_exp(beta * (u - lx0));
+        double x, y, em, E;
+        if (PB && it == 0) {
+            double o1[5];
+            vexp<ROW, 0x08u>(o1, u, beta * (u - lx0), pb[0], pb[1], pb[2]);
+            x = o1[0]; y = o1[1]; pb[0] = o1[2]; pb[1] = o1[3]; pb[2] = o1[4];
+            PSTAMP(12, x + y + pb[0] + pb[1] + pb[2]);
+            double o2[3];
+            vexp<ROW, 0x06u>(o2, -x, y, -pb[0]);
+            em = o2[0]; E = o2[1]; pb[3] = o2[2];
+            PSTAMP(13, em + E + pb[3]);
+        } else {
+            double o1[2];
+            vexp<ROW, 0x00u>(o1, u, beta * (u - lx0));
+            x = o1[0]; y = o1[1];
+            double o2[2];
+            vexp<ROW, 0x02u>(o2, -x, y);
+            em = o2[0]; E = o2[1];
+        }
         double h, dh;
-        h_and_dh(y, h, dh);
-        const double em = m_exp(-x), om = 1.0 - em;
+        h_and_dh(y, E, h, dh);
+        const double om = 1.0 - em;
         const double A = 3.0 + alpha + beta * h;
         const double g = x - om * A;
         const double dg = x * (1.0 - em * A) - om * beta * beta * dh * y;
         if (iters) *iters = it + 1;
         if (g == 0.0) { xroot = x; yroot = y; status = ROW_OK; break; }
         if (g < 0.0) ulo = u; else uhi = u;
-        const double step = -g / dg;
+        const double step = m_div(-g, dg);          // dg > 0 around the root
         if (fabs(step) <= 1e-6) {
-            // Newton is quadratic with |g''/2g'| < 1: the error left after a step
-            // of 1e-6 is below 1e-12 (the fp32 pre-solve normally leaves ~1e-7, so
-            // ~1e-14; brentq in the reference stops at 2e-12).  One fp64 evaluation.
             // x e^step and y e^(beta step) to third order: exact to 1e-24
             u += step;
             xroot = x * (1.0 + step * (1.0 + step * (0.5 + step * (1.0 / 6.0))));
@@ -186,57 +320,70 @@ __device__ inline double thin_fixed_point(double a)
 }
 
 // modified_blackbody.__init__ (modified_blackbody.py:168-337).
-// lnunorm = log(um_to_GHz / wavenorm), a per-fit constant.
-template <bool OPTHIN, bool NOALPHA>
-__device__ inline int sed_prologue(double T, double beta, double lambda0, double alpha,
-                                   double fnorm, double wavenorm, double lnunorm,
-                                   SedScalars &s, int *iters = nullptr)
+// lT = log T and lL = log lambda0 come from the caller's vlog (the sampler adds its
+// own logs to that call); nunorm = um_to_GHz / wavenorm and lnunorm = log(nunorm)
+// are per-fit constants.  Quotients with a positive denominator use m_div.
+template <bool OPTHIN, bool NOALPHA, bool ROW>
+__device__ inline int sed_prologue(double T, double beta, double alpha, double fnorm, double lT,
+                                   double lL, double nunorm, double lnunorm, SedScalars &s,
+                                   int *iters = nullptr)
 {
     const double nan = __builtin_nan("");
-    s.normfac = nan; s.xmerge = nan; s.kappa = nan; s.x0 = nan; s.hcokt = nan;
+    s.normfac = nan; s.xmerge = nan; s.kappa = nan; s.hcokt = nan; s.hokt9 = nan;
     s.lhokt9 = nan; s.lx0 = 0.0;
     if (!NOALPHA && alpha <= 0.0) return ROW_BAD_ALPHA;             // :219-221
     if (beta < 0.0) return ROW_BAD_BETA;                            // :222-224
-    const double hcokt = kH * kC_um / (kK * T);                     // :228
-    s.hcokt = hcokt;
-    const double xnorm = hcokt / wavenorm;                          // :233
-    const double lhokt9 = kLog1e9HoK - m_log(T);
+    const double hokt9 = m_div(1e9 * kH / kK, T);                   // fnu.pyx:16, per GHz
+    s.hokt9 = hokt9;
+    s.hcokt = hokt9 * kUmToGHz;                                     // :228, h c / k T in um
+    const double xnorm = hokt9 * nunorm;                            // :233
+    const double lhokt9 = kLog1e9HoK - lT;
     s.lhokt9 = lhokt9;
     const double lxnorm = lhokt9 + lnunorm;                         // log(xnorm)
     int status = ROW_OK;
     if (OPTHIN) {
         // fnorm expm1(xnorm) / xnorm^(3+beta)                       :240-241, :268-269
-        const double bbnorm = fnorm * m_expm1(xnorm) * m_exp(-(3.0 + beta) * lxnorm);
         if (NOALPHA) {
-            s.normfac = bbnorm;
+            double o1[2];
+            vexp<ROW, 0x01u>(o1, xnorm, -(3.0 + beta) * lxnorm);
+            s.normfac = fnorm * o1[0] * o1[1];
         } else {
             const double a = 3.0 + alpha + beta;                    // :253-254
             s.xmerge = thin_fixed_point(a);
-            s.kappa = m_exp(a * m_log(s.xmerge)) / m_expm1(s.xmerge);   // :259-261
+            double lxm[1];
+            vlog<ROW>(lxm, s.xmerge);
+            double o1[5];
+            vexp<ROW, 0x09u>(o1, xnorm, -(3.0 + beta) * lxnorm, a * lxm[0], s.xmerge, alpha * lxnorm);
+            s.kappa = m_div(o1[2], o1[3]);                          // :259-261
             if (xnorm > s.xmerge)                                   // :264-266
-                s.normfac = fnorm * m_exp(alpha * lxnorm) / s.kappa;
+                s.normfac = m_div(fnorm * o1[4], s.kappa);
             else
-                s.normfac = bbnorm;
+                s.normfac = fnorm * o1[0] * o1[1];
         }
     } else {
-        const double x0 = hcokt / lambda0;                          // :232
-        s.x0 = x0;
-        const double lx0 = lhokt9 + kLogUmToGHz - m_log(lambda0);   // log(x0)
+        const double lx0 = lhokt9 + kLogUmToGHz - lL;               // log(x0), :232
         s.lx0 = lx0;
         // (xnorm/x0)^beta; -fnorm expm1(xnorm) / (expm1(-(..)^beta) xnorm^3)   :274-276, :335-337
-        const double ynorm = m_exp(beta * (lxnorm - lx0));
-        const double bbnorm = fnorm * m_expm1(xnorm) /
-            (-m_expm1(-ynorm) * (xnorm * xnorm * xnorm));
         if (NOALPHA) {
-            s.normfac = bbnorm;
+            double o1[2];
+            vexp<ROW, 0x02u>(o1, beta * (lxnorm - lx0), xnorm);
+            double o2[1];
+            vexp<ROW, 0x01u>(o2, -o1[0]);
+            s.normfac = m_div(fnorm * o1[1], -o2[0] * (xnorm * xnorm * xnorm));
         } else {
             double xm, ym;
-            const double um = thick_merge_root(alpha, beta, lx0, status, xm, ym, iters); // :286-322
+            double pb[4] = {beta * (lxnorm - lx0), xnorm, alpha * lxnorm, 0.0};
+            const double um = thick_merge_root<ROW, true>(alpha, beta, lx0, status, xm, ym, pb, iters); // :286-322
+            PSTAMP(14, um + xm + ym);
+            const double bbnorm = m_div(fnorm * pb[1], -pb[3] * (xnorm * xnorm * xnorm));
             s.xmerge = xm;
             // -xm^(3+alpha) expm1(-(xm/x0)^beta) / expm1(xm)          :326-328
-            s.kappa = m_exp((3.0 + alpha) * um) * -m_expm1(-ym) / m_expm1(xm);
+            double o3[3];
+            vexp<ROW, 0x06u>(o3, (3.0 + alpha) * um, -ym, xm);
+            PSTAMP(15, o3[0] + o3[1] + o3[2]);
+            s.kappa = m_div(o3[0] * -o3[1], o3[2]);
             if (xnorm > xm)                                         // :331-333
-                s.normfac = fnorm * m_exp(alpha * lxnorm) / s.kappa;
+                s.normfac = m_div(fnorm * pb[2], s.kappa);
             else
                 s.normfac = bbnorm;
         }
@@ -249,7 +396,7 @@ __device__ inline int sed_prologue(double T, double beta, double lambda0, double
 //   thin : x = (3+beta)(1 - e^-x)
 //   thick: x = (1 - e^-x)(3 + beta h(y))       -- alpha_merge_eqn with alpha = 0
 // which is what the reference's _snudev root (:556-579) solves numerically.
-template <bool OPTHIN>
+template <bool OPTHIN, bool ROW>
 __device__ inline double sed_peak_wave(double T, double beta, double lx0, double hcokt,
                                        int &status)
 {
@@ -261,16 +408,15 @@ __device__ inline double sed_peak_wave(double T, double beta, double lx0, double
         }
         return hcokt / thin_fixed_point(3.0 + beta);
     }
-    double xp, yp;
-    thick_merge_root(0.0, beta, lx0, status, xp, yp);
+    double xp, yp, pb[4];
+    thick_merge_root<ROW, false>(0.0, beta, lx0, status, xp, yp, pb);
     return hcokt / xp;
 }
 
 template <bool OPTHIN, bool NOALPHA>
-__device__ inline void make_walker_k(double T, double beta, double alpha,
-                                     const SedScalars &s, WalkerK &w)
+__device__ inline void make_walker_k(double beta, double alpha, const SedScalars &s, WalkerK &w)
 {
-    w.hokt9 = 1e9 * kH / (kK * T);                                  // fnu.pyx:16
+    w.hokt9 = s.hokt9;
     w.lhokt9 = s.lhokt9;
     w.beta = beta;
     w.bp3 = beta + 3.0;
@@ -289,44 +435,76 @@ template <bool OPTHIN, bool NOALPHA, bool TAB = false>
 __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
                                              const Exp2Entry *tab = nullptr)
 {
-    auto ex = [&](double v) { if constexpr (TAB) return m_exp_t(v, tab); else return m_exp(v); };
-    auto em1 = [&](double v) { if constexpr (TAB) return m_expm1_t(v, tab); else return m_expm1(v); };
-    const double x = w.hokt9 * nu;
+    const double x = w.hokt9 * nu;                                  // > 0
     const double lx = w.lhokt9 + lnnu;
-    if (!NOALPHA) {
-        if (x > w.xmerge) return w.cpl * ex(-w.alpha * lx);         // :48-49, :102-103
-    }
-    if (OPTHIN) {
-        return w.cbb * m_div(ex(w.bp3 * lx), em1(x));               // :24-25, :51
+    if constexpr (TAB) {
+        // range clamps only where the argument can leave [-800, 800]
+        if (!NOALPHA) {
+            if (x > w.xmerge) return w.cpl * m_exp_t(-w.alpha * lx, tab);      // :48-49, :102-103
+        }
+        if (OPTHIN) {
+            return w.cbb * m_div(m_exp_t(w.bp3 * lx, tab), m_expm1_t<false, true>(x, tab));   // :24-25, :51
+        } else {
+            // y <= 800: expm1(-y) is -1 there anyway and -y needs no clamp of its own
+            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), 6.684), tab);  // :74, :105
+            return w.cbb * m_div(-m_expm1_t<false, false>(-y, tab) * (x * x * x),
+                                 m_expm1_t<false, true>(x, tab));               // :75-76, :106
+        }
     } else {
-        const double y = ex(w.beta * (lx - w.lx0));                 // :74, :105
-        return w.cbb * m_div(-em1(-y) * (x * x * x), em1(x));       // :75-76, :106
+        if (!NOALPHA) {
+            if (x > w.xmerge) return w.cpl * m_exp(-w.alpha * lx);
+        }
+        if (OPTHIN) {
+            return w.cbb * m_div(m_exp(w.bp3 * lx), m_expm1(x));
+        } else {
+            const double y = m_exp(w.beta * (lx - w.lx0));
+            return w.cbb * m_div(-m_expm1(-y) * (x * x * x), m_expm1(x));
+        }
     }
 }
 
 // wave64 sum through the DPP crossbar (no LDS traffic): butterflies inside each
 // row of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals upward;
 // the grand total lands in lane 63 and is broadcast through an SGPR.
+// KEEP: lanes the row mask leaves out keep v (the butterflies, where every lane has a
+// partner) or get 0 (the masked carries).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int plo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    const int phi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    constexpr bool all = ROW_MASK == 0xf;
+    const int plo = __builtin_amdgcn_update_dpp(all ? lo : 0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int phi = __builtin_amdgcn_update_dpp(all ? hi : 0, hi, CTRL, ROW_MASK, 0xf, false);
     return v + __hiloint2double(phi, plo);
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ double row_sum(double v)    // every lane: the total of its row
 {
     v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
     v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane holds its row's total
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v = row_sum(v);
     v = dpp_add<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
     v = dpp_add<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);    // uniform: the total in every lane
+}
+
+// The same total when only lanes 0..15 hold non-zero terms (the other rows would add
+// exact zeros): stop after the row stage.
+__device__ __forceinline__ double wave_sum_row0(double v)
+{
+    v = row_sum(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 0);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 0);
+    return __hiloint2double(hi, lo);
 }
 
 }  // namespace mbbd

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -87,7 +88,8 @@ struct mbb_ctx {
     // bands
     int nb = 0, nseg = 0, nchunk = 0, nq = 0;
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
-    int32_t *d_seg_c0 = nullptr, *d_band_s0 = nullptr;
+    int32_t *d_band_s0 = nullptr;
+    int4 *d_unit_tab = nullptr;
     // data
     int data_nb = 0, has_cov = 0, nsrc = 1;
     double *d_flux = nullptr, *d_ivar = nullptr, *d_invcov = nullptr;
@@ -167,7 +169,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
-    free_dev(c->d_seg_c0); free_dev(c->d_band_s0);
+    free_dev(c->d_unit_tab); free_dev(c->d_band_s0);
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
@@ -230,11 +232,32 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     }
     seg_c0.push_back(chunk);
     band_s0.push_back((int32_t)seg_c0.size() - 1);
+    // Dealing order.  Waves w, w+4, w+8, ... of a workgroup share a SIMD and unit u goes
+    // to wave u mod nwave, so position i of the table lands on SIMD i mod 4.  Longest
+    // segments first, each to the least loaded SIMD that still has a position free.
+    const int nseg = (int)seg_c0.size() - 1;
+    std::vector<int> by_size(nseg);
+    for (int i = 0; i < nseg; ++i) by_size[i] = i;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) {
+        return seg_c0[x + 1] - seg_c0[x] > seg_c0[y + 1] - seg_c0[y]; });
+    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+    std::vector<int4> unit_tab(nseg);
+    for (int k = 0; k < nseg; ++k) {
+        const int sgm = by_size[k];
+        int best = -1;
+        for (int g = 0; g < 4; ++g) {
+            if (g + 4 * used[g] >= nseg) continue;               // no position left on this SIMD
+            if (best < 0 || load[g] < load[best]) best = g;
+        }
+        unit_tab[best + 4 * used[best]] = make_int4(sgm, seg_c0[sgm], seg_c0[sgm + 1], 0);
+        load[best] += seg_c0[sgm + 1] - seg_c0[sgm];
+        ++used[best];
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = upload(&c->d_nu, nu))) return rc;
     if ((rc = upload(&c->d_lnnu, lnnu))) return rc;
     if ((rc = upload(&c->d_wt, wt))) return rc;
-    if ((rc = upload(&c->d_seg_c0, seg_c0))) return rc;
+    if ((rc = upload(&c->d_unit_tab, unit_tab))) return rc;
     if ((rc = upload(&c->d_band_s0, band_s0))) return rc;
     c->nb = nb;
     c->nchunk = chunk;
@@ -367,8 +390,7 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     // Small batches (an emcee half-step) are latency bound: one walker per
     // workgroup with about one segment per wave, so the chip sees n workgroups.
     // Once there are more walkers than CUs, 256-thread workgroups; beyond
-    // 8 workgroups per CU several walkers share a workgroup (lane-per-walker
-    // prologue amortised over up to 64 walkers).
+    // 8 workgroups per CU several walkers share a workgroup.
     const long cus = c->cu_count;
     long w = (n + cus * 8 - 1) / (cus * 8);
     if (w < 1) w = 1;
@@ -385,6 +407,8 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     if (t < 64) t = 64;
     if (t > 1024) t = 1024;
     threads = (int)((t / 64) * 64);
+    // the prologue runs on one row of 16 lanes per walker
+    if (threads < 16 * wpb) threads = ((16 * wpb + 63) / 64) * 64;
 }
 
 struct SamplerLaunch {
@@ -404,10 +428,11 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
-    a.seg_c0 = c->d_seg_c0; a.band_s0 = c->d_band_s0;
+    a.unit_tab = c->d_unit_tab; a.band_s0 = c->d_band_s0;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
-    a.nb = c->nb; a.nseg = c->nseg; a.nchunk = c->nchunk; a.wavenorm = c->wavenorm;
-    a.lnunorm = log(kUmToGHz / c->wavenorm);
+    a.nb = c->nb; a.nseg = c->nseg; a.nchunk = c->nchunk;
+    a.nunorm = kUmToGHz / c->wavenorm;
+    a.lnunorm = log(a.nunorm);
     for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
     for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
     a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
@@ -826,7 +851,7 @@ static int run_prologue(mbb_ctx *c, const double *pars, int n, int opthin, int n
     const int threads = 64, grid = (n + threads - 1) / threads;
     dispatch_variant(opthin, noalpha, [&](auto OT, auto NA) {
         hipLaunchKernelGGL((k_prologue<decltype(OT)::value, decltype(NA)::value>), dim3(grid),
-                           dim3(threads), 0, c->stream, c->d_sed_pars, n, wavenorm,
+                           dim3(threads), 0, c->stream, c->d_sed_pars, n, kUmToGHz / wavenorm,
                            log(kUmToGHz / wavenorm), want_peak, d_out6, c->d_sed_status,
                            c->d_sed_wk);
     });
@@ -1025,12 +1050,13 @@ extern "C" int mbb_stamps(mbb_ctx *c, unsigned long long *host, int nblocks)
     int rc = use(c);
     if (rc) return rc;
     if (!c->d_stamps) {
-        HIPCHK(hipMalloc((void **)&c->d_stamps, 8 * sizeof(unsigned long long) * 65536));
-        HIPCHK(hipMemset(c->d_stamps, 0, 8 * sizeof(unsigned long long) * 65536));
+        HIPCHK(hipMalloc((void **)&c->d_stamps, 32 * sizeof(unsigned long long) * 65536));
+        HIPCHK(hipMemset(c->d_stamps, 0, 32 * sizeof(unsigned long long) * 65536));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(mbbd::g_pstamps), &c->d_stamps, sizeof(c->d_stamps)));
     }
     if (host) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        HIPCHK(hipMemcpy(host, c->d_stamps, 8 * sizeof(unsigned long long) * nblocks, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(host, c->d_stamps, 32 * sizeof(unsigned long long) * nblocks, hipMemcpyDeviceToHost));
     }
     return MBB_OK;
 }

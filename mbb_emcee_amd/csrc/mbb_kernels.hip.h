@@ -32,15 +32,15 @@ struct LikeArgs {
     const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
     const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
     const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
-    const int32_t *seg_c0;    // [nseg+1] first chunk of each segment
+    const int4 *unit_tab;     // [nseg] {segment, first chunk, end chunk, 0} in dealing order
     const int32_t *band_s0;   // [nb+1]   first segment of each band
     const double *flux;       // [nb]
     const double *ivar;       // [nb]
     const double *invcov;     // [nb*nb] or nullptr
     int cov_in_lds;           // C^-1 copied to LDS (it fits) or read from global
     int nb, nseg, nchunk;
-    double wavenorm;
-    double lnunorm;           // log(um_to_GHz / wavenorm)
+    double nunorm;            // um_to_GHz / wavenorm, GHz
+    double lnunorm;           // log(nunorm)
     double lowlim[5];
     double uplim[6];
     double gmean[6];
@@ -92,7 +92,7 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 }
 
 // Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
-//   phase 1: lane-per-walker prologue (wave 0)            -> LDS
+//   phase 1: prologue, one row of 16 lanes per walker     -> LDS
 //   phase 2: (walker, segment) units dealt round-robin to waves; a lane strides
 //            over the segment's samples, then one wave64 shuffle reduction
 //   phase 3: band sums in fixed order, then one lane per walker forms lnL
@@ -118,30 +118,50 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
     double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
     // STAGE: the passband tables themselves (nu, log nu, weight), [nchunk*64] each
-    double *s_nu = reinterpret_cast<double *>(
-        (reinterpret_cast<uintptr_t>(prop + 8 * (size_t)W) + 15) & ~(uintptr_t)15);
+    // (offset arithmetic on smem_raw, not on a pointer cast to an integer: the latter
+    // loses the LDS address space and every table read becomes a flat load)
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(prop + 8 * (size_t)W) - smem_raw) + 15) &
+                           ~(size_t)15;
+    double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const int w0 = blockIdx.x * W;
+    // The compiler fetches kernel arguments where they are first used, one exposed
+    // scalar-cache round trip (~200 cycles) each; on the latency path that is a
+    // dozen of them.  Ask for the hot ones here so that they arrive in one batch.
+#define PIN(x) asm volatile("" ::"s"(x))
+    PIN(a.n); PIN(a.pars); PIN(a.nunorm); PIN(a.lnunorm); PIN(a.has_uplim); PIN(a.has_gprior);
+    PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]);
+    PIN(a.unit_tab); PIN(a.lnl); PIN(a.status); PIN(a.model_flux); PIN(a.invcov); PIN(a.nsrc);
+    PIN(a.debug); PIN(a.flux); PIN(a.ivar); PIN(a.rows_per_src);
+#undef PIN
 #ifdef MBB_STAMPS
-#define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();   // before the kernarg arrives
+#define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMPD(i, dep) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) { asm volatile("" ::"v"(dep)); a.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + 7] = t_entry;
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPD(i, dep) do { } while (0)
 #endif
     STAMP(0);
 
-    // While wave 0 runs the serial prologue the other waves stage the data the
-    // epilogue needs in LDS and pull their first segment's samples and the index
-    // table into this CU's L1, so that nothing after the barrier waits on L2.
-    if (wave > 0 || nwave == 1) {
-        const int t0 = (nwave == 1) ? tid : tid - 64, nt = (nwave == 1) ? 64 : (int)blockDim.x - 64;
+    // A walker's prologue runs on one row of 16 lanes (mbb_device.hip.h, "rows"), so
+    // the first ceil(16 W / 64) waves are prologue waves.  The other waves meanwhile
+    // stage what the later phases need in LDS and pull their first segment's samples
+    // and the index table into this CU's L1, so that nothing after the barrier waits
+    // on L2; without spare waves every wave stages first.
+    const int pwaves = min(nwave, (16 * W + 63) >> 6);
+    if (wave >= pwaves || pwaves == nwave) {
+        const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
+        const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
         for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
         for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
         for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
         if (a.cov_in_lds)
             for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
         if (STAGE) {
-            // passband tables -> LDS, 16 B per lane, while wave 0 is in the prologue
+            // passband tables -> LDS, 16 B per lane
             const int n2 = a.nchunk * 32;                      // double2 elements per array
             const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
             const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
@@ -150,13 +170,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
             double2 *l2 = reinterpret_cast<double2 *>(s_wt);
             for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-        } else {
+        } else if (wave >= pwaves) {
             const int u = wave;
             if (u < W * nseg) {
-                const int s = u % nseg;
-                const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
+                const int4 us = a.unit_tab[u % nseg];
                 double t = 0.0;
-                for (int c = c0; c < c1; ++c) {
+                for (int c = us.y; c < us.z; ++c) {
                     const int i = c * 64 + lane;
                     t += a.nu[i] + a.lnnu[i] + a.wt[i];
                 }
@@ -165,14 +184,21 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         }
     }
 
-    // ---- phase 1: gate + prologue + parameter-only penalties ----------------
-    if (tid < W) {
-        const int w = w0 + tid;
+    // this wave's first quadrature unit: asked for now, it is here when phase 2 begins
+    const int nunit = W * nseg;
+    int4 us_first = make_int4(0, 0, 0, 0);
+    if (wave < nunit) us_first = a.unit_tab[wave % nseg];
+
+    // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
+    // (the host guarantees blockDim.x >= 16 W)
+    if (const int j = tid >> 4; j < W) {
+        const int w = w0 + j;
+        const bool lead = (tid & 15) == 0;                    // the lane that writes to LDS
         WalkerK k;
         k.status = ROW_SKIP;
         double pen_u = 0.0, pen_g = 0.0;
         if (w < a.n) {
-            double p[5];
+            double p[5], lT, lL = 0.0;
             if (SAMPLER) {
                 // stretch move (Goodman & Weare 2010; what emcee does per half-step,
                 // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
@@ -195,14 +221,30 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 for (int i = 0; i < 5; ++i) {
                     const double cv = crow[i], sv = srow[i];
                     p[i] = cv - zz * (cv - sv);
-                    prop[tid * 8 + i] = p[i];
                 }
-                prop[tid * 8 + 5] = 4.0 * m_log(zz);          // (dim - 1) ln z, dim = 5
-                prop[tid * 8 + 6] = srow[5];
-                prop[tid * 8 + 7] = m_log(u3);
+                double lo[4];
+                vlog<true>(lo, p[0], p[2], zz, u3);
+                lT = lo[0]; lL = lo[1];
+                if (lead) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) prop[j * 8 + i] = p[i];
+                    prop[j * 8 + 5] = 4.0 * lo[2];            // (dim - 1) ln z, dim = 5
+                    prop[j * 8 + 6] = srow[5];
+                    prop[j * 8 + 7] = lo[3];                  // ln u
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
+                STAMPD(8, p[0] + p[1] + p[2] + p[3] + p[4]);
+                if (OPTHIN) {
+                    double lo[1];
+                    vlog<true>(lo, p[0]);
+                    lT = lo[0];
+                } else {
+                    double lo[2];
+                    vlog<true>(lo, p[0], p[2]);
+                    lT = lo[0]; lL = lo[1];
+                }
             }
             bool ok = true;                                   // likelihood.py:643-670
 #pragma unroll
@@ -216,10 +258,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             } else {
                 SedScalars s;
                 k.pad = 0;
-                k.status = sed_prologue<OPTHIN, NOALPHA>(p[0], p[1], p[2], p[3], p[4],
-                                                         a.wavenorm, a.lnunorm, s, &k.pad);
+                k.status = sed_prologue<OPTHIN, NOALPHA, true>(p[0], p[1], p[3], p[4], lT, lL,
+                                                               a.nunorm, a.lnunorm, s, &k.pad);
+                STAMPD(9, s.normfac);
                 if (k.status == ROW_OK) {
-                    make_walker_k<OPTHIN, NOALPHA>(p[0], p[1], p[3], s, k);
+                    make_walker_k<OPTHIN, NOALPHA>(p[1], p[3], s, k);
                     // _uplim_prior, likelihood.py:672-717
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
@@ -231,7 +274,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     double peak = 0.0;
                     if (((a.has_uplim | a.has_gprior) >> 5) & 1u) {
                         int pst;
-                        peak = sed_peak_wave<OPTHIN>(p[0], p[1], k.lx0, s.hcokt, pst);
+                        peak = sed_peak_wave<OPTHIN, true>(p[0], p[1], k.lx0, s.hcokt, pst);
                         if (pst != ROW_OK) k.status = pst;
                         k.peak = peak;
                     }
@@ -253,24 +296,29 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 }
             }
         }
-        wk[tid] = k;
-        pen[2 * tid] = pen_u;
-        pen[2 * tid + 1] = pen_g;
+        STAMPD(10, pen_u + pen_g);
+        if (lead) {
+            wk[j] = k;
+            pen[2 * j] = pen_u;
+            pen[2 * j + 1] = pen_g;
+        }
     }
     STAMP(1);
     __syncthreads();
     STAMP(2);
 
     // ---- phase 2: passband quadrature (response.py:572-576) -----------------
-    const int nunit = W * nseg;
     auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     for (int u = wave; u < nunit; u += nwave) {
-        const int j = u / nseg, s = u - j * nseg;
+        const int j = u / nseg;
+        // the table deals the segments so that the four SIMDs (wave mod 4) of the CU
+        // get equal numbers of chunks; which wave sums a segment does not change it
+        const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nseg];
         if (wk[j].status != ROW_OK) continue;                 // wave-uniform
         const WalkerK k = wk[j];
-        const int c0 = a.seg_c0[s], c1 = a.seg_c0[s + 1];
+        const int s = us.x, c0 = us.y, c1 = us.z;
         double acc = 0.0;
         int c = c0;
         for (; c + 2 <= c1; c += 2) {          // two independent chains in flight
@@ -288,36 +336,83 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             acc = fma(f, T_wt(i), acc);
         }
         acc = wave_sum(acc);
-        if (lane == 0) partial[u] = acc;
+        if (lane == 0) partial[j * nseg + s] = acc;
     }
     STAMP(3);
-    __syncthreads();
-    STAMP(4);
-    STAMP(5);
 
     // ---- phase 3: one wave per walker, one lane per band (likelihood.py:821-834)
-    for (int j = wave; j < W; j += nwave) {
-        const int st = wk[j].status;
-        if (st == ROW_SKIP) continue;                          // wave-uniform
+    // Whatever does not depend on the segment sums is fetched before the barrier, for
+    // the wave's first walker and the lane's first band: a wave that is done with its
+    // quadrature early would only wait there.  The code after the barrier is peeled
+    // the same way (FIRST), so that the usual case -- one walker per wave, at most 64
+    // bands -- runs without the bookkeeping of the general loops.
+    const bool multi = a.nsrc > 1;
+    // data of walker w's source: the LDS copy for one source, global for many
+    auto band_data = [&](int w, int b, double &fb, double &ib) {
+        if (multi) {
+            const int src = SAMPLER ? (w / a.m_count) : (w / a.rows_per_src);
+            fb = a.flux[(size_t)src * nb + b];
+            ib = a.ivar[(size_t)src * nb + b];
+        } else {
+            fb = s_flux[b];
+            ib = s_ivar[b];
+        }
+    };
+    int st_first = ROW_SKIP, sb_first0 = 0, sb_first1 = 0, pad_first = 0;
+    double fb_first = 0.0, ib_first = 0.0, pen_u_first = 0.0, pen_g_first = 0.0;
+    double *lnl_first = nullptr;
+    int32_t *status_first = nullptr;
+    if (wave < W) {
+        st_first = wk[wave].status;
+        pad_first = wk[wave].pad;
+        pen_u_first = pen[2 * wave];
+        pen_g_first = pen[2 * wave + 1];
+        if (a.lnl) lnl_first = a.lnl + (w0 + wave);
+        if (a.status) status_first = a.status + (w0 + wave);
+        if (lane < nb) {
+            sb_first0 = s_band[lane];
+            sb_first1 = s_band[lane + 1];
+            band_data(w0 + wave, lane, fb_first, ib_first);
+        }
+    }
+    __syncthreads();
+    STAMP(4);
+
+    auto epilogue = [&](const int j, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const int st = FIRST ? st_first : wk[j].status;
+        if (st == ROW_SKIP) return;                            // wave-uniform
         const int w = w0 + j;
+        const double pen_u = FIRST ? pen_u_first : pen[2 * j];
+        const double pen_g = FIRST ? pen_g_first : pen[2 * j + 1];
         double acc = 0.0;
         if (st == ROW_OK) {
             double *mf = mflux + (size_t)j * nb;
-            // data of this walker's source: LDS copy for one source, global for many
-            const double *fsrc = s_flux, *isrc = s_ivar;
-            if (a.nsrc > 1) {
-                const int src = SAMPLER ? (w / a.m_count) : (w / a.rows_per_src);
-                fsrc = a.flux + (size_t)src * nb;
-                isrc = a.ivar + (size_t)src * nb;
-            }
-            for (int b = lane; b < nb; b += 64) {              // band fluxes, fixed order
+            const double *pj = partial + j * nseg;
+            auto band = [&](const int b, auto firstb_c) {      // band flux, fixed order
+                constexpr bool FB = decltype(firstb_c)::value;
                 double sum = 0.0;
-                for (int sg = s_band[b]; sg < s_band[b + 1]; ++sg) sum += partial[j * nseg + sg];
+                const int sg0 = FB ? sb_first0 : s_band[b];
+                const int sg1 = FB ? sb_first1 : s_band[b + 1];
+                for (int sg = sg0; sg < sg1; sg += 4) {        // four reads per wait, same order
+                    const int l = sg1 - 1;
+                    const double q0 = pj[sg], q1 = pj[min(sg + 1, l)], q2 = pj[min(sg + 2, l)],
+                                 q3 = pj[min(sg + 3, l)];
+                    sum += q0;
+                    if (sg + 1 < sg1) sum += q1;
+                    if (sg + 2 < sg1) sum += q2;
+                    if (sg + 3 < sg1) sum += q3;
+                }
                 if (a.model_flux) a.model_flux[(size_t)w * nb + b] = sum;
-                const double d = fsrc[b] - sum;                // :821
+                double fb = fb_first, ib = ib_first;
+                if (!FB) band_data(w, b, fb, ib);
+                const double d = fb - sum;                     // :821
                 if (a.invcov) mf[b] = d;
-                else acc = fma(d * d, isrc[b], acc);           // :825
-            }
+                else acc = fma(d * d, ib, acc);                // :825
+            };
+            if (lane < nb) band(lane, first_c);
+            if (nb > 64)
+                for (int b = lane + 64; b < nb; b += 64) band(b, std::false_type{});
             if (a.invcov) {                                    // :823
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -328,7 +423,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     acc = fma(mf[i], t, acc);
                 }
             }
-            acc = wave_sum(acc);
+            STAMPD(5, acc);
+            acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
+            STAMPD(16, acc);
         } else if (a.model_flux) {
             for (int b = lane; b < nb; b += 64) a.model_flux[(size_t)w * nb + b] = __builtin_nan("");
         }
@@ -338,9 +435,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             else if (st != ROW_OK) r = __builtin_nan("");
             else {
                 r = -0.5 * acc;
-                r += pen[2 * j];                               // :828
-                if (a.has_gprior) r += pen[2 * j + 1];         // :830-831
+                r += pen_u;                                    // :828
+                if (a.has_gprior) r += pen_g;                  // :830-831
             }
+            double *lnl_out = FIRST ? lnl_first : (a.lnl ? a.lnl + w : nullptr);
+            int32_t *status_out = FIRST ? status_first : (a.status ? a.status + w : nullptr);
             if (SAMPLER) {
                 // accept with probability min(1, z^(dim-1) P(q)/P(s))
                 const int src = w / a.m_count;
@@ -361,19 +460,20 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
                     crow[5] = accept ? r : q[6];
                 }
-                if (a.lnl) a.lnl[w] = r;
-            } else {
-                a.lnl[w] = r;
             }
-            if (a.status) a.status[w] = a.debug ? (st | (wk[j].pad << 8)) : st;
+            if (lnl_out) *lnl_out = r;
+            if (status_out) *status_out = a.debug ? (st | ((FIRST ? pad_first : wk[j].pad) << 8)) : st;
         }
-    }
+    };
+    if (wave < W) epilogue(wave, std::true_type{});
+    if (W > nwave)
+        for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
     STAMP(6);
 }
 
 // modified_blackbody.__init__ + max_wave for n rows, one lane per row.
 template <bool OPTHIN, bool NOALPHA>
-__global__ void k_prologue(const double *pars, int n, double wavenorm, double lnunorm,
+__global__ void k_prologue(const double *pars, int n, double nunorm, double lnunorm,
                            int want_peak, double *out, int32_t *status, WalkerK *wk_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,18 +484,19 @@ __global__ void k_prologue(const double *pars, int n, double wavenorm, double ln
     const double p5[5] = {T, beta, lambda0, alpha, fnorm};
     int st = ROW_NONFINITE;
     if (finite5(p5))
-        st = sed_prologue<OPTHIN, NOALPHA>(T, beta, lambda0, alpha, fnorm, wavenorm, lnunorm, s);
+        st = sed_prologue<OPTHIN, NOALPHA, false>(T, beta, alpha, fnorm, m_log(T),
+                                                  OPTHIN ? 0.0 : m_log(lambda0), nunorm, lnunorm, s);
     else
-        s.normfac = s.xmerge = s.kappa = s.x0 = s.hcokt = __builtin_nan("");
+        s.normfac = s.xmerge = s.kappa = s.hcokt = __builtin_nan("");
     const double nan = __builtin_nan("");
     double peak = nan;
     WalkerK k;
     k.status = st;
     if (st == ROW_OK) {
-        make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
+        make_walker_k<OPTHIN, NOALPHA>(beta, alpha, s, k);
         if (want_peak) {
             int pst;
-            peak = sed_peak_wave<OPTHIN>(T, beta, k.lx0, s.hcokt, pst);
+            peak = sed_peak_wave<OPTHIN, false>(T, beta, k.lx0, s.hcokt, pst);
             if (pst != ROW_OK) st = pst;
         }
     }
@@ -404,7 +505,7 @@ __global__ void k_prologue(const double *pars, int n, double wavenorm, double ln
         out[i * 6 + 0] = s.normfac;
         out[i * 6 + 1] = s.xmerge;
         out[i * 6 + 2] = s.kappa;
-        out[i * 6 + 3] = s.x0;
+        out[i * 6 + 3] = OPTHIN ? nan : s.hcokt / lambda0;         // x0, :232
         out[i * 6 + 4] = NOALPHA ? nan : s.hcokt / s.xmerge;        // wavemerge :382-388
         out[i * 6 + 5] = peak;
     }
@@ -479,11 +580,12 @@ __global__ void k_fnu_explicit(const double *freq, int n, double T, double beta,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     SedScalars s;
-    s.normfac = normfac; s.xmerge = xmerge; s.kappa = kappa; s.x0 = x0; s.hcokt = 0.0;
+    s.normfac = normfac; s.xmerge = xmerge; s.kappa = kappa; s.hcokt = 0.0;
+    s.hokt9 = m_div(1e9 * kH / kK, T);
     s.lhokt9 = kLog1e9HoK - m_log(T);
     s.lx0 = OPTHIN ? 0.0 : m_log(x0);
     WalkerK k;
-    make_walker_k<OPTHIN, NOALPHA>(T, beta, alpha, s, k);
+    make_walker_k<OPTHIN, NOALPHA>(beta, alpha, s, k);
     const double nu = freq[i];
     out[i] = fnu_sample<OPTHIN, NOALPHA>(k, nu, m_log(nu));
 }
