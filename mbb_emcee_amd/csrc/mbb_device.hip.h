@@ -328,9 +328,7 @@ __device__ inline int sed_prologue(double T, double beta, double alpha, double f
                                    double lL, double nunorm, double lnunorm, SedScalars &s,
                                    int *iters = nullptr)
 {
-    const double nan = __builtin_nan("");
-    s.normfac = nan; s.xmerge = nan; s.kappa = nan; s.hcokt = nan; s.hokt9 = nan;
-    s.lhokt9 = nan; s.lx0 = 0.0;
+    // (s is left untouched on the two error returns, and xmerge / kappa without alpha)
     if (!NOALPHA && alpha <= 0.0) return ROW_BAD_ALPHA;             // :219-221
     if (beta < 0.0) return ROW_BAD_BETA;                            // :222-224
     const double hokt9 = m_div(1e9 * kH / kK, T);                   // fnu.pyx:16, per GHz
@@ -340,6 +338,7 @@ __device__ inline int sed_prologue(double T, double beta, double alpha, double f
     const double lhokt9 = kLog1e9HoK - lT;
     s.lhokt9 = lhokt9;
     const double lxnorm = lhokt9 + lnunorm;                         // log(xnorm)
+    s.lx0 = 0.0;
     int status = ROW_OK;
     if (OPTHIN) {
         // fnorm expm1(xnorm) / xnorm^(3+beta)                       :240-241, :268-269

@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         const bool lead = (tid & 15) == 0;                    // the lane that writes to LDS
         WalkerK k;
         k.status = ROW_SKIP;
+        k.pad = 0;
         double pen_u = 0.0, pen_g = 0.0;
         if (w < a.n) {
             double p[5], lT, lL = 0.0;
@@ -257,12 +258,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 k.status = ROW_NONFINITE;
             } else {
                 SedScalars s;
-                k.pad = 0;
                 k.status = sed_prologue<OPTHIN, NOALPHA, true>(p[0], p[1], p[3], p[4], lT, lL,
                                                                a.nunorm, a.lnunorm, s, &k.pad);
                 STAMPD(9, s.normfac);
                 if (k.status == ROW_OK) {
                     make_walker_k<OPTHIN, NOALPHA>(p[1], p[3], s, k);
+                    if (a.has_uplim | a.has_gprior) {          // one test when there are none
                     // _uplim_prior, likelihood.py:672-717
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
@@ -293,12 +294,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         double d = peak - a.gmean[5];
                         pen_g -= 0.5 * a.givar[5] * d * d;
                     }
+                    }
                 }
             }
         }
         STAMPD(10, pen_u + pen_g);
         if (lead) {
-            wk[j] = k;
+            if (k.status == ROW_OK) wk[j] = k;
+            else { wk[j].status = k.status; wk[j].pad = k.pad; }
             pen[2 * j] = pen_u;
             pen[2 * j + 1] = pen_g;
         }
@@ -480,15 +483,15 @@ __global__ void k_prologue(const double *pars, int n, double nunorm, double lnun
     if (i >= n) return;
     const double T = pars[i * 5 + 0], beta = pars[i * 5 + 1], lambda0 = pars[i * 5 + 2],
                  alpha = pars[i * 5 + 3], fnorm = pars[i * 5 + 4];
+    const double nan = __builtin_nan("");
     SedScalars s;
+    s.normfac = s.xmerge = s.kappa = s.hcokt = s.hokt9 = s.lhokt9 = nan;
+    s.lx0 = 0.0;
     const double p5[5] = {T, beta, lambda0, alpha, fnorm};
     int st = ROW_NONFINITE;
     if (finite5(p5))
         st = sed_prologue<OPTHIN, NOALPHA, false>(T, beta, alpha, fnorm, m_log(T),
                                                   OPTHIN ? 0.0 : m_log(lambda0), nunorm, lnunorm, s);
-    else
-        s.normfac = s.xmerge = s.kappa = s.hcokt = __builtin_nan("");
-    const double nan = __builtin_nan("");
     double peak = nan;
     WalkerK k;
     k.status = st;
