@@ -359,11 +359,13 @@ def main():
             c5.sync(); t5 = time.perf_counter()
             smp5.advance_async(20); c5.sync()
             t5 = (time.perf_counter() - t5) / 20
-            flops5, flops_src = None, None
+            flops5, flops_src, valu5 = None, None, None
             try:
                 import glob
                 ff = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_valu_cfg5*.json")))[-1]
-                flops5 = json.load(open(ff))["fp64_flops_per_launch"]
+                pm5 = json.load(open(ff))
+                flops5 = pm5["fp64_flops_per_launch"]
+                valu5 = pm5.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
                 flops_src = os.path.relpath(ff, ROOT)
             except Exception:
                 pass
@@ -374,7 +376,12 @@ def main():
                     "fp64_tflops": (flops5 / (ms5 * 1e-3) / 1e12) if flops5 else None,
                     "fp64_vector_peak_tflops": FP64_VALU_PEAK_TFLOPS,
                     "fp64_frac": (flops5 / (ms5 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if flops5 else None,
-                    "flops_source": "%s (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)" % flops_src}
+                    "flops_source": "%s (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)" % flops_src,
+                    # the roof that does bind this launch: every wave64 VALU instruction holds
+                    # its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
+                    "valu_wave_instructions": valu5,
+                    "valu_issue_bound_ms": (valu5 * 4.0 / 1024.0 / 2.4e9 * 1e3) if valu5 else None,
+                    "valu_issue_frac": (valu5 * 4.0 / 1024.0 / 2.4e9 * 1e3 / ms5) if valu5 else None}
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:

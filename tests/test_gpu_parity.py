@@ -871,6 +871,42 @@ def test_random_configurations_vs_oracle(mbb, oracle, seed):
     assert np.array_equal(got, like(pars), equal_nan=True)
 
 
+@pytest.mark.parametrize("opthin,noalpha", [(False, False), (False, True), (True, False), (True, True)])
+def test_wide_parameter_ranges_vs_oracle(mbb, oracle, opthin, noalpha):
+    """The whole prior volume a fit can wander through, not just the neighbourhood of a
+    good fit: T 3-200 K, beta 0-4.5, lambda0 5-3000 um, alpha 0.1-10, fnorm 0.01-1000 mJy,
+    with a lambda_peak prior so that the second root find runs too.  Band fluxes and
+    lnL against the oracle; the merge-point solve must converge on every row."""
+    rng = np.random.RandomState(4242)
+    n = 600
+    pars = np.column_stack([np.exp(rng.uniform(np.log(3), np.log(200), n)), rng.uniform(0.0, 4.5, n),
+                            np.exp(rng.uniform(np.log(5), np.log(3000), n)),
+                            np.exp(rng.uniform(np.log(0.1), np.log(10), n)),
+                            np.exp(rng.uniform(np.log(0.01), np.log(1000), n))])
+    pars[:8, 1] = 0.0                                        # beta = 0 exactly
+    names = ["PACS_100um", "SPIRE_250um", "SPIRE_500um", "SCUBA2_850um", "GISMO_2mm"]
+    like = mbb.likelihood(opthin=opthin, noalpha=noalpha, response=True)
+    flux = np.array([30.0, 60.0, 25.0, 6.0, 0.5])
+    unc = 0.1 * flux + 0.2
+    like.set_phot(names, flux, unc)
+    like.set_gaussian_prior("lambda_peak", 120.0, 40.0)
+    has_g, gm, gs = [0] * 6, [0.0] * 6, [1.0] * 6
+    has_g[5], gm[5], gs[5] = 1, 120.0, 40.0
+    bands = [(r.wavelength, r._sedmult, r._normfac) for r in like._responses]
+    orc = oracle.OracleLikelihood(flux, unc, bands=bands, opthin=opthin, noalpha=noalpha, wavenorm=500.0,
+                                  lowlim=like.lowlims, has_uplim=[int(b) for b in like.has_uplims],
+                                  uplim=like.uplims, has_gprior=has_g, gprior_mean=gm, gprior_sigma=gs)
+    ref, rflux = orc(pars, nthreads=4, return_flux=True)
+    got = like(pars)
+    gflux = like.model_flux(pars)
+    fin = np.isfinite(ref)
+    assert fin.sum() > 0.9 * n
+    assert np.array_equal(np.isfinite(got), fin)
+    ok = fin[:, None] & (rflux > 1e-280)
+    assert np.max(np.abs(gflux[ok] / rflux[ok] - 1.0)) < 1e-11          # SURVEY 8(c): 1e-12 + the oracle's brentq
+    lnl_close(got, ref, rtol=1e-9)          # (a row whose root find failed would have raised)
+
+
 def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
     """The sharded form of the device sampler (each rank moves a contiguous block of
     the half-ensemble, in-place all-gather of the state rows) is exercised on one
