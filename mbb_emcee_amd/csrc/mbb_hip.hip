@@ -86,9 +86,9 @@ struct mbb_ctx {
     int opthin = 0, noalpha = 0;
     double wavenorm = 500.0;
     // bands
-    int nb = 0, nseg = 0, nchunk = 0, nq = 0;
+    int nb = 0, nseg = 0, nunit = 0, npart = 0, nchunk = 0, nq = 0;
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
-    int32_t *d_band_s0 = nullptr;
+    int2 *d_band_rng = nullptr;
     int4 *d_unit_tab = nullptr;
     // data
     int data_nb = 0, has_cov = 0, nsrc = 1;
@@ -169,7 +169,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
-    free_dev(c->d_unit_tab); free_dev(c->d_band_s0);
+    free_dev(c->d_unit_tab); free_dev(c->d_band_rng);
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
@@ -208,49 +208,68 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     if (!freq || !weight || !offsets || nb <= 0) return fail(MBB_ERR_ARG, "bad band tables");
     if (offsets[0] != 0) return fail(MBB_ERR_ARG, "offsets[0] must be 0");
     const int segc = (int)(c->opt_seg_chunks > 0 ? c->opt_seg_chunks : 4);
+    for (int b = 0; b < nb; ++b) {
+        if (offsets[b + 1] - offsets[b] <= 0) return fail(MBB_ERR_ARG, "empty band");
+        for (int i = offsets[b]; i < offsets[b + 1]; ++i)
+            if (!(freq[i] > 0.0) || !isfinite(freq[i])) return fail(MBB_ERR_ARG, "non-positive frequency");
+    }
     std::vector<double> nu, lnnu, wt;
-    std::vector<int32_t> seg_c0, band_s0;
+    auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i]); };
+    auto pad = [&]() { nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0); };
+    // Bands with a passband: chunks of 64 samples, segments of <= segc chunks, one
+    // result slot per segment.  Single-sample bands (delta-function photometry, the
+    // reference's default: response.py:572-574, likelihood.py:817) are packed 64 to a
+    // chunk after them, lane = band, and each lane's f*w is its band's flux: one result
+    // slot per lane, no reduction.  A band's flux is the sum of its slots [s0, s1).
+    std::vector<int32_t> seg_c0;
+    std::vector<int2> band_rng(nb);
     int chunk = 0;
     for (int b = 0; b < nb; ++b) {
         const int n = offsets[b + 1] - offsets[b];
-        if (n <= 0) return fail(MBB_ERR_ARG, "empty band");
-        band_s0.push_back((int32_t)seg_c0.size());
+        if (n == 1) continue;
+        band_rng[b].x = (int)seg_c0.size();
         const int nch = (n + 63) / 64;
         for (int cc = 0; cc < nch; cc += segc) seg_c0.push_back(chunk + cc);
+        band_rng[b].y = (int)seg_c0.size();
         for (int i = 0; i < nch * 64; ++i) {
-            if (i < n) {
-                const double f = freq[offsets[b] + i];
-                if (!(f > 0.0) || !isfinite(f)) return fail(MBB_ERR_ARG, "non-positive frequency");
-                nu.push_back(f);
-                lnnu.push_back(log(f));
-                wt.push_back(weight[offsets[b] + i]);
-            } else {
-                nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0);
-            }
+            if (i < n) push(offsets[b] + i);
+            else pad();
         }
         chunk += nch;
     }
     seg_c0.push_back(chunk);
-    band_s0.push_back((int32_t)seg_c0.size() - 1);
+    const int nseg = (int)seg_c0.size() - 1;
+    int nd = 0;
+    for (int b = 0; b < nb; ++b)
+        if (offsets[b + 1] - offsets[b] == 1) {
+            band_rng[b] = make_int2(nseg + nd, nseg + nd + 1);
+            push(offsets[b]);
+            ++nd;
+        }
+    const int ndc = (nd + 63) / 64;
+    for (int i = nd; i < ndc * 64; ++i) pad();
     // Dealing order.  Waves w, w+4, w+8, ... of a workgroup share a SIMD and unit u goes
     // to wave u mod nwave, so position i of the table lands on SIMD i mod 4.  Longest
-    // segments first, each to the least loaded SIMD that still has a position free.
-    const int nseg = (int)seg_c0.size() - 1;
-    std::vector<int> by_size(nseg);
-    for (int i = 0; i < nseg; ++i) by_size[i] = i;
+    // units first, each to the least loaded SIMD that still has a position free.
+    const int nunit = nseg + ndc;
+    std::vector<int4> units(nunit);
+    for (int i = 0; i < nseg; ++i) units[i] = make_int4(i, seg_c0[i], seg_c0[i + 1], 0);
+    for (int k = 0; k < ndc; ++k) units[nseg + k] = make_int4(nseg + 64 * k, chunk + k, chunk + k + 1, 1);
+    std::vector<int> by_size(nunit);
+    for (int i = 0; i < nunit; ++i) by_size[i] = i;
     std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) {
-        return seg_c0[x + 1] - seg_c0[x] > seg_c0[y + 1] - seg_c0[y]; });
+        return units[x].z - units[x].y > units[y].z - units[y].y; });
     int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
-    std::vector<int4> unit_tab(nseg);
-    for (int k = 0; k < nseg; ++k) {
-        const int sgm = by_size[k];
+    std::vector<int4> unit_tab(nunit);
+    for (int k = 0; k < nunit; ++k) {
+        const int4 un = units[by_size[k]];
         int best = -1;
         for (int g = 0; g < 4; ++g) {
-            if (g + 4 * used[g] >= nseg) continue;               // no position left on this SIMD
+            if (g + 4 * used[g] >= nunit) continue;              // no position left on this SIMD
             if (best < 0 || load[g] < load[best]) best = g;
         }
-        unit_tab[best + 4 * used[best]] = make_int4(sgm, seg_c0[sgm], seg_c0[sgm + 1], 0);
-        load[best] += seg_c0[sgm + 1] - seg_c0[sgm];
+        unit_tab[best + 4 * used[best]] = un;
+        load[best] += un.z - un.y;
         ++used[best];
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -258,10 +277,12 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     if ((rc = upload(&c->d_lnnu, lnnu))) return rc;
     if ((rc = upload(&c->d_wt, wt))) return rc;
     if ((rc = upload(&c->d_unit_tab, unit_tab))) return rc;
-    if ((rc = upload(&c->d_band_s0, band_s0))) return rc;
+    if ((rc = upload(&c->d_band_rng, band_rng))) return rc;
     c->nb = nb;
-    c->nchunk = chunk;
-    c->nseg = (int)seg_c0.size() - 1;
+    c->nchunk = chunk + ndc;
+    c->nseg = nseg;
+    c->nunit = nunit;
+    c->npart = nseg + 64 * ndc;
     c->nq = offsets[nb];
     return MBB_OK;
 }
@@ -399,9 +420,9 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     wpb = (int)w;
     long t = 256;
     if (wpb == 1 && n <= cus) {
-        t = (long)((c->nseg + 3) / 4) * 256;           // ~ one segment per wave
+        t = (long)((c->nunit + 3) / 4) * 256;          // ~ one unit per wave
         if (t > 1024) t = 1024;
-        if (c->nseg <= 4) t = 256;
+        if (c->nunit <= 4) t = 256;
     }
     if (c->opt_threads > 0) t = c->opt_threads;
     if (t < 64) t = 64;
@@ -428,9 +449,9 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
-    a.unit_tab = c->d_unit_tab; a.band_s0 = c->d_band_s0;
+    a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
-    a.nb = c->nb; a.nseg = c->nseg; a.nchunk = c->nchunk;
+    a.nb = c->nb; a.nunit = c->nunit; a.npart = c->npart; a.nchunk = c->nchunk;
     a.nunorm = kUmToGHz / c->wavenorm;
     a.lnunorm = log(a.nunorm);
     for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
@@ -446,8 +467,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
 #endif
     const int grid = (n + wpb - 1) / wpb;
     const size_t cov_bytes = c->has_cov ? 8 * (size_t)c->nb * c->nb : 0;
-    const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->nseg + 8 * (size_t)c->nb + 16) +
-                             16 * (size_t)c->nb + 4 * ((size_t)c->nb + 4) + 64 * (size_t)wpb;
+    const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->npart + 8 * (size_t)c->nb + 16) +
+                             16 * (size_t)c->nb + 8 * ((size_t)c->nb + 2) + 64 * (size_t)wpb;
     // the inverse covariance goes to LDS when it fits beside everything else
     a.cov_in_lds = (c->has_cov && smem_base + cov_bytes <= 96 * 1024) ? 1 : 0;
     const size_t smem = smem_base + (a.cov_in_lds ? cov_bytes : 0);

@@ -32,13 +32,15 @@ struct LikeArgs {
     const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
     const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
     const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
-    const int4 *unit_tab;     // [nseg] {segment, first chunk, end chunk, 0} in dealing order
-    const int32_t *band_s0;   // [nb+1]   first segment of each band
+    const int4 *unit_tab;     // [nunit] {result slot, first chunk, end chunk, kind} in dealing order;
+                              // kind 0: a segment, reduced to one slot; 1: a chunk of 64 single-sample
+                              // bands, lane l's value goes to slot + l
+    const int2 *band_rng;     // [nb] the band's result slots [s0, s1)
     const double *flux;       // [nb]
     const double *ivar;       // [nb]
     const double *invcov;     // [nb*nb] or nullptr
     int cov_in_lds;           // C^-1 copied to LDS (it fits) or read from global
-    int nb, nseg, nchunk;
+    int nb, nunit, npart, nchunk;   // units and result slots per walker
     double nunorm;            // um_to_GHz / wavenorm, GHz
     double lnunorm;           // log(nunorm)
     double lowlim[5];
@@ -106,17 +108,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     const int W = a.wpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
-    const int nseg = a.nseg, nb = a.nb;
+    const int nun = a.nunit, npart = a.npart, nb = a.nb;
     WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);
-    double *partial = reinterpret_cast<double *>(wk + W);   // [W*nseg]
-    double *mflux = partial + (size_t)W * nseg;             // [W*nb]
+    double *partial = reinterpret_cast<double *>(wk + W);   // [W*npart]
+    double *mflux = partial + (size_t)W * npart;            // [W*nb]
     double *pen = mflux + (size_t)W * nb;                   // [W*2]
     double *s_flux = pen + 2 * (size_t)W;                   // [nb]
     double *s_ivar = s_flux + nb;                           // [nb]
     double *s_invcov = s_ivar + nb;                         // [nb*nb] when a.invcov
-    int *s_band = reinterpret_cast<int *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));  // [nb+1]
+    int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));  // [nb]
     // SAMPLER: per walker the proposal q[5], (dim-1) log z, old lnprob, log u
-    double *prop = reinterpret_cast<double *>(s_band + ((nb + 2) & ~1));     // [W*8]
+    double *prop = reinterpret_cast<double *>(s_band + nb + 1);              // [W*8]
     // STAGE: the passband tables themselves (nu, log nu, weight), [nchunk*64] each
     // (offset arithmetic on smem_raw, not on a pointer cast to an integer: the latter
     // loses the LDS address space and every table read becomes a flat load)
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
         for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
         for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
-        for (int b = t0; b <= nb; b += nt) s_band[b] = a.band_s0[b];
+        for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
         if (a.cov_in_lds)
             for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
         if (STAGE) {
@@ -172,8 +174,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
         } else if (wave >= pwaves) {
             const int u = wave;
-            if (u < W * nseg) {
-                const int4 us = a.unit_tab[u % nseg];
+            if (u < W * nun) {
+                const int4 us = a.unit_tab[u % nun];
                 double t = 0.0;
                 for (int c = us.y; c < us.z; ++c) {
                     const int i = c * 64 + lane;
@@ -185,9 +187,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     }
 
     // this wave's first quadrature unit: asked for now, it is here when phase 2 begins
-    const int nunit = W * nseg;
+    const int nunit = W * nun;
     int4 us_first = make_int4(0, 0, 0, 0);
-    if (wave < nunit) us_first = a.unit_tab[wave % nseg];
+    if (wave < nunit) us_first = a.unit_tab[wave % nun];
 
     // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
     // (the host guarantees blockDim.x >= 16 W)
@@ -315,10 +317,10 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     for (int u = wave; u < nunit; u += nwave) {
-        const int j = u / nseg;
+        const int j = u / nun;
         // the table deals the segments so that the four SIMDs (wave mod 4) of the CU
         // get equal numbers of chunks; which wave sums a segment does not change it
-        const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nseg];
+        const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nun];
         if (wk[j].status != ROW_OK) continue;                 // wave-uniform
         const WalkerK k = wk[j];
         const int s = us.x, c0 = us.y, c1 = us.z;
@@ -338,8 +340,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, T_nu(i), T_ln(i), s_tab);
             acc = fma(f, T_wt(i), acc);
         }
-        acc = wave_sum(acc);
-        if (lane == 0) partial[j * nseg + s] = acc;
+        if (us.w == 0) {
+            acc = wave_sum(acc);
+            if (lane == 0) partial[j * npart + s] = acc;
+        } else {
+            partial[j * npart + s + lane] = acc;              // 64 single-sample bands
+        }
     }
     STAMP(3);
 
@@ -373,8 +379,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         if (a.lnl) lnl_first = a.lnl + (w0 + wave);
         if (a.status) status_first = a.status + (w0 + wave);
         if (lane < nb) {
-            sb_first0 = s_band[lane];
-            sb_first1 = s_band[lane + 1];
+            const int2 rng = s_band[lane];
+            sb_first0 = rng.x;
+            sb_first1 = rng.y;
             band_data(w0 + wave, lane, fb_first, ib_first);
         }
     }
@@ -391,12 +398,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         double acc = 0.0;
         if (st == ROW_OK) {
             double *mf = mflux + (size_t)j * nb;
-            const double *pj = partial + j * nseg;
+            const double *pj = partial + j * npart;
             auto band = [&](const int b, auto firstb_c) {      // band flux, fixed order
                 constexpr bool FB = decltype(firstb_c)::value;
                 double sum = 0.0;
-                const int sg0 = FB ? sb_first0 : s_band[b];
-                const int sg1 = FB ? sb_first1 : s_band[b + 1];
+                int sg0 = sb_first0, sg1 = sb_first1;
+                if (!FB) { const int2 rng = s_band[b]; sg0 = rng.x; sg1 = rng.y; }
                 for (int sg = sg0; sg < sg1; sg += 4) {        // four reads per wait, same order
                     const int l = sg1 - 1;
                     const double q0 = pj[sg], q1 = pj[min(sg + 1, l)], q2 = pj[min(sg + 2, l)],

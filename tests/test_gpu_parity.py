@@ -658,6 +658,33 @@ def test_many_bands_and_covariance_vs_oracle(mbb, oracle, nbands):
         np.testing.assert_allclose(like.get_sed(pars[3], wave), like.model_flux(pars[3])[0], rtol=1e-13)
 
 
+def test_mixed_delta_and_passband_bands_keep_their_order(mbb, oracle):
+    """Single-sample bands are packed 64 to a chunk behind the passband chunks; the
+    band fluxes must come back in the caller's band order whatever the mixture."""
+    names = ["SPIRE_250um", "Y_delta_1300um", "PACS_100um", "Y_delta_2000um", "Y_delta_70um", "SCUBA2_850um"]
+    like = mbb.likelihood(response=True)
+    like.set_phot(names, np.ones(6), np.ones(6))
+    truth = np.array([22.0, 1.6, 180.0, 2.8, 50.0])
+    flux = like.model_flux(truth)[0]
+    unc = 0.1 * flux + 0.1
+    like.set_phot(names, flux, unc)
+    bands = [(r.wavelength, np.ones(1), 1.0) if r.isdelta else (r.wavelength, r._sedmult, r._normfac)
+             for r in like._responses]
+    assert [r.isdelta for r in like._responses] == [False, True, False, True, True, False]
+    rng = np.random.RandomState(12)
+    pars = truth * (1.0 + 0.08 * rng.normal(size=(130, 5)))
+    orc = oracle.OracleLikelihood(flux, unc, bands=bands, has_uplim=[int(b) for b in like.has_uplims],
+                                  uplim=like.uplims)
+    ref, rflux = orc(pars, nthreads=4, return_flux=True)
+    np.testing.assert_allclose(like.model_flux(pars), rflux, rtol=1e-12)
+    lnl_close(like(pars), ref)
+    for wpb, thr in ((1, 64), (4, 256), (16, 256)):
+        like.context.set_option("walkers_per_group", wpb); like.context.set_option("block_threads", thr)
+        assert np.array_equal(like(pars), like.__call__(pars))
+        lnl_close(like(pars), ref)
+    like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
+
+
 def test_long_passbands_and_segment_length(mbb, oracle, tmp_path):
     """Passbands far longer than the wheel's (5000 and 12000 samples; tables too
     big for LDS) and every segment length give the oracle's answer; a given
