@@ -306,13 +306,22 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
 // (modified_blackbody.py:246-254) and, with a = 3 + beta, the thin SED peak.
 // F(x) = x - a(1 - e^-x) is convex and F(a) > 0, so Newton from x = a descends
 // monotonically onto the root.
+// Three fp32 steps with the hardware exp/rcp first (a e^-x < 1 from x = a on, so the
+// slope stays positive), then fp64 steps until one is below 1e-8 x: two as a rule.
 __device__ inline double thin_fixed_point(double a)
 {
-    double x = a;
+    const float af = (float)a;
+    float xf = af;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const float e = __builtin_amdgcn_exp2f(xf * -1.44269504088896341f);
+        xf -= (xf - af * (1.0f - e)) * __builtin_amdgcn_rcpf(1.0f - af * e);
+    }
+    double x = (xf > 0.0f && xf <= af) ? (double)xf : a;
     for (int it = 0; it < 60; ++it) {
         const double e = m_exp(-x);
         const double F = x - a * (1.0 - e), dF = 1.0 - a * e;
-        const double step = -F / dF;
+        const double step = m_div(-F, dF);
         x += step;
         if (fabs(step) <= 1e-8 * fabs(x)) break;       // quadratic: next error < 1 ulp
     }
