@@ -172,7 +172,11 @@ int mbb_event_elapsed_ms(mbb_ctx *ctx, void *start, void *stop, float *ms);
 int mbb_event_destroy(mbb_ctx *ctx, void *ev);
 
 /* Tunables: "walkers_per_group" (0 = auto), "block_threads" (0 = auto),
- * "zero_copy" (host path reads/writes pinned host memory from the kernel). */
+ * "zero_copy" (host path reads/writes pinned host memory from the kernel),
+ * "spin_wait" (how mbb_lnlike_batch waits: 0 blocks on the stream, 1 polls it,
+ * 2 -- the default -- watches the result slots in pinned memory, which are final
+ * before the kernel's completion signal is), "seg_chunks", "stage_tables",
+ * "virtual_ranks", "debug". */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
 int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 

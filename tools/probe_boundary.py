@@ -10,7 +10,7 @@ def main():
     like, flux = make_likelihood(0)
     ctx = like._sync_device()
     allw = np.tile(walkers(1), (16, 1))
-    for zc, spin in ((0, 0), (0, 1), (1, 0), (1, 1)):
+    for zc, spin in ((0, 0), (1, 0), (1, 1), (1, 2)):
         ctx.set_option("zero_copy", zc); ctx.set_option("spin_wait", spin)
         for n in (125, 250, 2000):
             p = allw[:n]
