@@ -192,6 +192,45 @@ def main():
 
     use_rccl = world > 1 and collective.startswith("nccl")
 
+    # One guarded rehearsal of the exact call the timed loop makes: a collective that
+    # never returns (transport set-up, IPC) must cost the RCCL path, not the run.  All
+    # ranks then agree (over gloo) whether to keep it.
+    hung = False
+    if use_rccl:
+        import threading
+        import torch
+        state = {"ok": False}
+
+        def rehearse():
+            try:
+                for h in range(2):
+                    ctx.lnlike_allgather_device(d_pars[h], half, d_lnl[h], d_status, d_all[h])
+                ctx.sync()
+                state["ok"] = True
+            except Exception as e:           # noqa
+                print("rank %d: RCCL rehearsal failed: %r" % (rank, e), file=sys.stderr)
+
+        th0 = threading.Thread(target=rehearse, daemon=True)
+        th0.start()
+        th0.join(timeout=90.0)
+        hung = th0.is_alive()
+        flag = torch.tensor([1 if state["ok"] else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            use_rccl = False
+            collective = "HOST FALLBACK: gloo all_gather of f64[125] per half-step (RCCL all-gather %s)" % (
+                "did not return" if hung else "failed on some rank")
+            if hung:
+                # this context's stream is stuck behind the collective: take a fresh one
+                like, flux = make_likelihood(local_rank % ndev)
+                ctx = like._sync_device()
+                d_pars = []
+                for p in props:
+                    b = ctx.alloc(p.nbytes); b.upload(p); d_pars.append(b)
+                d_lnl = [ctx.alloc(half * 8) for _ in range(2)]
+                d_status = ctx.alloc(half * 4)
+                d_all = [ctx.alloc(world * half * 8) for _ in range(2)]
+
     def step(i):
         for h in range(2):
             if use_rccl:      # fused kernel + ncclAllGather of the 125 new lnprob, one C call
@@ -416,6 +455,9 @@ def main():
         print(json.dumps(out))
     barrier()
     if world > 1:
+        if hung:                 # a stuck collective would also hang the HIP teardown
+            sys.stdout.flush()
+            os._exit(0)
         if use_rccl:
             ctx.comm_destroy()
         dist.destroy_process_group()
