@@ -87,6 +87,7 @@ struct mbb_ctx {
     double wavenorm = 500.0;
     // bands
     int nb = 0, nseg = 0, nunit = 0, npart = 0, nchunk = 0, nq = 0;
+    int simd_chunks[4] = {0, 0, 0, 0};   // chunks dealt to each SIMD position by the unit table
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
     int2 *d_band_rng = nullptr;
     int4 *d_unit_tab = nullptr;
@@ -284,6 +285,7 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     c->nseg = nseg;
     c->nunit = nunit;
     c->npart = nseg + 64 * ndc;
+    for (int g = 0; g < 4; ++g) c->simd_chunks[g] = load[g];
     c->nq = offsets[nb];
     return MBB_OK;
 }
@@ -1128,6 +1130,9 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     if (!c || !name || !value) return fail(MBB_ERR_ARG, "null argument");
     if (!strcmp(name, "nb")) *value = c->nb;
     else if (!strcmp(name, "nseg")) *value = c->nseg;
+    else if (!strcmp(name, "nunit")) *value = c->nunit;
+    else if (!strcmp(name, "simd_chunks_max")) *value = *std::max_element(c->simd_chunks, c->simd_chunks + 4);
+    else if (!strcmp(name, "simd_chunks_min")) *value = *std::min_element(c->simd_chunks, c->simd_chunks + 4);
     else if (!strcmp(name, "nchunk")) *value = c->nchunk;
     else if (!strcmp(name, "nq")) *value = c->nq;
     else if (!strcmp(name, "cu_count")) *value = c->cu_count;

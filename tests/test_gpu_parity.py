@@ -658,6 +658,20 @@ def test_many_bands_and_covariance_vs_oracle(mbb, oracle, nbands):
         np.testing.assert_allclose(like.get_sed(pars[3], wave), like.model_flux(pars[3])[0], rtol=1e-13)
 
 
+def test_unit_table_balances_the_simds(mbb, g_lnl):
+    """cfg2: 39 chunks in 12 segments; the dealing order gives the four SIMDs of a CU
+    10/10/10/9 chunks (round-robin in band order would give 11/11/9/8).  Delta-function
+    photometry: all bands in one packed chunk."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like._sync_device()
+    assert ctx.info("nchunk") == 39 and ctx.info("nseg") == 12 and ctx.info("nunit") == 12
+    assert (ctx.info("simd_chunks_max"), ctx.info("simd_chunks_min")) == (10, 9)
+    d = mbb.likelihood()
+    d.set_phot(np.linspace(100.0, 1200.0, 40), np.ones(40), np.ones(40))
+    c2 = d._sync_device()
+    assert (c2.info("nchunk"), c2.info("nseg"), c2.info("nunit")) == (1, 0, 1)
+
+
 def test_mixed_delta_and_passband_bands_keep_their_order(mbb, oracle):
     """Single-sample bands are packed 64 to a chunk behind the passband chunks; the
     band fluxes must come back in the caller's band order whatever the mixture."""
