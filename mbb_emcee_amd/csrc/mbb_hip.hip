@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -90,6 +91,7 @@ struct mbb_ctx {
     int simd_chunks[4] = {0, 0, 0, 0};   // chunks dealt to each SIMD position by the unit table
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
     int2 *d_band_rng = nullptr;
+    int32_t *d_tail_slot = nullptr;
     int4 *d_unit_tab = nullptr;
     // data
     int data_nb = 0, has_cov = 0, nsrc = 1;
@@ -117,6 +119,7 @@ struct mbb_ctx {
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
+    long opt_pack_tails = 1;  // band leftovers share chunks, one row of 16 lanes each (0: a chunk per leftover)
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
@@ -171,7 +174,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
-    free_dev(c->d_unit_tab); free_dev(c->d_band_rng);
+    free_dev(c->d_unit_tab); free_dev(c->d_band_rng); free_dev(c->d_tail_slot);
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
@@ -218,61 +221,130 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     std::vector<double> nu, lnnu, wt;
     auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i]); };
     auto pad = [&]() { nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0); };
-    // Bands with a passband: chunks of 64 samples, segments of <= segc chunks, one
-    // result slot per segment.  Single-sample bands (delta-function photometry, the
-    // reference's default: response.py:572-574, likelihood.py:817) are packed 64 to a
-    // chunk after them, lane = band, and each lane's f*w is its band's flux: one result
-    // slot per lane, no reduction.  A band's flux is the sum of its slots [s0, s1).
-    std::vector<int32_t> seg_c0;
+    // A band with a passband is cut into chunks of 64 samples; segments of <= segc chunks
+    // are one unit of work and one result slot each.  What is left over at the end of a
+    // band (fewer than 49 samples) does not get a chunk of its own: the leftovers of all
+    // bands share *tail chunks*, each leftover in whole rows of 16 lanes, one result slot
+    // per row (a row total is the first stage of the wave reduction anyway).  Single-sample
+    // bands (delta-function photometry, the reference's default: response.py:572-574,
+    // likelihood.py:817) are packed 64 to a chunk, lane = band, one slot per lane, no
+    // reduction.  Slots are numbered band by band, so a band's flux is the sum of its
+    // slots [s0, s1) in that order.  Table order: full chunks, tail chunks, delta chunks.
+    const bool pack_tails = c->opt_pack_tails != 0;
+    struct Tail { int band, first, count; };
+    std::vector<int4> units;                       // {slot | tail chunk, c0, c1, kind}
+    std::vector<Tail> tails;
     std::vector<int2> band_rng(nb);
-    int chunk = 0;
+    std::vector<int> tail_slot_of_row;             // slot of each tail row, in packing order
+    int chunk = 0, slot = 0, nseg = 0;
     for (int b = 0; b < nb; ++b) {
         const int n = offsets[b + 1] - offsets[b];
         if (n == 1) continue;
-        band_rng[b].x = (int)seg_c0.size();
-        const int nch = (n + 63) / 64;
-        for (int cc = 0; cc < nch; cc += segc) seg_c0.push_back(chunk + cc);
-        band_rng[b].y = (int)seg_c0.size();
-        for (int i = 0; i < nch * 64; ++i) {
-            if (i < n) push(offsets[b] + i);
+        int full = n / 64, rem = n % 64;
+        int trows = (rem + 15) / 16;
+        if (!pack_tails || trows == 4) { full += rem ? 1 : 0; trows = 0; rem = 0; }
+        band_rng[b].x = slot;
+        for (int cc = 0; cc < full; cc += segc) {
+            units.push_back(make_int4(slot++, chunk + cc, chunk + (cc + segc < full ? cc + segc : full), 0));
+            ++nseg;
+        }
+        const int in_full = n - rem;               // samples that sit in full chunks
+        for (int i = 0; i < full * 64; ++i) {
+            if (i < in_full) push(offsets[b] + i);
             else pad();
         }
-        chunk += nch;
+        chunk += full;
+        for (int r = 0; r < trows; ++r) {
+            tails.push_back({b, offsets[b] + in_full + 16 * r, (rem - 16 * r < 16) ? rem - 16 * r : 16});
+            tail_slot_of_row.push_back(slot++);
+        }
+        band_rng[b].y = slot;
     }
-    seg_c0.push_back(chunk);
-    const int nseg = (int)seg_c0.size() - 1;
+    const int ntc = ((int)tails.size() + 3) / 4;
+    std::vector<int32_t> tail_slot(4 * (size_t)(ntc > 0 ? ntc : 1), -1);
+    for (int k = 0; k < ntc; ++k) {
+        for (int r = 0; r < 4; ++r) {
+            const size_t t = 4 * (size_t)k + r;
+            const int cnt = t < tails.size() ? tails[t].count : 0;
+            if (t < tails.size()) tail_slot[t] = tail_slot_of_row[t];
+            for (int i = 0; i < 16; ++i) {
+                if (i < cnt) push(tails[t].first + i);
+                else pad();
+            }
+        }
+        units.push_back(make_int4(k, chunk + k, chunk + k + 1, 2));
+    }
+    chunk += ntc;
     int nd = 0;
     for (int b = 0; b < nb; ++b)
         if (offsets[b + 1] - offsets[b] == 1) {
-            band_rng[b] = make_int2(nseg + nd, nseg + nd + 1);
+            band_rng[b] = make_int2(slot + nd, slot + nd + 1);
             push(offsets[b]);
             ++nd;
         }
     const int ndc = (nd + 63) / 64;
     for (int i = nd; i < ndc * 64; ++i) pad();
+    for (int k = 0; k < ndc; ++k) units.push_back(make_int4(slot + 64 * k, chunk + k, chunk + k + 1, 1));
     // Dealing order.  Waves w, w+4, w+8, ... of a workgroup share a SIMD and unit u goes
     // to wave u mod nwave, so position i of the table lands on SIMD i mod 4.  Longest
     // units first, each to the least loaded SIMD that still has a position free.
-    const int nunit = nseg + ndc;
-    std::vector<int4> units(nunit);
-    for (int i = 0; i < nseg; ++i) units[i] = make_int4(i, seg_c0[i], seg_c0[i + 1], 0);
-    for (int k = 0; k < ndc; ++k) units[nseg + k] = make_int4(nseg + 64 * k, chunk + k, chunk + k + 1, 1);
+    const int nunit = (int)units.size();
+    auto len = [&](int u) { return units[u].z - units[u].y; };
     std::vector<int> by_size(nunit);
     for (int i = 0; i < nunit; ++i) by_size[i] = i;
-    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) {
-        return units[x].z - units[x].y > units[y].z - units[y].y; });
-    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
-    std::vector<int4> unit_tab(nunit);
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return len(x) > len(y); });
+    std::vector<int> mine[4];
+    int load[4] = {0, 0, 0, 0}, cap[4];
+    for (int g = 0; g < 4; ++g) cap[g] = (nunit - g + 3) / 4;            // positions g, g+4, ...
     for (int k = 0; k < nunit; ++k) {
-        const int4 un = units[by_size[k]];
         int best = -1;
         for (int g = 0; g < 4; ++g) {
-            if (g + 4 * used[g] >= nunit) continue;              // no position left on this SIMD
+            if ((int)mine[g].size() >= cap[g]) continue;
             if (best < 0 || load[g] < load[best]) best = g;
         }
-        unit_tab[best + 4 * used[best]] = un;
-        load[best] += un.z - un.y;
-        ++used[best];
+        mine[best].push_back(by_size[k]);
+        load[best] += len(by_size[k]);
+    }
+    // The greedy deal can be a chunk off when the SIMDs have different numbers of
+    // positions.  With few units (the latency regime, where it matters) search for the
+    // deal with the smallest maximum: depth first over the units by decreasing length,
+    // bounded, pruned at the best maximum found so far.
+    if (nunit <= 24) {
+        int total = 0;
+        for (int u = 0; u < nunit; ++u) total += len(u);
+        const int floor_max = (total + 3) / 4;
+        int best_max = *std::max_element(load, load + 4);
+        std::vector<int> where(nunit, 0), best_where;
+        int cur[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+        long nodes = 0;
+        std::function<void(int)> dfs = [&](int k) {
+            if (best_max == floor_max || ++nodes > 200000) return;
+            if (k == nunit) {
+                const int m = *std::max_element(cur, cur + 4);
+                if (m < best_max) { best_max = m; best_where = where; }
+                return;
+            }
+            const int l = len(by_size[k]);
+            for (int g = 0; g < 4; ++g) {
+                if (cnt[g] >= cap[g] || cur[g] + l >= best_max) continue;
+                cur[g] += l; ++cnt[g]; where[k] = g;
+                dfs(k + 1);
+                cur[g] -= l; --cnt[g];
+            }
+        };
+        dfs(0);
+        if (!best_where.empty()) {
+            for (int g = 0; g < 4; ++g) { mine[g].clear(); load[g] = 0; }
+            for (int k = 0; k < nunit; ++k) {
+                mine[best_where[k]].push_back(by_size[k]);
+                load[best_where[k]] += len(by_size[k]);
+            }
+        }
+    }
+    std::vector<int4> unit_tab(nunit);
+    for (int g = 0; g < 4; ++g) {
+        std::stable_sort(mine[g].begin(), mine[g].end(), [&](int x, int y) { return len(x) > len(y); });
+        for (size_t i = 0; i < mine[g].size(); ++i) unit_tab[g + 4 * i] = units[mine[g][i]];
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if ((rc = upload(&c->d_nu, nu))) return rc;
@@ -280,11 +352,12 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
     if ((rc = upload(&c->d_wt, wt))) return rc;
     if ((rc = upload(&c->d_unit_tab, unit_tab))) return rc;
     if ((rc = upload(&c->d_band_rng, band_rng))) return rc;
+    if ((rc = upload(&c->d_tail_slot, tail_slot))) return rc;
     c->nb = nb;
     c->nchunk = chunk + ndc;
     c->nseg = nseg;
     c->nunit = nunit;
-    c->npart = nseg + 64 * ndc;
+    c->npart = slot + 64 * ndc;
     for (int g = 0; g < 4; ++g) c->simd_chunks[g] = load[g];
     c->nq = offsets[nb];
     return MBB_OK;
@@ -455,7 +528,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
-    a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng;
+    a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
     a.nb = c->nb; a.nunit = c->nunit; a.npart = c->npart; a.nchunk = c->nchunk;
     a.nunorm = kUmToGHz / c->wavenorm;
@@ -1120,6 +1193,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "debug")) c->opt_debug = value;
     else if (!strcmp(name, "stage_tables")) c->opt_stage = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin = value;
+    else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;

@@ -35,7 +35,10 @@ struct LikeArgs {
     const int4 *unit_tab;     // [nunit] {result slot, first chunk, end chunk, kind} in dealing order;
                               // kind 0: a segment, reduced to one slot; 1: a chunk of 64 single-sample
                               // bands, lane l's value goes to slot + l
+                              // 2: a tail chunk (slot field = its index k): row r of 16 lanes is the
+                              // leftover of some band and goes to tail_slot[4k + r] (-1: unused row)
     const int2 *band_rng;     // [nb] the band's result slots [s0, s1)
+    const int32_t *tail_slot; // [4 * tail chunks]
     const double *flux;       // [nb]
     const double *ivar;       // [nb]
     const double *invcov;     // [nb*nb] or nullptr
@@ -343,6 +346,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         if (us.w == 0) {
             acc = wave_sum(acc);
             if (lane == 0) partial[j * npart + s] = acc;
+        } else if (us.w == 2) {                               // four band leftovers, one per row
+            acc = row_sum(acc);
+            if ((lane & 15) == 0) {
+                const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                if (sl >= 0) partial[j * npart + sl] = acc;
+            }
         } else {
             partial[j * npart + s + lane] = acc;              // 64 single-sample bands
         }

@@ -659,13 +659,22 @@ def test_many_bands_and_covariance_vs_oracle(mbb, oracle, nbands):
 
 
 def test_unit_table_balances_the_simds(mbb, g_lnl):
-    """cfg2: 39 chunks in 12 segments; the dealing order gives the four SIMDs of a CU
-    10/10/10/9 chunks (round-robin in band order would give 11/11/9/8).  Delta-function
-    photometry: all bands in one packed chunk."""
+    """cfg2 (2209 samples): 34 full chunks in 11 segments plus 2 tail chunks that hold the
+    six leftover rows of five bands (a chunk per leftover would make it 39); the dealing
+    order gives each of the four SIMDs of a CU 9 chunks.  Delta-function photometry:
+    all bands in one packed chunk."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like._sync_device()
-    assert ctx.info("nchunk") == 39 and ctx.info("nseg") == 12 and ctx.info("nunit") == 12
-    assert (ctx.info("simd_chunks_max"), ctx.info("simd_chunks_min")) == (10, 9)
+    assert ctx.info("nchunk") == 36 and ctx.info("nseg") == 11 and ctx.info("nunit") == 13
+    assert (ctx.info("simd_chunks_max"), ctx.info("simd_chunks_min")) == (9, 9)
+    ref = like(g_lnl["cfg2/thick_walpha/pars"])
+    ctx.set_option("pack_tails", 0)
+    like._dirty = True
+    c0 = like._sync_device()
+    assert c0.info("nchunk") == 39 and c0.info("nunit") == 12
+    assert np.allclose(like(g_lnl["cfg2/thick_walpha/pars"]), ref, rtol=1e-13, atol=0)
+    ctx.set_option("pack_tails", 1)
+    like._dirty = True
     d = mbb.likelihood()
     d.set_phot(np.linspace(100.0, 1200.0, 40), np.ones(40), np.ones(40))
     c2 = d._sync_device()
@@ -728,7 +737,15 @@ def test_long_passbands_and_segment_length(mbb, oracle, tmp_path):
                                   has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)(pars, nthreads=8)
     base = like(pars)
     lnl_close(base, ref)
-    assert like.context.info("nchunk") == 79 + 188 + 2
+    # 5000, 12000 and (third band) samples: full chunks, their leftovers share tail chunks
+    nfull = sum(len(r._sedmult) // 64 + (1 if len(r._sedmult) % 64 > 48 else 0) for r in bands)
+    nrows = sum(-(-(len(r._sedmult) % 64) // 16) if len(r._sedmult) % 64 <= 48 else 0 for r in bands)
+    assert like.context.info("nchunk") == nfull + -(-nrows // 4)
+    like.context.set_option("pack_tails", 0)                # one chunk per leftover, as a check
+    like._dirty = True
+    assert np.allclose(like(pars), base, rtol=1e-13, atol=0) and like.context.info("nchunk") == 79 + 188 + 2
+    like.context.set_option("pack_tails", 1)
+    like._dirty = True
     for seg in (1, 2, 8, 64):
         like.context.set_option("seg_chunks", seg)
         like._dirty = True
