@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <functional>
@@ -88,6 +89,7 @@ struct mbb_ctx {
     double wavenorm = 500.0;
     // bands
     int nb = 0, nseg = 0, nunit = 0, npart = 0, nchunk = 0, nq = 0;
+    long t_prep_ns = 0, t_launch_ns = 0, t_wait_ns = 0;   // phases of the last mbb_lnlike_batch
     int simd_chunks[4] = {0, 0, 0, 0};   // chunks dealt to each SIMD position by the unit table
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
     int2 *d_band_rng = nullptr;
@@ -650,6 +652,8 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
     if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
     if ((rc = ensure_capacity(c, (size_t)n, model_flux != nullptr))) return rc;
     const size_t nbytes = (size_t)n * 5 * sizeof(double);
+    auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
+    const long t_a = now_ns();
     memcpy(c->h_pars, pars, nbytes);
     if (c->opt_zero_copy) {
         // the kernel reads the pinned parameter block and writes lnL straight
@@ -670,7 +674,9 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
             uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
             for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
         }
+        const long t_b = now_ns();
         if ((rc = launch_lnlike(c, dp, n, dl, ds, df))) return rc;
+        const long t_c = now_ns();
         bool seen = false;
         if (watch) {
             const volatile uint64_t *hl = reinterpret_cast<const volatile uint64_t *>(c->h_lnl);
@@ -683,6 +689,7 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
             }
         }
         if (!seen && (rc = wait_stream(c))) return rc;
+        c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
     } else {
         HIPCHK(hipMemcpyAsync(c->d_pars, c->h_pars, nbytes, hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_lnlike(c, c->d_pars, n, c->d_lnl, c->d_status,
@@ -1205,6 +1212,9 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     if (!strcmp(name, "nb")) *value = c->nb;
     else if (!strcmp(name, "nseg")) *value = c->nseg;
     else if (!strcmp(name, "nunit")) *value = c->nunit;
+    else if (!strcmp(name, "last_prep_ns")) *value = c->t_prep_ns;
+    else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;
+    else if (!strcmp(name, "last_wait_ns")) *value = c->t_wait_ns;
     else if (!strcmp(name, "simd_chunks_max")) *value = *std::max_element(c->simd_chunks, c->simd_chunks + 4);
     else if (!strcmp(name, "simd_chunks_min")) *value = *std::min_element(c->simd_chunks, c->simd_chunks + 4);
     else if (!strcmp(name, "nchunk")) *value = c->nchunk;

@@ -21,6 +21,9 @@ def main():
             t0 = time.perf_counter()
             for _ in range(reps): ctx.lnlike_batch(p)
             dt2 = (time.perf_counter() - t0) / reps
+            ph = np.array([[ctx.info("last_prep_ns"), ctx.info("last_launch_ns"), ctx.info("last_wait_ns")]
+                           for _ in range(200) if ctx.lnlike_batch(p) is not None])
+            print("   C-ABI phases (median ns): copy-in+sentinels %d, hipLaunchKernel %d, wait %d" % tuple(np.median(ph, axis=0)))
             print("spin=%d " % spin, end=""); print("zero_copy=%d n=%6d  likelihood.__call__ %.1f us/call %.3g evals/s | C-ABI only %.1f us/call %.3g evals/s"
                   % (zc, n, dt * 1e6, n / dt, dt2 * 1e6, n / dt2), flush=True)
 
