@@ -175,7 +175,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * "zero_copy" (host path reads/writes pinned host memory from the kernel),
  * "spin_wait" (how mbb_lnlike_batch waits: 0 blocks on the stream, 1 polls it,
  * 2 -- the default -- watches the result slots in pinned memory, which are final
- * before the kernel's completion signal is), "seg_chunks", "pack_tails" (band
+ * before the kernel's completion signal is), "bar_params" (host path writes the
+ * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug". */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);

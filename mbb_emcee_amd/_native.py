@@ -149,6 +149,9 @@ class Context(object):
         _check(self.lib.mbb_ctx_create(int(device), C.byref(h)))
         self.h = h
         self.device = int(device)
+        # the same entry point with untyped pointer arguments (see lnlike_batch)
+        self._lnlike_batch_raw = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp)(
+            ("mbb_lnlike_batch", self.lib))
 
     def close(self):
         if getattr(self, "h", None):
@@ -207,13 +210,22 @@ class Context(object):
 
     # ---- hot path ------------------------------------------------------------
     def lnlike_batch(self, pars, want_flux=False):
-        p = _f64(pars).reshape(-1, 5)
-        n = p.shape[0]
+        # this is called once per half-step by host-driven samplers: raw addresses instead
+        # of ctypes pointer objects (about 1 us apiece)
+        p = pars if (type(pars) is np.ndarray and pars.dtype == np.float64
+                     and pars.flags.c_contiguous) else _f64(pars)
+        n = p.size // 5
+        if p.size != 5 * n:
+            raise ValueError("pars is not of expected length 5")
         lnl = np.empty(n)
-        st = np.zeros(n, dtype=np.int32)
+        st = np.empty(n, dtype=np.int32)          # every entry is written by the library
         fl = np.empty((n, self.info("nb"))) if want_flux else None
-        _check(self.lib.mbb_lnlike_batch(self.h, _d(p), n, _d(lnl), _i(st),
-                                         _d(fl) if want_flux else None))
+        rc = self._lnlike_batch_raw(self.h, p.__array_interface__["data"][0], n,
+                                    lnl.__array_interface__["data"][0],
+                                    st.__array_interface__["data"][0],
+                                    fl.__array_interface__["data"][0] if want_flux else None)
+        if rc:
+            _check(rc)
         return (lnl, st, fl) if want_flux else (lnl, st)
 
     def lnlike_batch_device(self, d_pars, n, d_lnl, d_status=None, d_flux=None):
@@ -331,6 +343,8 @@ def default_context():
 def raise_for_status(status):
     """Map per-row status codes onto the reference's exceptions
     (modified_blackbody.py:219-224, :294-316)."""
+    if status.size == 0 or status.max() < 2:                    # the usual case, one pass
+        return
     bad = status[(status >= 2) & (status != ROW_NONFINITE)]     # NaN in -> NaN out, no raise
     if bad.size:
         code = int(bad[0])

@@ -110,6 +110,8 @@ struct mbb_ctx {
     double *d_pars = nullptr, *d_lnl = nullptr, *d_mflux = nullptr;
     int32_t *d_status = nullptr;
     double *h_pars = nullptr, *h_lnl = nullptr, *h_mflux = nullptr;   // pinned
+    double *w_pars = nullptr;    // device memory the host writes through the PCIe BAR (fine-grained), or null
+    int large_bar = -1;
     int32_t *h_status = nullptr;
     // scratch for SED-level calls
     size_t sed_cap = 0, sed_out_cap = 0;
@@ -121,6 +123,7 @@ struct mbb_ctx {
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
+    long opt_bar_params = 1;  // host path: write the parameter rows into device memory through the BAR
     long opt_pack_tails = 1;  // band leftovers share chunks, one row of 16 lanes each (0: a chunk per leftover)
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
@@ -180,6 +183,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
+    free_dev(c->w_pars);
     free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
     free_dev(c->d_sed_wk);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -468,6 +472,21 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         HIPCHK(hipHostMalloc((void **)&c->h_pars, cap * 5 * sizeof(double), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&c->h_lnl, cap * sizeof(double), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&c->h_status, cap * sizeof(int32_t), hipHostMallocMapped));
+        // With a large BAR the host can store into (fine-grained) device memory directly:
+        // posted writes, and the kernel then reads its parameter rows from local memory
+        // instead of pulling them across PCIe.
+        free_dev(c->w_pars);
+        c->w_pars = nullptr;
+        if (c->large_bar < 0) {
+            int lb = 0;
+            if (hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess) lb = 0;
+            c->large_bar = lb;
+        }
+        if (c->large_bar > 0 &&
+            hipExtMallocWithFlags((void **)&c->w_pars, cap * 5 * sizeof(double), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            c->w_pars = nullptr;
+        }
         c->cap = cap;
     }
     if (want_flux && n * (size_t)c->nb > c->cap_flux) {
@@ -654,13 +673,20 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
     const size_t nbytes = (size_t)n * 5 * sizeof(double);
     auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
     const long t_a = now_ns();
-    memcpy(c->h_pars, pars, nbytes);
+    const bool push = c->opt_zero_copy && c->opt_bar_params && c->w_pars;
+    if (push) {
+        memcpy(c->w_pars, pars, nbytes);           // CPU stores through the BAR ...
+        __builtin_ia32_sfence();                   // ... drained before the doorbell is rung
+    } else {
+        memcpy(c->h_pars, pars, nbytes);
+    }
     if (c->opt_zero_copy) {
         // the kernel reads the pinned parameter block and writes lnL straight
         // into pinned host memory: no copy commands on the stream at all
         double *dp, *dl, *df = nullptr;
         int32_t *ds;
-        HIPCHK(hipHostGetDevicePointer((void **)&dp, c->h_pars, 0));
+        if (push) dp = c->w_pars;
+        else HIPCHK(hipHostGetDevicePointer((void **)&dp, c->h_pars, 0));
         HIPCHK(hipHostGetDevicePointer((void **)&dl, c->h_lnl, 0));
         HIPCHK(hipHostGetDevicePointer((void **)&ds, c->h_status, 0));
         if (model_flux) HIPCHK(hipHostGetDevicePointer((void **)&df, c->h_mflux, 0));
@@ -1201,6 +1227,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "stage_tables")) c->opt_stage = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin = value;
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
+    else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;

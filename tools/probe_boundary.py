@@ -10,8 +10,8 @@ def main():
     like, flux = make_likelihood(0)
     ctx = like._sync_device()
     allw = np.tile(walkers(1), (16, 1))
-    for zc, spin in ((0, 0), (1, 0), (1, 1), (1, 2)):
-        ctx.set_option("zero_copy", zc); ctx.set_option("spin_wait", spin)
+    for zc, spin, bar in ((0, 0, 0), (1, 0, 0), (1, 2, 0), (1, 2, 1), (1, 2, 0), (1, 2, 1)):
+        ctx.set_option("zero_copy", zc); ctx.set_option("spin_wait", spin); ctx.set_option("bar_params", bar)
         for n in (125, 250, 2000):
             p = allw[:n]
             for _ in range(50): like(p)
@@ -24,7 +24,7 @@ def main():
             ph = np.array([[ctx.info("last_prep_ns"), ctx.info("last_launch_ns"), ctx.info("last_wait_ns")]
                            for _ in range(200) if ctx.lnlike_batch(p) is not None])
             print("   C-ABI phases (median ns): copy-in+sentinels %d, hipLaunchKernel %d, wait %d" % tuple(np.median(ph, axis=0)))
-            print("spin=%d " % spin, end=""); print("zero_copy=%d n=%6d  likelihood.__call__ %.1f us/call %.3g evals/s | C-ABI only %.1f us/call %.3g evals/s"
+            print("spin=%d bar=%d " % (spin, bar), end=""); print("zero_copy=%d n=%6d  likelihood.__call__ %.1f us/call %.3g evals/s | C-ABI only %.1f us/call %.3g evals/s"
                   % (zc, n, dt * 1e6, n / dt, dt2 * 1e6, n / dt2), flush=True)
 
 if __name__ == "__main__":
