@@ -124,9 +124,9 @@ class EnsembleSampler(object):
     # ---- lnprob ----------------------------------------------------------------
     def _get_lnprob(self, p):
         p = np.ascontiguousarray(p, dtype=np.float64)
-        if np.any(np.isinf(p)):
-            raise ValueError("At least one parameter value was infinite.")
-        if np.any(np.isnan(p)):
+        if not np.isfinite(p).all():                       # one pass in the usual case
+            if np.any(np.isinf(p)):
+                raise ValueError("At least one parameter value was infinite.")
             raise ValueError("At least one parameter value was NaN.")
         if self.vectorize:
             lnp = np.asarray(self.lnprobfn(p, *self.args, **self.kwargs), dtype=np.float64)
@@ -135,58 +135,71 @@ class EnsembleSampler(object):
         else:
             lnp = np.array([self.lnprobfn(row, *self.args, **self.kwargs) for row in p],
                            dtype=np.float64)
-        if np.any(np.isnan(lnp)):
+        if np.isnan(lnp).any():
             bad = p[np.isnan(lnp)]
             raise ValueError("lnprob returned NaN for parameters {}".format(bad[0]))
         return lnp
 
     # ---- sampling ----------------------------------------------------------------
-    def sample(self, p0, lnprob0=None, rstate0=None, iterations=1, storechain=True):
+    def _begin(self, p0, lnprob0, rstate0, iterations, storechain):
         if rstate0 is not None:
             self.random_state = rstate0
         p = np.array(p0, dtype=np.float64)
         if p.shape != (self.k, self.dim):
             raise ValueError("p0 must have shape (nwalkers, dim)")
-        halfk = self.k // 2
         lnprob = lnprob0 if lnprob0 is not None else self._get_lnprob(p)
         lnprob = np.array(lnprob, dtype=np.float64)
         if np.any(np.isnan(lnprob)):
             raise ValueError("The initial lnprob was NaN.")
+        i0 = self._chain.shape[1]
         if storechain:
-            i0 = self._chain.shape[1]
             self._chain = np.concatenate(
                 (self._chain, np.zeros((self.k, iterations, self.dim))), axis=1)
             self._lnprob = np.concatenate((self._lnprob, np.zeros((self.k, iterations))), axis=1)
-        first, second = slice(halfk), slice(halfk, self.k)
-        for it in range(int(iterations)):
+        return p, lnprob, i0
+
+    def _advance(self, p, lnprob, i0, its, storechain):
+        """The stretch move proper, `its` = range of iteration numbers; p and lnprob are
+        updated in place.  One likelihood launch per half-step."""
+        halfk = self.k // 2
+        halves = ((slice(halfk), slice(halfk, self.k), 0), (slice(halfk, self.k), slice(halfk), halfk))
+        rand, randint, a, dm1 = self._random.rand, self._random.randint, self.a, self.dim - 1.0
+        for it in its:
             self.iterations += 1
-            for S0, S1 in ((first, second), (second, first)):
+            for S0, S1, off in halves:
                 s, cset = p[S0], p[S1]
                 ns, nc = s.shape[0], cset.shape[0]
-                zz = ((self.a - 1.0) * self._random.rand(ns) + 1.0) ** 2 / self.a
-                partner = cset[self._random.randint(nc, size=ns)]
+                zz = ((a - 1.0) * rand(ns) + 1.0) ** 2 / a
+                partner = cset[randint(nc, size=ns)]
                 q = partner - zz[:, None] * (partner - s)
                 newlnprob = self._get_lnprob(q)
-                lnpdiff = (self.dim - 1.0) * np.log(zz) + newlnprob - lnprob[S0]
-                accept = lnpdiff > np.log(self._random.rand(ns))
-                idx = np.arange(self.k)[S0][accept]
-                p[idx] = q[accept]
-                lnprob[idx] = newlnprob[accept]
-                self.naccepted[idx] += 1
+                lnpdiff = dm1 * np.log(zz) + newlnprob - lnprob[S0]
+                idx = np.flatnonzero(lnpdiff > np.log(rand(ns)))
+                p[idx + off] = q[idx]
+                lnprob[idx + off] = newlnprob[idx]
+                self.naccepted[idx + off] += 1
             if storechain:
                 self._chain[:, i0 + it, :] = p
                 self._lnprob[:, i0 + it] = lnprob
+
+    def sample(self, p0, lnprob0=None, rstate0=None, iterations=1, storechain=True):
+        p, lnprob, i0 = self._begin(p0, lnprob0, rstate0, int(iterations), storechain)
+        for it in range(int(iterations)):
+            self._advance(p, lnprob, i0, (it,), storechain)
             yield p, lnprob, self.random_state
 
-    def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, **kwargs):
-        """Run N steps from pos0; returns (pos, lnprob, rstate) like emcee 2.x."""
+    def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, storechain=True):
+        """Run N steps from pos0; returns (pos, lnprob, rstate) like emcee 2.x.  (Same moves
+        as iterating sample(), without copying the generator's state out at every step.)"""
         if pos0 is None:
             if self._last_run_mcmc_result is None:
                 raise ValueError("Cannot have pos0=None if run_mcmc has never been called.")
             pos0, lnprob0, rstate0 = self._last_run_mcmc_result
-        results = None
-        for results in self.sample(pos0, lnprob0, rstate0, iterations=N, **kwargs):
-            pass
-        if results is not None:
-            self._last_run_mcmc_result = (results[0].copy(), results[1].copy(), results[2])
+        N = int(N)
+        p, lnprob, i0 = self._begin(pos0, lnprob0, rstate0, N, storechain)
+        if N <= 0:
+            return None
+        self._advance(p, lnprob, i0, range(N), storechain)
+        results = (p, lnprob, self.random_state)
+        self._last_run_mcmc_result = (p.copy(), lnprob.copy(), results[2])
         return results
