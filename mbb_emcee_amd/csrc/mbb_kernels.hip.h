@@ -88,8 +88,12 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const unsigned int hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const unsigned int hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a high and a low
+        // half: integer multiplies are quarter rate and this sits on the latency path
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+        const unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
         const unsigned int n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
         c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -380,6 +384,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double fb_first = 0.0, ib_first = 0.0, pen_u_first = 0.0, pen_g_first = 0.0;
     double *lnl_first = nullptr;
     int32_t *status_first = nullptr;
+    double q_first[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // SAMPLER: the proposal record
+    if (SAMPLER && wave < W) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q_first[i] = prop[wave * 8 + i];
+    }
     if (wave < W) {
         st_first = wk[wave].status;
         pad_first = wk[wave].pad;
@@ -464,7 +473,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 const int src = w / a.m_count;
                 const int row = src * a.nw_src + a.s_begin + (w - src * a.m_count);
                 double *srow = a.pos6 + (size_t)row * 6;
-                const double *q = prop + j * 8;
+                double q[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) q[i] = FIRST ? q_first[i] : prop[j * 8 + i];
                 if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
                 const bool accept = (q[5] + r - q[6]) > q[7];
                 if (accept) {
