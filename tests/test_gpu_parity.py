@@ -708,6 +708,52 @@ def test_mixed_delta_and_passband_bands_keep_their_order(mbb, oracle):
     like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
 
 
+def test_band_sizes_around_the_chunk_and_row_boundaries(mbb, oracle, tmp_path):
+    """Passbands of 2 ... 193 samples: nothing but tail rows (< 49 samples), a padded
+    chunk (49-63), exact multiples of 16 and 64, and one sample either side of each --
+    band fluxes and lnL against the oracle, and the same numbers from the layout with a
+    chunk per leftover."""
+    from mbb_emcee_amd import response
+    sizes = [2, 15, 16, 17, 32, 33, 47, 48, 49, 63, 64, 65, 80, 81, 127, 128, 129, 193]
+    rng = np.random.RandomState(21)
+    bands = []
+    for k, n in enumerate(sizes):
+        lo = 60.0 + 45.0 * k
+        x = np.linspace(lo, lo + 30.0, n)
+        t = 0.2 + rng.rand(n)
+        fn = tmp_path / ("sz%d.txt" % n)
+        np.savetxt(fn, np.column_stack([x, t]))
+        r = response("SZ%d" % n)
+        r.setup(str(fn), xtype="wave", xunits="microns", senstype="energy", normtype="power",
+                xnorm=lo + 15.0, normparam=-1.0)
+        bands.append(r)
+    like = mbb.likelihood(response=True)
+    for r in bands:
+        like._responsewheel._responses[r.name] = r
+    names = [r.name for r in bands]
+    like.set_phot(names, np.ones(len(sizes)), np.ones(len(sizes)))
+    truth = np.array([25.0, 1.7, 150.0, 2.5, 60.0])
+    flux = like.model_flux(truth)[0]
+    unc = 0.1 * flux + 0.05
+    like.set_phot(names, flux, unc)
+    pars = truth * (1.0 + 0.07 * rng.normal(size=(150, 5)))
+    orc = oracle.OracleLikelihood(flux, unc, bands=[(r.wavelength, r._sedmult, r._normfac) for r in bands],
+                                  has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
+    ref, rflux = orc(pars, nthreads=4, return_flux=True)
+    got, gflux = like(pars), like.model_flux(pars)
+    np.testing.assert_allclose(gflux, rflux, rtol=1e-12)
+    lnl_close(got, ref)
+    nfull = sum(n // 64 + (1 if n % 64 > 48 else 0) for n in sizes)
+    nrows = sum(-(-(n % 64) // 16) for n in sizes if n % 64 <= 48)
+    assert like.context.info("nchunk") == nfull + -(-nrows // 4)
+    like.context.set_option("pack_tails", 0)
+    like._dirty = True
+    np.testing.assert_allclose(like.model_flux(pars), gflux, rtol=2e-15)
+    assert like.context.info("nchunk") == sum(-(-n // 64) for n in sizes)
+    like.context.set_option("pack_tails", 1)
+    like._dirty = True
+
+
 def test_long_passbands_and_segment_length(mbb, oracle, tmp_path):
     """Passbands far longer than the wheel's (5000 and 12000 samples; tables too
     big for LDS) and every segment length give the oracle's answer; a given
