@@ -65,6 +65,7 @@ struct WalkerK {
     double xmerge;   // +inf when there is no Wien-side power law
     double cbb;      // normfac
     double cpl;      // normfac * kappa
+    double kap;      // kappa (the fused kernel sums unscaled samples and applies normfac per band)
     double peak;     // lambda_peak in um (only when requested)
     int status;
     int pad;
@@ -433,40 +434,45 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
     w.xmerge = NOALPHA ? __builtin_inf() : s.xmerge;
     w.cbb = s.normfac;
     w.cpl = NOALPHA ? 0.0 : s.normfac * s.kappa;
+    w.kap = NOALPHA ? 0.0 : s.kappa;
 }
 
 // One quadrature sample: f_nu at frequency nu (GHz), lnnu = log(nu).
 // fnu.pyx:9-108, the four kernels.  tab != nullptr selects the table-driven
 // exp/expm1 (the table sits in LDS; the passband loop), nullptr the polynomial
 // ones (one-off evaluations).
-template <bool OPTHIN, bool NOALPHA, bool TAB = false>
+// SCALE = false: without the factor normfac -- the fused kernel applies it once per band
+// instead of once per sample (the Wien side is then kappa x^-alpha).
+template <bool OPTHIN, bool NOALPHA, bool TAB = false, bool SCALE = true>
 __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
                                              const Exp2Entry *tab = nullptr)
 {
     const double x = w.hokt9 * nu;                                  // > 0
     const double lx = w.lhokt9 + lnnu;
+    auto scaled = [&](double v) { if constexpr (SCALE) return w.cbb * v; else return v; };
     if constexpr (TAB) {
         // range clamps only where the argument can leave [-800, 800]
         if (!NOALPHA) {
-            if (x > w.xmerge) return w.cpl * m_exp_t(-w.alpha * lx, tab);      // :48-49, :102-103
+            if (x > w.xmerge)                                       // :48-49, :102-103
+                return (SCALE ? w.cpl : w.kap) * m_exp_t(-w.alpha * lx, tab);
         }
         if (OPTHIN) {
-            return w.cbb * m_div(m_exp_t(w.bp3 * lx, tab), m_expm1_t<false, true>(x, tab));   // :24-25, :51
+            return scaled(m_div(m_exp_t(w.bp3 * lx, tab), m_expm1_t<false, true>(x, tab)));   // :24-25, :51
         } else {
             // y <= 800: expm1(-y) is -1 there anyway and -y needs no clamp of its own
             const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), 6.684), tab);  // :74, :105
-            return w.cbb * m_div(-m_expm1_t<false, false>(-y, tab) * (x * x * x),
-                                 m_expm1_t<false, true>(x, tab));               // :75-76, :106
+            return scaled(m_div(-m_expm1_t<false, false>(-y, tab) * (x * x * x),
+                                m_expm1_t<false, true>(x, tab)));               // :75-76, :106
         }
     } else {
         if (!NOALPHA) {
-            if (x > w.xmerge) return w.cpl * m_exp(-w.alpha * lx);
+            if (x > w.xmerge) return (SCALE ? w.cpl : w.kap) * m_exp(-w.alpha * lx);
         }
         if (OPTHIN) {
-            return w.cbb * m_div(m_exp(w.bp3 * lx), m_expm1(x));
+            return scaled(m_div(m_exp(w.bp3 * lx), m_expm1(x)));
         } else {
             const double y = m_exp(w.beta * (lx - w.lx0));
-            return w.cbb * m_div(-m_expm1(-y) * (x * x * x), m_expm1(x));
+            return scaled(m_div(-m_expm1(-y) * (x * x * x), m_expm1(x)));
         }
     }
 }

@@ -337,14 +337,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const int i0 = c * 64 + lane, i1 = i0 + 64;
             const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
             const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n0, l0, s_tab);
-            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, n1, l1, s_tab);
+            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n0, l0, s_tab);
+            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n1, l1, s_tab);
             acc = fma(f0, q0, acc);
             acc = fma(f1, q1, acc);
         }
         if (c < c1) {
             const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable>(k, T_nu(i), T_ln(i), s_tab);
+            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, T_nu(i), T_ln(i), s_tab);
             acc = fma(f, T_wt(i), acc);
         }
         if (us.w == 0) {
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         }
     };
     int st_first = ROW_SKIP, sb_first0 = 0, sb_first1 = 0, pad_first = 0;
-    double fb_first = 0.0, ib_first = 0.0, pen_u_first = 0.0, pen_g_first = 0.0;
+    double fb_first = 0.0, ib_first = 0.0, pen_u_first = 0.0, pen_g_first = 0.0, cbb_first = 0.0;
     double *lnl_first = nullptr;
     int32_t *status_first = nullptr;
     double q_first[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // SAMPLER: the proposal record
@@ -392,6 +392,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (wave < W) {
         st_first = wk[wave].status;
         pad_first = wk[wave].pad;
+        cbb_first = wk[wave].cbb;
         pen_u_first = pen[2 * wave];
         pen_g_first = pen[2 * wave + 1];
         if (a.lnl) lnl_first = a.lnl + (w0 + wave);
@@ -417,6 +418,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         if (st == ROW_OK) {
             double *mf = mflux + (size_t)j * nb;
             const double *pj = partial + j * npart;
+            const double cbb = FIRST ? cbb_first : wk[j].cbb;  // normfac: the samples were summed without it
             auto band = [&](const int b, auto firstb_c) {      // band flux, fixed order
                 constexpr bool FB = decltype(firstb_c)::value;
                 double sum = 0.0;
@@ -431,6 +433,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     if (sg + 2 < sg1) sum += q2;
                     if (sg + 3 < sg1) sum += q3;
                 }
+                sum *= cbb;
                 if (a.model_flux) a.model_flux[(size_t)w * nb + b] = sum;
                 double fb = fb_first, ib = ib_first;
                 if (!FB) band_data(w, b, fb, ib);
