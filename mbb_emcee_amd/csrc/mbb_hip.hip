@@ -502,10 +502,7 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
     return MBB_OK;
 }
 
-// Walkers per block and block size.  Small batches (an emcee half-step) are
-// latency bound: one walker per 1024-thread block so that every segment of a
-// walker has its own wave and the chip sees n blocks.  Large batches amortise
-// the lane-per-walker prologue over up to 64 walkers per 256-thread block.
+// Walkers per workgroup and workgroup size.
 static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
 {
     // Small batches (an emcee half-step) are latency bound: one walker per
@@ -584,7 +581,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     }
     // LDS staging of the passband tables.  Measured (profiles/r01/ab_stage.txt,
     // interleaved A/B): in the latency regime (one walker per workgroup, the copy
-    // hides under the serial prologue) it is 1.5 % faster; with many walkers per
+    // hides under the prologue) it is 1.5 % faster; with many walkers per
     // workgroup it is 4-5 % slower than reading the tables through L2, because
     // 60 KB of LDS per workgroup caps residency at two workgroups per CU.
     const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);

@@ -3,7 +3,7 @@
 // The device library's exp/expm1/pow carry special-case handling and long
 // Horner chains that the likelihood path does not need: its arguments are finite,
 // its quotients have positive finite-or-inf denominators, and it is either
-// latency bound (one lane per walker in the prologue) or VALU-issue bound (the
+// latency bound (one row of lanes per walker in the prologue) or VALU-issue bound (the
 // passband loop).  These versions use one shared range reduction, an Estrin
 // polynomial (dependency depth 5 instead of 13) and no branches.
 //
