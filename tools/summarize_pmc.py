@@ -16,9 +16,10 @@ def main(fetch_dir, write_dir, out):
     f = per_kernel(glob.glob(fetch_dir + "/*/*_counter_collection.csv")[0], "FETCH_SIZE")
     w = per_kernel(glob.glob(write_dir + "/*/*_counter_collection.csv")[0], "WRITE_SIZE")
     res = {"units": "KB per dispatch as reported by rocprofv3 (FETCH_SIZE = TCC_EA0_RDREQ x 64 B)",
-           "note": "gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; "
-                   "this kernel reads 8 B/lane, a width the guide leaves uncalibrated, so the "
-                   "figure is quoted uncorrected. Infinity-Cache hits are counted.",
+           "note": "gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x; the "
+                   "staged kernel reads its tables that way (calibration: tools/probe_traffic_calib.py), "
+                   "so add 8 XCD copies x table bytes / 2 to traffic_bytes_per_launch. "
+                   "Infinity-Cache hits are counted.",
            "kernels": {}}
     for k in f:
         if "lnlike" in k:
