@@ -919,7 +919,7 @@ def test_full_size_cfg3_and_cfg5_properties(mbb, g_lnl, oracle):
 
 
 # --------------------------------------------------------------- randomised configurations
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_configurations_vs_oracle(mbb, oracle, seed):
     """Random band subsets (wheel bands, specials, repeats, a single band), random
     model variant, random limits / priors / lambda_peak terms, diagonal or full
