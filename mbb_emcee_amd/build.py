@@ -12,7 +12,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mbb_device.hip.h"),
+SRC_HOST = os.path.join(HERE, "csrc", "mbb_host_tables.cpp")      # host-only table builders
+DEPS = [SRC, SRC_HOST, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
+        os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
+        os.path.join(HERE, "csrc", "mbb_device.hip.h"),
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),
         os.path.join(HERE, "csrc", "mbb_kernels.hip.h"),
         os.path.join(os.path.dirname(HERE), "include", "mbb_hip.h")]
@@ -38,7 +41,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB, SRC, "-ldl"]
+           "-o", LIB, SRC, SRC_HOST, "-ldl"]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

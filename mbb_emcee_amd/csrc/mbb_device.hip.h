@@ -32,6 +32,8 @@ using mbbm::m_exp_t;
 using mbbm::m_expm1_t;
 using mbbm::Exp2Entry;
 using mbbm::kExp2Tab;
+using mbbm::kExp2N;
+using mbbm::poly8_eval;
 
 // modified_blackbody.py:15-18
 constexpr double kH = 6.6260693e-34;      // J s
@@ -60,6 +62,7 @@ struct WalkerK {
     double lhokt9;   // log(hokt9)
     double beta;
     double bp3;      // beta + 3                               fnu.pyx:19
+    double bp2;      // beta + 2 (x^(beta+3)/expm1(x) = x^(beta+2) b(x), b = x/expm1(x))
     double alpha;
     double lx0;      // log(x0), thick only
     double xmerge;   // +inf when there is no Wien-side power law
@@ -429,6 +432,7 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
     w.lhokt9 = s.lhokt9;
     w.beta = beta;
     w.bp3 = beta + 3.0;
+    w.bp2 = beta + 2.0;
     w.alpha = NOALPHA ? 0.0 : alpha;
     w.lx0 = OPTHIN ? 0.0 : s.lx0;
     w.xmerge = NOALPHA ? __builtin_inf() : s.xmerge;
@@ -437,15 +441,28 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
     w.kap = NOALPHA ? 0.0 : s.kappa;
 }
 
+// The tables of the sample loop, all in LDS: 2^(j/256) for exp (mbb_math.hip.h) and the
+// piecewise polynomials of b(x) = x/expm1(x) and c(y) = (1 - e^-y)/y (mbb_host_tables.h).
+struct SampleTabs { const Exp2Entry *e; const double *b; const double *c; };
+
+constexpr double kLn40 = 3.6888794541139363;       // e^-40 < 2^-57: 1 - e^-y is 1 beyond
+
 // One quadrature sample: f_nu at frequency nu (GHz), lnnu = log(nu).
-// fnu.pyx:9-108, the four kernels.  tab != nullptr selects the table-driven
-// exp/expm1 (the table sits in LDS; the passband loop), nullptr the polynomial
-// ones (one-off evaluations).
+// fnu.pyx:9-108, the four kernels.
+// TAB = true (the passband loop of the fused kernel; `tabs` points into LDS): the Planck
+// factor x^3/expm1(x) is x^2 b(x) and the optical-depth factor 1 - e^-y is y c(y), with b
+// and c read off piecewise degree-7 polynomials -- 11 operations each instead of an
+// expm1 (19) plus, for b, a division (10) -- so a sample costs one exp (the power
+// x^(beta+2), (x/x0)^beta or x^-alpha), never a division.  For x > 64, beyond the table,
+// 1 - e^-x is 1 to the last bit and b(x) = x e^-x.
+// TAB = false (one-off evaluations): polynomial exp/expm1 and a true division, the
+// same formulas as the reference term by term; the parity tests hold the two against
+// each other on the passband grids.
 // SCALE = false: without the factor normfac -- the fused kernel applies it once per band
 // instead of once per sample (the Wien side is then kappa x^-alpha).
 template <bool OPTHIN, bool NOALPHA, bool TAB = false, bool SCALE = true>
 __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
-                                             const Exp2Entry *tab = nullptr)
+                                             const SampleTabs *tabs = nullptr)
 {
     const double x = w.hokt9 * nu;                                  // > 0
     const double lx = w.lhokt9 + lnnu;
@@ -454,15 +471,16 @@ __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double
         // range clamps only where the argument can leave [-800, 800]
         if (!NOALPHA) {
             if (x > w.xmerge)                                       // :48-49, :102-103
-                return (SCALE ? w.cpl : w.kap) * m_exp_t(-w.alpha * lx, tab);
+                return (SCALE ? w.cpl : w.kap) * m_exp_t<true, false>(-w.alpha * lx, tabs->e);
         }
+        double bx;
+        if (x <= 64.0) bx = poly8_eval(tabs->b, x);
+        else bx = x * m_exp_t<true, false>(-x, tabs->e);
         if (OPTHIN) {
-            return scaled(m_div(m_exp_t(w.bp3 * lx, tab), m_expm1_t<false, true>(x, tab)));   // :24-25, :51
+            return scaled(m_exp_t(w.bp2 * lx, tabs->e) * bx);                   // :24-25, :51
         } else {
-            // y <= 800: expm1(-y) is -1 there anyway and -y needs no clamp of its own
-            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), 6.684), tab);  // :74, :105
-            return scaled(m_div(-m_expm1_t<false, false>(-y, tab) * (x * x * x),
-                                m_expm1_t<false, true>(x, tab)));               // :75-76, :106
+            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);  // :74, :105
+            return scaled((y * poly8_eval(tabs->c, y)) * ((x * x) * bx));       // :75-76, :106
         }
     } else {
         if (!NOALPHA) {

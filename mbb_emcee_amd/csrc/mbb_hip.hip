@@ -25,6 +25,11 @@
 #include "../../include/mbb_hip.h"
 #include "mbb_device.hip.h"
 #include "mbb_kernels.hip.h"
+#include "mbb_host_tables.h"
+
+static_assert(kPolyBDoubles == mbbh::kPolyBCount * (mbbh::kPolyDeg + 1), "poly table size");
+static_assert(kPolyCDoubles == mbbh::kPolyCCount * (mbbh::kPolyDeg + 1), "poly table size");
+static_assert(sizeof(mbbh::Unit) == sizeof(int4) && sizeof(mbbh::SlotRange) == sizeof(int2), "layout");
 
 
 // ---------------------------------------------------------------------------
@@ -92,6 +97,7 @@ struct mbb_ctx {
     long t_prep_ns = 0, t_launch_ns = 0, t_wait_ns = 0;   // phases of the last mbb_lnlike_batch
     int simd_chunks[4] = {0, 0, 0, 0};   // chunks dealt to each SIMD position by the unit table
     double *d_nu = nullptr, *d_lnnu = nullptr, *d_wt = nullptr;
+    double *d_poly_b = nullptr, *d_poly_c = nullptr;     // piecewise polynomials of the sample loop
     int2 *d_band_rng = nullptr;
     int32_t *d_tail_slot = nullptr;
     int4 *d_unit_tab = nullptr;
@@ -128,6 +134,7 @@ struct mbb_ctx {
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
+    size_t lds_granted[16] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -165,6 +172,14 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->cu_count = prop.multiProcessorCount;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        std::vector<double> pb, pc;
+        mbbh::build_poly_tables(pb, pc);
+        HIPCHK(hipMalloc((void **)&c->d_poly_b, pb.size() * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->d_poly_c, pc.size() * sizeof(double)));
+        HIPCHK(hipMemcpy(c->d_poly_b, pb.data(), pb.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_poly_c, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     *out = c;
     return MBB_OK;
 }
@@ -179,6 +194,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
+    free_dev(c->d_poly_b); free_dev(c->d_poly_c);
     free_dev(c->d_unit_tab); free_dev(c->d_band_rng); free_dev(c->d_tail_slot);
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
@@ -216,156 +232,28 @@ extern "C" int mbb_set_bands(mbb_ctx *c, const double *freq, const double *weigh
 {
     int rc = use(c);
     if (rc) return rc;
-    if (!freq || !weight || !offsets || nb <= 0) return fail(MBB_ERR_ARG, "bad band tables");
-    if (offsets[0] != 0) return fail(MBB_ERR_ARG, "offsets[0] must be 0");
-    const int segc = (int)(c->opt_seg_chunks > 0 ? c->opt_seg_chunks : 4);
-    for (int b = 0; b < nb; ++b) {
-        if (offsets[b + 1] - offsets[b] <= 0) return fail(MBB_ERR_ARG, "empty band");
-        for (int i = offsets[b]; i < offsets[b + 1]; ++i)
-            if (!(freq[i] > 0.0) || !isfinite(freq[i])) return fail(MBB_ERR_ARG, "non-positive frequency");
-    }
-    std::vector<double> nu, lnnu, wt;
-    auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i]); };
-    auto pad = [&]() { nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0); };
-    // A band with a passband is cut into chunks of 64 samples; segments of <= segc chunks
-    // are one unit of work and one result slot each.  What is left over at the end of a
-    // band (fewer than 49 samples) does not get a chunk of its own: the leftovers of all
-    // bands share *tail chunks*, each leftover in whole rows of 16 lanes, one result slot
-    // per row (a row total is the first stage of the wave reduction anyway).  Single-sample
-    // bands (delta-function photometry, the reference's default: response.py:572-574,
-    // likelihood.py:817) are packed 64 to a chunk, lane = band, one slot per lane, no
-    // reduction.  Slots are numbered band by band, so a band's flux is the sum of its
-    // slots [s0, s1) in that order.  Table order: full chunks, tail chunks, delta chunks.
-    const bool pack_tails = c->opt_pack_tails != 0;
-    struct Tail { int band, first, count; };
-    std::vector<int4> units;                       // {slot | tail chunk, c0, c1, kind}
-    std::vector<Tail> tails;
-    std::vector<int2> band_rng(nb);
-    std::vector<int> tail_slot_of_row;             // slot of each tail row, in packing order
-    int chunk = 0, slot = 0, nseg = 0;
-    for (int b = 0; b < nb; ++b) {
-        const int n = offsets[b + 1] - offsets[b];
-        if (n == 1) continue;
-        int full = n / 64, rem = n % 64;
-        int trows = (rem + 15) / 16;
-        if (!pack_tails || trows == 4) { full += rem ? 1 : 0; trows = 0; rem = 0; }
-        band_rng[b].x = slot;
-        for (int cc = 0; cc < full; cc += segc) {
-            units.push_back(make_int4(slot++, chunk + cc, chunk + (cc + segc < full ? cc + segc : full), 0));
-            ++nseg;
-        }
-        const int in_full = n - rem;               // samples that sit in full chunks
-        for (int i = 0; i < full * 64; ++i) {
-            if (i < in_full) push(offsets[b] + i);
-            else pad();
-        }
-        chunk += full;
-        for (int r = 0; r < trows; ++r) {
-            tails.push_back({b, offsets[b] + in_full + 16 * r, (rem - 16 * r < 16) ? rem - 16 * r : 16});
-            tail_slot_of_row.push_back(slot++);
-        }
-        band_rng[b].y = slot;
-    }
-    const int ntc = ((int)tails.size() + 3) / 4;
-    std::vector<int32_t> tail_slot(4 * (size_t)(ntc > 0 ? ntc : 1), -1);
-    for (int k = 0; k < ntc; ++k) {
-        for (int r = 0; r < 4; ++r) {
-            const size_t t = 4 * (size_t)k + r;
-            const int cnt = t < tails.size() ? tails[t].count : 0;
-            if (t < tails.size()) tail_slot[t] = tail_slot_of_row[t];
-            for (int i = 0; i < 16; ++i) {
-                if (i < cnt) push(tails[t].first + i);
-                else pad();
-            }
-        }
-        units.push_back(make_int4(k, chunk + k, chunk + k + 1, 2));
-    }
-    chunk += ntc;
-    int nd = 0;
-    for (int b = 0; b < nb; ++b)
-        if (offsets[b + 1] - offsets[b] == 1) {
-            band_rng[b] = make_int2(slot + nd, slot + nd + 1);
-            push(offsets[b]);
-            ++nd;
-        }
-    const int ndc = (nd + 63) / 64;
-    for (int i = nd; i < ndc * 64; ++i) pad();
-    for (int k = 0; k < ndc; ++k) units.push_back(make_int4(slot + 64 * k, chunk + k, chunk + k + 1, 1));
-    // Dealing order.  Waves w, w+4, w+8, ... of a workgroup share a SIMD and unit u goes
-    // to wave u mod nwave, so position i of the table lands on SIMD i mod 4.  Longest
-    // units first, each to the least loaded SIMD that still has a position free.
-    const int nunit = (int)units.size();
-    auto len = [&](int u) { return units[u].z - units[u].y; };
-    std::vector<int> by_size(nunit);
-    for (int i = 0; i < nunit; ++i) by_size[i] = i;
-    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return len(x) > len(y); });
-    std::vector<int> mine[4];
-    int load[4] = {0, 0, 0, 0}, cap[4];
-    for (int g = 0; g < 4; ++g) cap[g] = (nunit - g + 3) / 4;            // positions g, g+4, ...
-    for (int k = 0; k < nunit; ++k) {
-        int best = -1;
-        for (int g = 0; g < 4; ++g) {
-            if ((int)mine[g].size() >= cap[g]) continue;
-            if (best < 0 || load[g] < load[best]) best = g;
-        }
-        mine[best].push_back(by_size[k]);
-        load[best] += len(by_size[k]);
-    }
-    // The greedy deal can be a chunk off when the SIMDs have different numbers of
-    // positions.  With few units (the latency regime, where it matters) search for the
-    // deal with the smallest maximum: depth first over the units by decreasing length,
-    // bounded, pruned at the best maximum found so far.
-    if (nunit <= 24) {
-        int total = 0;
-        for (int u = 0; u < nunit; ++u) total += len(u);
-        const int floor_max = (total + 3) / 4;
-        int best_max = *std::max_element(load, load + 4);
-        std::vector<int> where(nunit, 0), best_where;
-        int cur[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
-        long nodes = 0;
-        std::function<void(int)> dfs = [&](int k) {
-            if (best_max == floor_max || ++nodes > 200000) return;
-            if (k == nunit) {
-                const int m = *std::max_element(cur, cur + 4);
-                if (m < best_max) { best_max = m; best_where = where; }
-                return;
-            }
-            const int l = len(by_size[k]);
-            for (int g = 0; g < 4; ++g) {
-                if (cnt[g] >= cap[g] || cur[g] + l >= best_max) continue;
-                cur[g] += l; ++cnt[g]; where[k] = g;
-                dfs(k + 1);
-                cur[g] -= l; --cnt[g];
-            }
-        };
-        dfs(0);
-        if (!best_where.empty()) {
-            for (int g = 0; g < 4; ++g) { mine[g].clear(); load[g] = 0; }
-            for (int k = 0; k < nunit; ++k) {
-                mine[best_where[k]].push_back(by_size[k]);
-                load[best_where[k]] += len(by_size[k]);
-            }
-        }
-    }
-    std::vector<int4> unit_tab(nunit);
-    for (int g = 0; g < 4; ++g) {
-        std::stable_sort(mine[g].begin(), mine[g].end(), [&](int x, int y) { return len(x) > len(y); });
-        for (size_t i = 0; i < mine[g].size(); ++i) unit_tab[g + 4 * i] = units[mine[g][i]];
-    }
+    mbbh::BandLayout L;
+    const char *why = "bad band tables";
+    if (mbbh::build_band_layout(freq, weight, offsets, nb, (int)c->opt_seg_chunks, c->opt_pack_tails != 0, L, &why))
+        return fail(MBB_ERR_ARG, why);
+    std::vector<int4> unit_tab(L.unit_tab.size());
+    std::vector<int2> band_rng(L.band_rng.size());
+    memcpy(unit_tab.data(), L.unit_tab.data(), unit_tab.size() * sizeof(int4));
+    memcpy(band_rng.data(), L.band_rng.data(), band_rng.size() * sizeof(int2));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if ((rc = upload(&c->d_nu, nu))) return rc;
-    if ((rc = upload(&c->d_lnnu, lnnu))) return rc;
-    if ((rc = upload(&c->d_wt, wt))) return rc;
+    if ((rc = upload(&c->d_nu, L.nu))) return rc;
+    if ((rc = upload(&c->d_lnnu, L.lnnu))) return rc;
+    if ((rc = upload(&c->d_wt, L.wt))) return rc;
     if ((rc = upload(&c->d_unit_tab, unit_tab))) return rc;
     if ((rc = upload(&c->d_band_rng, band_rng))) return rc;
-    if ((rc = upload(&c->d_tail_slot, tail_slot))) return rc;
+    if ((rc = upload(&c->d_tail_slot, L.tail_slot))) return rc;
     c->nb = nb;
-    c->nchunk = chunk + ndc;
-    c->nseg = nseg;
-    c->nunit = nunit;
-    c->npart = slot + 64 * ndc;
-    for (int g = 0; g < 4; ++g) c->simd_chunks[g] = load[g];
-    c->nq = offsets[nb];
+    c->nchunk = L.nchunk;
+    c->nseg = L.nseg;
+    c->nunit = L.nunit;
+    c->npart = L.npart;
+    for (int g = 0; g < 4; ++g) c->simd_chunks[g] = L.simd_chunks[g];
+    c->nq = L.nq;
     return MBB_OK;
 }
 
@@ -502,25 +390,36 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
     return MBB_OK;
 }
 
+// LDS the kernel declares statically: the 2^(j/256) table and the piecewise polynomials
+// (mbb_kernels.hip.h); the rest of the CU's 160 KB is what a launch may ask for dynamically.
+static size_t static_lds(const mbb_ctx *c)
+{
+    return sizeof(Exp2Entry) * kExp2N + sizeof(double) * kPolyBDoubles +
+           sizeof(double) * (c->opthin ? 2 : kPolyCDoubles);
+}
+static size_t dynamic_lds_limit(const mbb_ctx *c) { return 160 * 1024 - static_lds(c) - 2048; }
+
 // Walkers per workgroup and workgroup size.
 static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
 {
     // Small batches (an emcee half-step) are latency bound: one walker per
     // workgroup with about one segment per wave, so the chip sees n workgroups.
-    // Once there are more walkers than CUs, 256-thread workgroups; beyond
-    // 8 workgroups per CU several walkers share a workgroup.
+    // The static tables (36-57 KB) allow two workgroups per CU, so beyond one walker
+    // per CU the workgroups are 512 threads wide -- 16 waves per CU -- and share their
+    // tables among up to 32 walkers (a wave then takes whole walkers, 4 each).
     const long cus = c->cu_count;
-    long w = (n + cus * 8 - 1) / (cus * 8);
-    if (w < 1) w = 1;
-    if (w > 16) w = 16;          // measured at 250 000 walkers: 16 beats 32 and 64
-    if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
-    wpb = (int)w;
-    long t = 256;
-    if (wpb == 1 && n <= cus) {
+    long w = 1, t = 256;
+    if (n <= cus) {
         t = (long)((c->nunit + 3) / 4) * 256;          // ~ one unit per wave
         if (t > 1024) t = 1024;
         if (c->nunit <= 4) t = 256;
+    } else {
+        w = (n + cus * 2 - 1) / (cus * 2);
+        if (w > 32) w = 32;
+        t = 512;
     }
+    if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
+    wpb = (int)w;
     if (c->opt_threads > 0) t = c->opt_threads;
     if (t < 64) t = 64;
     if (t > 1024) t = 1024;
@@ -546,6 +445,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
+    a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
     a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
     a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
     a.nb = c->nb; a.nunit = c->nunit; a.npart = c->npart; a.nchunk = c->nchunk;
@@ -567,9 +467,10 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->npart + 8 * (size_t)c->nb + 16) +
                              16 * (size_t)c->nb + 8 * ((size_t)c->nb + 2) + 64 * (size_t)wpb;
     // the inverse covariance goes to LDS when it fits beside everything else
-    a.cov_in_lds = (c->has_cov && smem_base + cov_bytes <= 96 * 1024) ? 1 : 0;
+    const size_t dyn_limit = dynamic_lds_limit(c);
+    a.cov_in_lds = (c->has_cov && smem_base + cov_bytes <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
     const size_t smem = smem_base + (a.cov_in_lds ? cov_bytes : 0);
-    if (smem > 160 * 1024) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
+    if (smem > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid;
     a.nsrc = c->nsrc;
     a.rows_per_src = 0;
@@ -585,9 +486,9 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     // workgroup it is 4-5 % slower than reading the tables through L2, because
     // 60 KB of LDS per workgroup caps residency at two workgroups per CU.
     const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);
-    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= 156 * 1024;
+    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= dyn_limit;
     if (c->opt_stage == 0) stage = false;
-    if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= 156 * 1024;
+    if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= dyn_limit;
     const size_t smem_total = smem + (stage ? table_bytes + 16 : 0);
     c->last_smem = (long)smem_total;
     c->last_stage = stage ? 1 : 0;
@@ -618,16 +519,13 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             k_lnlike<true, true, true, false>,    k_lnlike<true, true, true, true>};
         kern = table[vi];
     }
-    if (smem_total > 64 * 1024) {
-        // raise the kernel's dynamic-LDS ceiling once per variant and size, not per launch
-        static size_t granted[16][16] = {};       // [device][variant]
-        size_t &g = granted[c->device & 15][vi_of_kernel];
+    if (static_lds(c) + smem_total > 60 * 1024) {
+        // beyond 64 KB of LDS per workgroup (static + dynamic) the kernel's dynamic-LDS
+        // ceiling has to be raised: once per context, variant and size, not per launch
+        size_t &g = c->lds_granted[vi_of_kernel];
         if (smem_total > g) {
-            // 160 KB per CU, minus the kernel's static 2 KB table and some slack
-            const size_t ceiling = 160 * 1024 - 4096;
-            if (smem_total > ceiling) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
-            size_t want = (smem_total + 32767) & ~(size_t)32767;
-            if (want > ceiling) want = ceiling;
+            size_t want = (smem_total + 16383) & ~(size_t)16383;
+            if (want > dyn_limit) want = dyn_limit;
             HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)want));
             g = want;

@@ -1,0 +1,279 @@
+// mbb_host_tables.cpp -- see mbb_host_tables.h.  Host-only, no HIP.
+#include "mbb_host_tables.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <functional>
+
+namespace mbbh {
+
+int build_band_layout(const double *freq, const double *weight, const int32_t *offsets, int nb,
+                      int seg_chunks, bool pack_tails, BandLayout &L, const char **err)
+{
+    static const char *msgs[] = {"", "bad band tables", "offsets[0] must be 0", "empty band",
+                                 "non-positive frequency"};
+    auto bad = [&](int code) { if (err) *err = msgs[-code]; return code; };
+    if (!freq || !weight || !offsets || nb <= 0) return bad(-1);
+    if (offsets[0] != 0) return bad(-2);
+    const int segc = seg_chunks > 0 ? seg_chunks : 4;
+    for (int b = 0; b < nb; ++b) {
+        if (offsets[b + 1] - offsets[b] <= 0) return bad(-3);
+        for (int i = offsets[b]; i < offsets[b + 1]; ++i)
+            if (!(freq[i] > 0.0) || !isfinite(freq[i])) return bad(-4);
+    }
+    L = BandLayout();
+    std::vector<double> &nu = L.nu, &lnnu = L.lnnu, &wt = L.wt;
+    auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i]); };
+    auto pad = [&]() { nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0); };
+    // A band with a passband is cut into chunks of 64 samples; segments of <= segc chunks
+    // are one unit of work and one result slot each.  What is left over at the end of a
+    // band (fewer than 49 samples) does not get a chunk of its own: the leftovers of all
+    // bands share *tail chunks*, each leftover in whole rows of 16 lanes, one result slot
+    // per row (a row total is the first stage of the wave reduction anyway).  Single-sample
+    // bands (delta-function photometry, the reference's default: response.py:572-574,
+    // likelihood.py:817) are packed 64 to a chunk, lane = band, one slot per lane, no
+    // reduction.  Slots are numbered band by band, so a band's flux is the sum of its
+    // slots [s0, s1) in that order.  Table order: full chunks, tail chunks, delta chunks.
+    struct Tail { int band, first, count; };
+    std::vector<Unit> units;                       // {slot | tail chunk, c0, c1, kind}
+    std::vector<Tail> tails;
+    std::vector<SlotRange> band_rng(nb);
+    std::vector<int> tail_slot_of_row;             // slot of each tail row, in packing order
+    int chunk = 0, slot = 0, nseg = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int n = offsets[b + 1] - offsets[b];
+        if (n == 1) continue;
+        int full = n / 64, rem = n % 64;
+        int trows = (rem + 15) / 16;
+        if (!pack_tails || trows == 4) { full += rem ? 1 : 0; trows = 0; rem = 0; }
+        band_rng[b].s0 = slot;
+        for (int cc = 0; cc < full; cc += segc) {
+            units.push_back(Unit{slot++, chunk + cc, chunk + (cc + segc < full ? cc + segc : full), 0});
+            ++nseg;
+        }
+        const int in_full = n - rem;               // samples that sit in full chunks
+        for (int i = 0; i < full * 64; ++i) {
+            if (i < in_full) push(offsets[b] + i);
+            else pad();
+        }
+        chunk += full;
+        for (int r = 0; r < trows; ++r) {
+            tails.push_back({b, offsets[b] + in_full + 16 * r, (rem - 16 * r < 16) ? rem - 16 * r : 16});
+            tail_slot_of_row.push_back(slot++);
+        }
+        band_rng[b].s1 = slot;
+    }
+    const int ntc = ((int)tails.size() + 3) / 4;
+    std::vector<int32_t> tail_slot(4 * (size_t)(ntc > 0 ? ntc : 1), -1);
+    for (int k = 0; k < ntc; ++k) {
+        for (int r = 0; r < 4; ++r) {
+            const size_t t = 4 * (size_t)k + r;
+            const int cnt = t < tails.size() ? tails[t].count : 0;
+            if (t < tails.size()) tail_slot[t] = tail_slot_of_row[t];
+            for (int i = 0; i < 16; ++i) {
+                if (i < cnt) push(tails[t].first + i);
+                else pad();
+            }
+        }
+        units.push_back(Unit{k, chunk + k, chunk + k + 1, 2});
+    }
+    chunk += ntc;
+    int nd = 0;
+    for (int b = 0; b < nb; ++b)
+        if (offsets[b + 1] - offsets[b] == 1) {
+            band_rng[b] = SlotRange{slot + nd, slot + nd + 1};
+            push(offsets[b]);
+            ++nd;
+        }
+    const int ndc = (nd + 63) / 64;
+    for (int i = nd; i < ndc * 64; ++i) pad();
+    for (int k = 0; k < ndc; ++k) units.push_back(Unit{slot + 64 * k, chunk + k, chunk + k + 1, 1});
+    // Dealing order.  Waves w, w+4, w+8, ... of a workgroup share a SIMD and unit u goes
+    // to wave u mod nwave, so position i of the table lands on SIMD i mod 4.  Longest
+    // units first, each to the least loaded SIMD that still has a position free.
+    const int nunit = (int)units.size();
+    auto len = [&](int u) { return units[u].c1 - units[u].c0; };
+    std::vector<int> by_size(nunit);
+    for (int i = 0; i < nunit; ++i) by_size[i] = i;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int x, int y) { return len(x) > len(y); });
+    std::vector<int> mine[4];
+    int load[4] = {0, 0, 0, 0}, cap[4];
+    for (int g = 0; g < 4; ++g) cap[g] = (nunit - g + 3) / 4;            // positions g, g+4, ...
+    for (int k = 0; k < nunit; ++k) {
+        int best = -1;
+        for (int g = 0; g < 4; ++g) {
+            if ((int)mine[g].size() >= cap[g]) continue;
+            if (best < 0 || load[g] < load[best]) best = g;
+        }
+        mine[best].push_back(by_size[k]);
+        load[best] += len(by_size[k]);
+    }
+    // The greedy deal can be a chunk off when the SIMDs have different numbers of
+    // positions.  With few units (the latency regime, where it matters) search for the
+    // deal with the smallest maximum: depth first over the units by decreasing length,
+    // bounded, pruned at the best maximum found so far.
+    if (nunit <= 24) {
+        int total = 0;
+        for (int u = 0; u < nunit; ++u) total += len(u);
+        const int floor_max = (total + 3) / 4;
+        int best_max = *std::max_element(load, load + 4);
+        std::vector<int> where(nunit, 0), best_where;
+        int cur[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+        long nodes = 0;
+        std::function<void(int)> dfs = [&](int k) {
+            if (best_max == floor_max || ++nodes > 200000) return;
+            if (k == nunit) {
+                const int m = *std::max_element(cur, cur + 4);
+                if (m < best_max) { best_max = m; best_where = where; }
+                return;
+            }
+            const int l = len(by_size[k]);
+            for (int g = 0; g < 4; ++g) {
+                if (cnt[g] >= cap[g] || cur[g] + l >= best_max) continue;
+                cur[g] += l; ++cnt[g]; where[k] = g;
+                dfs(k + 1);
+                cur[g] -= l; --cnt[g];
+            }
+        };
+        dfs(0);
+        if (!best_where.empty()) {
+            for (int g = 0; g < 4; ++g) { mine[g].clear(); load[g] = 0; }
+            for (int k = 0; k < nunit; ++k) {
+                mine[best_where[k]].push_back(by_size[k]);
+                load[best_where[k]] += len(by_size[k]);
+            }
+        }
+    }
+    L.unit_tab.assign(nunit, Unit{0, 0, 0, 0});
+    for (int g = 0; g < 4; ++g) {
+        std::stable_sort(mine[g].begin(), mine[g].end(), [&](int x, int y) { return len(x) > len(y); });
+        for (size_t i = 0; i < mine[g].size(); ++i) L.unit_tab[g + 4 * i] = units[mine[g][i]];
+    }
+    L.band_rng = band_rng;
+    L.tail_slot = tail_slot;
+    L.nb = nb;
+    L.nchunk = chunk + ndc;
+    L.nseg = nseg;
+    L.nunit = nunit;
+    L.npart = slot + 64 * ndc;
+    for (int g = 0; g < 4; ++g) L.simd_chunks[g] = load[g];
+    L.nq = offsets[nb];
+    return 0;
+}
+
+// ---- piecewise polynomials -----------------------------------------------------
+namespace {
+
+typedef long double ld;
+
+ld b_fun(ld x)        // x / expm1(x), b(0) = 1
+{
+    if (fabsl(x) < 1e-6L) return 1.0L - x / 2 + x * x / 12;       // next term x^4/720
+    return x / expm1l(x);
+}
+
+ld c_fun(ld y)        // (1 - exp(-y)) / y, c(0) = 1
+{
+    if (fabsl(y) < 1e-6L) return 1.0L - y / 2 + y * y / 6;        // next term y^3/24
+    return -expm1l(-y) / y;
+}
+
+void fit_table(ld (*f)(ld), int count, std::vector<double> &out)
+{
+    constexpr int N = kPolyDeg + 1;
+    const ld h = 0.125L, hh = h / 2;
+    // Chebyshev nodes on [-1, 1] and the inverse of their Vandermonde matrix (Gauss-Jordan
+    // with partial pivoting in long double; 8 x 8, condition ~ 1e3)
+    ld s[N], V[N][2 * N];
+    const ld pi = acosl(-1.0L);
+    for (int k = 0; k < N; ++k) s[k] = cosl((2 * k + 1) * pi / (2 * N));
+    for (int r = 0; r < N; ++r) {
+        ld p = 1.0L;
+        for (int c = 0; c < N; ++c) { V[r][c] = p; p *= s[r]; }
+        for (int c = 0; c < N; ++c) V[r][N + c] = (r == c) ? 1.0L : 0.0L;
+    }
+    for (int col = 0; col < N; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < N; ++r)
+            if (fabsl(V[r][col]) > fabsl(V[piv][col])) piv = r;
+        if (piv != col)
+            for (int c = 0; c < 2 * N; ++c) std::swap(V[piv][c], V[col][c]);
+        const ld d = V[col][col];
+        for (int c = 0; c < 2 * N; ++c) V[col][c] /= d;
+        for (int r = 0; r < N; ++r) {
+            if (r == col) continue;
+            const ld m = V[r][col];
+            if (m != 0.0L)
+                for (int c = 0; c < 2 * N; ++c) V[r][c] -= m * V[col][c];
+        }
+    }
+    out.assign((size_t)count * N, 0.0);
+    for (int i = 0; i < count; ++i) {
+        const ld xc = (ld)i * h;
+        ld val[N];
+        for (int k = 0; k < N; ++k) val[k] = f(xc + hh * s[k]);
+        ld scale = 1.0L;
+        for (int k = 0; k < N; ++k) {                 // coefficient of (t / hh)^k, rescaled to t^k
+            ld a = 0.0L;
+            for (int j = 0; j < N; ++j) a += V[k][N + j] * val[j];
+            out[(size_t)i * N + k] = (double)(a / scale);
+            scale *= hh;
+        }
+    }
+}
+
+}  // namespace
+
+void build_poly_tables(std::vector<double> &b, std::vector<double> &c)
+{
+    fit_table(b_fun, kPolyBCount, b);
+    fit_table(c_fun, kPolyCCount, c);
+}
+
+}  // namespace mbbh
+
+// ---- C hooks for the CPU tests (the sanitizer build binds these through ctypes) --------
+extern "C" int mbbh_poly_counts(int *nb_intervals, int *nc_intervals, int *ncoef)
+{
+    *nb_intervals = mbbh::kPolyBCount;
+    *nc_intervals = mbbh::kPolyCCount;
+    *ncoef = mbbh::kPolyDeg + 1;
+    return 0;
+}
+
+extern "C" int mbbh_poly_tables(double *b, double *c)
+{
+    std::vector<double> vb, vc;
+    mbbh::build_poly_tables(vb, vc);
+    std::copy(vb.begin(), vb.end(), b);
+    std::copy(vc.begin(), vc.end(), c);
+    return 0;
+}
+
+// counts[9] = nchunk, nunit, npart, nseg, nq, simd_chunks[4]; the arrays must hold
+// cap_chunks * 64 samples, cap_units units (4 ints each), nb slot ranges (2 ints each)
+// and 4 * cap_chunks tail slots.  Returns the builder's code, or -9 if a capacity is short.
+extern "C" int mbbh_band_layout(const double *freq, const double *weight, const int32_t *offsets, int nb,
+                                int seg_chunks, int pack_tails, int32_t *counts, double *nu, double *lnnu,
+                                double *wt, int32_t *unit_tab, int32_t *band_rng, int32_t *tail_slot,
+                                int cap_chunks, int cap_units)
+{
+    mbbh::BandLayout L;
+    const char *err = nullptr;
+    const int rc = mbbh::build_band_layout(freq, weight, offsets, nb, seg_chunks, pack_tails != 0, L, &err);
+    if (rc) return rc;
+    if (L.nchunk > cap_chunks || L.nunit > cap_units || (int)L.tail_slot.size() > 4 * cap_chunks) return -9;
+    counts[0] = L.nchunk; counts[1] = L.nunit; counts[2] = L.npart; counts[3] = L.nseg; counts[4] = L.nq;
+    for (int g = 0; g < 4; ++g) counts[5 + g] = L.simd_chunks[g];
+    std::copy(L.nu.begin(), L.nu.end(), nu);
+    std::copy(L.lnnu.begin(), L.lnnu.end(), lnnu);
+    std::copy(L.wt.begin(), L.wt.end(), wt);
+    for (int u = 0; u < L.nunit; ++u) {
+        unit_tab[4 * u] = L.unit_tab[u].slot; unit_tab[4 * u + 1] = L.unit_tab[u].c0;
+        unit_tab[4 * u + 2] = L.unit_tab[u].c1; unit_tab[4 * u + 3] = L.unit_tab[u].kind;
+    }
+    for (int b = 0; b < nb; ++b) { band_rng[2 * b] = L.band_rng[b].s0; band_rng[2 * b + 1] = L.band_rng[b].s1; }
+    std::copy(L.tail_slot.begin(), L.tail_slot.end(), tail_slot);
+    return 0;
+}

@@ -23,6 +23,8 @@ constexpr bool kUseExpTable = false;
 #else
 constexpr bool kUseExpTable = true;
 #endif
+constexpr int kPolyBDoubles = (64 * 8 + 1) * 8;      // mbbh::kPolyBCount intervals x 8 coefficients
+constexpr int kPolyCDoubles = (40 * 8 + 1) * 8;      // mbbh::kPolyCCount
 
 // ---------------------------------------------------------------------------
 // kernel arguments
@@ -32,6 +34,8 @@ struct LikeArgs {
     const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
     const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
     const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
+    const double *poly_b;     // [kPolyBCount*8] piecewise polynomials of x/expm1(x) (mbb_host_tables.h)
+    const double *poly_c;     // [kPolyCCount*8] ... of (1 - e^-y)/y
     const int4 *unit_tab;     // [nunit] {result slot, first chunk, end chunk, kind} in dealing order;
                               // kind 0: a segment, reduced to one slot; 1: a chunk of 64 single-sample
                               // bands, lane l's value goes to slot + l
@@ -111,7 +115,9 @@ template <bool OPTHIN, bool NOALPHA, bool SAMPLER, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[128];                        // 2^(j/128) for the sample loop
+    __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
+    __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
+    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];   // (1 - e^-y)/y (thick only)
     const int W = a.wpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
@@ -164,7 +170,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (wave >= pwaves || pwaves == nwave) {
         const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
         const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
-        for (int i = t0; i < 128; i += nt) s_tab[i] = kExp2Tab[i];
+        for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+        {
+            const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+            double2 *lb = reinterpret_cast<double2 *>(s_pb);
+            for (int i = t0; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
+            if (!OPTHIN) {
+                const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+                double2 *lc = reinterpret_cast<double2 *>(s_pc);
+                for (int i = t0; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
+            }
+        }
         for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
         for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
         if (a.cov_in_lds)
@@ -323,13 +339,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
-    for (int u = wave; u < nunit; u += nwave) {
-        const int j = u / nun;
-        // the table deals the segments so that the four SIMDs (wave mod 4) of the CU
-        // get equal numbers of chunks; which wave sums a segment does not change it
-        const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nun];
-        if (wk[j].status != ROW_OK) continue;                 // wave-uniform
-        const WalkerK k = wk[j];
+    const SampleTabs tabs = {s_tab, s_pb, s_pc};
+    auto do_unit = [&](const WalkerK &k, const int j, const int4 us) {
         const int s = us.x, c0 = us.y, c1 = us.z;
         double acc = 0.0;
         int c = c0;
@@ -337,14 +348,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const int i0 = c * 64 + lane, i1 = i0 + 64;
             const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
             const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n0, l0, s_tab);
-            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n1, l1, s_tab);
+            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n0, l0, &tabs);
+            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n1, l1, &tabs);
             acc = fma(f0, q0, acc);
             acc = fma(f1, q1, acc);
         }
         if (c < c1) {
             const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, T_nu(i), T_ln(i), s_tab);
+            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, T_nu(i), T_ln(i), &tabs);
             acc = fma(f, T_wt(i), acc);
         }
         if (us.w == 0) {
@@ -358,6 +369,27 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             }
         } else {
             partial[j * npart + s + lane] = acc;              // 64 single-sample bands
+        }
+    };
+    if (W >= nwave) {
+        // many walkers per workgroup (big batches): a wave takes whole walkers, so the
+        // walker's constants are fetched once and there is no (walker, unit) arithmetic;
+        // every walker has the same units, so the waves stay balanced
+        for (int j = wave; j < W; j += nwave) {
+            if (wk[j].status != ROW_OK) continue;                 // wave-uniform
+            const WalkerK k = wk[j];
+            for (int uu = 0; uu < nun; ++uu) do_unit(k, j, a.unit_tab[uu]);
+        }
+    } else {
+        // few walkers (an emcee half-step: one per workgroup): the units of a walker are
+        // dealt to the waves; the table deals the segments so that the four SIMDs (wave mod
+        // 4) of the CU get equal numbers of chunks; which wave sums a segment does not change it
+        for (int u = wave; u < nunit; u += nwave) {
+            const int j = u / nun;
+            const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nun];
+            if (wk[j].status != ROW_OK) continue;                 // wave-uniform
+            const WalkerK k = wk[j];
+            do_unit(k, j, us);
         }
     }
     STAMP(3);

@@ -31,7 +31,7 @@ def main():
     d_lnl = ctx.alloc(n * 8); d_st = ctx.alloc(n * 4)
     nq = ctx.info("nq")
     best = None
-    sweep = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (4, 256), (8, 256), (16, 256), (32, 256), (64, 256), (16, 512), (32, 512), (8, 128), (16, 128)]
+    sweep = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (16, 256), (8, 512), (16, 512), (24, 512), (32, 512), (24, 384), (32, 1024), (48, 768), (48, 1024), (64, 1024)]
     if "--stage" in sys.argv:
         sweep = [(16, 256, 0), (16, 256, 1), (16, 512, 1), (32, 512, 1), (32, 1024, 1), (64, 1024, 1), (64, 512, 1), (32, 256, 1), (8, 256, 1)]
     for item in sweep:

@@ -26,8 +26,8 @@ def main():
             d_pars = ctx.alloc(p.nbytes); d_pars.upload(p)
             d_lnl = ctx.alloc(n * 8); d_st = ctx.alloc(n * 4)
             res = []
-            geos = [(0, 0)] if n > 4000 else [(0, 0), (1, 256), (1, 512), (1, 1024), (2, 256), (4, 256)]
-            if n > 4000: geos += [(16, 256), (32, 256), (64, 256), (64, 512), (64, 1024)]
+            geos = [(0, 0)] if n > 4000 else [(0, 0), (1, 256), (1, 512), (1, 1024), (2, 256), (2, 512), (4, 512), (8, 512)]
+            if n > 4000: geos += [(16, 256), (16, 512), (32, 512), (32, 1024), (64, 1024)]
             for wpb, thr in geos:
                 ctx.set_option("walkers_per_group", wpb); ctx.set_option("block_threads", thr)
                 us = timeit(ctx, d_pars, n, d_lnl, d_st, reps=200 if n < 4000 else 5)
