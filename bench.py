@@ -6,20 +6,40 @@
 Workload (BASELINE.json configs[1] / configs[2], SURVEY.md 8d "cfg2/cfg3"):
 8 passbands (PACS 70/100/160, SPIRE 250/350/500, SCUBA2 850, Bolocam 1.1mm;
 2209 quadrature samples), optically thick + alpha model, 250 walkers per GPU.
-One *step* is one emcee step of that ensemble: two half-ensemble launches of
-125 walkers each (mbb_fit.py:80-81 -> emcee's two half-steps), and with N > 1
-GPUs one RCCL all-gather of the 125 new log-probabilities after each launch.
-Inputs (proposed positions) are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0.  `value` = whole-job walker-likelihood
-evaluations per second.  torch is used only as launcher plumbing
-(torch.distributed gloo rendezvous + barrier); all device work goes through the
-C-ABI of libmbb_hip.so.
+One *step* is one MCMC step of the whole ensemble (metric M2): the
+device-resident stretch-move sampler advances 250 N walkers, two DEPENDENT launches
+per step (emcee's two half-steps, mbb_fit.py:80-81 / :533), each evaluating the
+fused likelihood of its half; with N > 1 ranks the ensemble is sharded (125 moving
+walkers per GPU per launch) and the moved state rows are exchanged after every
+launch -- an in-place ncclAllGather over RCCL, or the one-hop peer-write exchange
+(--exchange ipc).  Positions live in HBM for the whole run: there is no host round
+trip inside the timed region.  `value` = walker-likelihood evaluations per second of
+that real chain = 250 N K / t.
+
+Also on the line (rank 0, N = 1, outside the timed region):
+  boundary      SURVEY.md 8d metric M1: synchronous likelihood.__call__ on host arrays
+                (PCIe inclusive), median of >= 200 calls, for 125 and 250 rows
+  pipelined     independent launches on pre-computed proposals enqueued back to back
+                (an upper bound: no dependence between launches)
+  roofline      the binding roof of the dominant kernel: fp64 vector arithmetic
+                (flop and VALU counts from the committed rocprofv3 PMC pass of this very
+                launch), the empirical sample-arithmetic roof measured in this run, and
+                the HBM figures north_star asks for
+  cfg5          1000 sources x 250 walkers in one launch (BASELINE.json configs[4])
+  cpu_baseline  the CPU oracle timed on this box's cores
+
+Prints ONE JSON line on rank 0.  torch is used only as launcher plumbing
+(torch.distributed gloo rendezvous + barrier); all device work goes through the C-ABI
+of libmbb_hip.so.  A collective that cannot be set up or does not return is a failure:
+the line says so and the exit status is non-zero.
 """
 import argparse
+import glob
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,6 +54,11 @@ TRUTH = np.array([12.0, 1.8, 600.0, 3.0, 40.0])
 NW_PER_GPU = 250
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
+N_SIMD = 1024                  # 256 CUs x 4
+CLOCK_HZ = 2.4e9
+# tools/issue_cost.hip, profiles/r02/issue_cost_v1.txt: cycles one wave64 VALU
+# instruction holds its SIMD, four waves per SIMD
+CYC_FP64, CYC_OTHER = 4.3, 4.0
 
 
 def walkers(nranks):
@@ -98,22 +123,71 @@ def cpu_baseline(like, flux, pars):
             "single_thread_value": rate1}, ref[:250]
 
 
+def newest_profile(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)))
+    return files[-1] if files else None
+
+
 def measured_traffic(kernel_substr):
     """HBM-side bytes per launch of the dominant kernel from the newest committed
     rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of this same
     command; tools/summarize_pmc.py).  bench.py cannot run the profiler on itself."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))
-    if not files:
+    f = newest_profile("pmc_traffic*.json")
+    if not f:
         return None, None
     try:
-        d = json.load(open(files[-1]))
+        d = json.load(open(f))
         for k, v in d["kernels"].items():
             if kernel_substr in k:
-                return v["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+                return v["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
     except Exception:
         pass
     return None, None
+
+
+def measured_valu(pattern, kernel_substr):
+    """VALU / fp64 instruction counts per launch from the newest committed PMC summary
+    (tools/summarize_valu.py)."""
+    f = newest_profile(pattern)
+    if not f:
+        return None, None
+    try:
+        d = json.load(open(f))
+        ks = d.get("kernels", {d.get("kernel", ""): d})
+        for k, v in ks.items():
+            if kernel_substr in k:
+                return v, os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
+def valu_roofline(pm, pm_src, kernel_s, label):
+    """fp64-vector roofline object from PMC counts per launch and a launch duration."""
+    if not pm:
+        return None
+    c = pm["counters_per_launch"]
+    fma, add, mul = (c.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("FMA_F64", "ADD_F64", "MUL_F64"))
+    valu = c.get("SQ_INSTS_VALU", 0.0)
+    flops = 64.0 * (2.0 * fma + add + mul)
+    f64 = fma + add + mul + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+    # issue bound: every wave64 VALU instruction holds its SIMD 4.3 (fp64 pipe) or about 4
+    # cycles (everything else once it is mixed with fp64 work): tools/issue_cost.hip
+    issue_s = (f64 * CYC_FP64 + (valu - f64) * CYC_OTHER) / N_SIMD / CLOCK_HZ
+    tf = flops / kernel_s / 1e12
+    return {"bound": "fp64-valu", "kernel": label, "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+            "fp64_flops_per_launch": flops, "valu_wave_instructions_per_launch": valu,
+            "fp64_wave_instructions_per_launch": f64,
+            "fp64_share_of_valu": f64 / valu if valu else None,
+            "valu_issue_bound_us": issue_s * 1e6, "valu_issue_frac": issue_s / kernel_s,
+            "issue_cost_model": "fp64 %.1f / other %.1f cycles per wave instruction per SIMD, %d SIMDs at "
+                                "%.1f GHz (profiles/r02/issue_cost_v1.txt)" % (CYC_FP64, CYC_OTHER, N_SIMD, CLOCK_HZ / 1e9),
+            "kernel_us": kernel_s * 1e6, "counters_source": pm_src}
+
+
+def emit(obj):
+    print(json.dumps(obj), flush=True)
 
 
 def main():
@@ -122,8 +196,13 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--probe-reps", type=int, default=2000)
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 250 000-walker launch")
+    ap.add_argument("--no-extras", action="store_true", help="timed region only (profiler passes)")
+    ap.add_argument("--exchange", choices=("rccl", "ipc"), default="rccl",
+                    help="N > 1: how the moved state rows travel after each launch")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than devices (rehearsal of the N > 1 path on one GPU; "
+                         "needs --exchange ipc; the line is marked invalid for scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,130 +214,116 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    if N != world and world > 1:
+    if N != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (N, world))
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    try:
+        metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        metric = "walker-likelihood evals/sec (+ MCMC steps/sec), 250 walkers x 8 bands"
+    base = {"metric": metric, "value": None, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2/cfg3: 8-band PACS+SPIRE+SCUBA2_850+Bolocam passband integration "
+                                   "(NQ=2209), thick+alpha, one ensemble of 250 walkers per GPU advanced by "
+                                   "the device-resident stretch move, two dependent launches per step",
+                       "walkers_per_gpu": NW_PER_GPU, "walkers": NW_PER_GPU * world, "bands": 8,
+                       "nq": 2209, "launches_per_step": 2}}
+
+    def fail(code, **kw):
+        """A failed run still prints its line (rank 0) and leaves with a non-zero status."""
+        if rank == 0:
+            out = dict(base)
+            out.update(kw)
+            emit(out)
+        sys.stdout.flush()
+        os._exit(code)          # a wedged stream would also hang interpreter teardown
+
     from mbb_emcee_amd import _native
     ndev = max(1, _native.load().mbb_device_count())
+    if world > ndev and not (args.oversubscribe and args.exchange == "ipc"):
+        fail(2, error="%d ranks on %d device(s): RCCL needs one device per rank" % (world, ndev),
+             collective="unavailable: %d ranks on %d device(s)" % (world, ndev), valid_for_scaling=False)
     like, flux = make_likelihood(local_rank % ndev)     # one GPU per rank on a real node
     ctx = like._sync_device()
     nq, nb = ctx.info("nq"), ctx.info("nb")
+    base["config"]["nq"] = nq
+    half = NW_PER_GPU // 2
 
-    # RCCL communicator through the C-ABI; the unique id travels over gloo.
-    # If RCCL cannot be brought up on every rank the gather degrades to a host
-    # all-gather over gloo (said so in config.collective) rather than no number.
+    # ---- N > 1: the exchange of the moved state rows --------------------------------
     collective = "none"
     if world > 1:
         import torch
-        ok = 1
+        ok, why = 1, ""
         try:
-            uid = [ctx.comm_unique_id() if rank == 0 else None]
-        except Exception as e:                      # librccl missing
-            uid, ok = [None], 0
-            print("rank %d: RCCL unavailable: %s" % (rank, e), file=sys.stderr)
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0] is None:
-            ok = 0
-        if ok:
-            try:
+            if args.exchange == "ipc":
+                from mbb_emcee_amd import parallel
+                parallel.ipc_exchange_setup(ctx, rank, world, dist)
+                collective = ("one-hop peer writes: each rank stores its %d moved state rows x 6 f64 into every "
+                              "peer's buffer (hipIpc mappings) and raises a per-launch flag" % half)
+            else:
+                uid = [ctx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
                 ctx.comm_init(world, rank, uid[0])
-            except Exception as e:
-                ok = 0
-                print("rank %d: ncclCommInitRank failed: %s" % (rank, e), file=sys.stderr)
+                collective = "in-place ncclAllGather of %d state rows x 6 f64 per launch (RCCL via C-ABI)" % half
+        except Exception as e:
+            ok, why = 0, repr(e)
+            print("rank %d: exchange set-up failed: %s" % (rank, why), file=sys.stderr)
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            collective = "ncclAllGather f64[125] per half-step (RCCL via C-ABI)"
-        else:
-            if ok:
-                ctx.comm_destroy()
-            collective = "HOST FALLBACK: gloo all_gather of f64[125] per half-step (RCCL init failed)"
+        if int(flag[0]) == 0:
+            fail(3, error="exchange set-up failed on some rank" + (": " + why if why else ""),
+                 collective="unavailable: %s set-up failed" % args.exchange)
+    base["config"]["collective"] = collective
+    if world > ndev:
+        base["valid_for_scaling"] = False
+        base["config"]["note"] = "%d ranks share %d device(s): a rehearsal of the exchange, not a scaling point" % (world, ndev)
 
+    import mbb_emcee_amd as mbb
     allw = walkers(world)
-    pos = allw[rank * NW_PER_GPU:(rank + 1) * NW_PER_GPU]
-    half = NW_PER_GPU // 2
-    NSETS = 8
-    props = proposals(pos, NSETS, seed=100 + rank)        # 2*NSETS arrays [125, 5]
-    d_pars = []
-    for p in props:
-        b = ctx.alloc(p.nbytes); b.upload(p); d_pars.append(b)
-    d_lnl = [ctx.alloc(half * 8) for _ in range(2)]
-    d_status = ctx.alloc(half * 4)
-    d_all = [ctx.alloc(world * half * 8) for _ in range(2)]
+    nwt = NW_PER_GPU * world
+    smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
 
-    use_rccl = world > 1 and collective.startswith("nccl")
+    # One guarded rehearsal of exactly what the timed loop does.  A collective that never
+    # returns is a failure of the run, not something to time around: say so and leave.
+    state = {"ok": False, "err": None}
 
-    # One guarded rehearsal of the exact call the timed loop makes: a collective that
-    # never returns (transport set-up, IPC) must cost the RCCL path, not the run.  All
-    # ranks then agree (over gloo) whether to keep it.
-    hung = False
-    if use_rccl:
-        import threading
+    def rehearse():
+        try:
+            smp.run_mcmc(allw[:nwt], 20, storechain=False)
+            ctx.sync()
+            state["ok"] = True
+        except Exception as e:           # noqa
+            state["err"] = repr(e)
+
+    th = threading.Thread(target=rehearse, daemon=True)
+    th.start()
+    th.join(timeout=120.0)
+    if th.is_alive():
+        fail(4, error="the exchange did not return within 120 s", collective_hung=True,
+             hang=collective)
+    if world > 1:
         import torch
-        state = {"ok": False}
-
-        def rehearse():
-            try:
-                for h in range(2):
-                    ctx.lnlike_allgather_device(d_pars[h], half, d_lnl[h], d_status, d_all[h])
-                ctx.sync()
-                state["ok"] = True
-            except Exception as e:           # noqa
-                print("rank %d: RCCL rehearsal failed: %r" % (rank, e), file=sys.stderr)
-
-        th0 = threading.Thread(target=rehearse, daemon=True)
-        th0.start()
-        th0.join(timeout=90.0)
-        hung = th0.is_alive()
         flag = torch.tensor([1 if state["ok"] else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
-            use_rccl = False
-            collective = "HOST FALLBACK: gloo all_gather of f64[125] per half-step (RCCL all-gather %s)" % (
-                "did not return" if hung else "failed on some rank")
-            if hung:
-                # this context's stream is stuck behind the collective: take a fresh one
-                like, flux = make_likelihood(local_rank % ndev)
-                ctx = like._sync_device()
-                d_pars = []
-                for p in props:
-                    b = ctx.alloc(p.nbytes); b.upload(p); d_pars.append(b)
-                d_lnl = [ctx.alloc(half * 8) for _ in range(2)]
-                d_status = ctx.alloc(half * 4)
-                d_all = [ctx.alloc(world * half * 8) for _ in range(2)]
+            fail(5, error="sampler rehearsal failed on some rank: %s" % state["err"])
+    elif not state["ok"]:
+        fail(5, error="sampler rehearsal failed: %s" % state["err"])
 
-    def step(i):
-        for h in range(2):
-            if use_rccl:      # fused kernel + ncclAllGather of the 125 new lnprob, one C call
-                ctx.lnlike_allgather_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h],
-                                            d_status, d_all[h])
-            elif world > 1:
-                import torch
-                ctx.lnlike_batch_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h], d_status)
-                loc = torch.from_numpy(d_lnl[h].download(np.float64, half))
-                full = torch.empty(world * half, dtype=torch.float64)
-                dist.all_gather_into_tensor(full, loc)
-                d_all[h].upload(full.numpy())
-            else:
-                ctx.lnlike_batch_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h], d_status)
-
-    def cuda_sync():
-        ctx.sync()
-
-    for i in range(args.warmup):
-        step(i)
-    cuda_sync(); barrier()
+    # ---- the timed region: K dependent MCMC steps --------------------------------
+    smp.advance_async(args.warmup)
+    ctx.sync(); barrier()
     e0, e1 = ctx.event(), ctx.event()
     t0 = time.perf_counter()
     ctx.record(e0)
-    for i in range(args.steps):
-        step(i)
+    smp.advance_async(args.steps)
     ctx.record(e1)
-    cuda_sync(); barrier()
+    ctx.sync(); barrier()
     elapsed = time.perf_counter() - t0
     stream_ms = ctx.elapsed_ms(e0, e1)
     if dist is not None:
@@ -266,201 +331,175 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-
-    # ---- cfg3 as a complete MCMC: one ensemble of 250*N walkers sharded over the N
-    # GPUs, device-resident sampler, in-place ncclAllGather of the moved state rows
-    # per half-step.  Every rank takes part; guarded by a timeout so that a stuck
-    # collective cannot cost the main result.
-    sharded = None
-    if use_rccl:
-        import threading
-        import mbb_emcee_amd as mbb
-        res = {}
-
-        def leg():
-            try:
-                nwt = NW_PER_GPU * world
-                smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
-                smp.run_mcmc(allw[:nwt], 20, storechain=False)
-                ks = max(100, min(args.steps, 2000))
-                ctx.sync(); dist.barrier()
-                t0s = time.perf_counter()
-                smp.advance_async(ks)
-                ctx.sync(); dist.barrier()
-                dts = time.perf_counter() - t0s
-                res.update({"walkers": nwt, "steps": ks, "steps_per_s": ks / dts,
-                            "evals_per_s": nwt * ks / dts, "us_per_step": dts / ks * 1e6,
-                            "collective": "in-place ncclAllGather of %d state rows x 6 f64 per half-step"
-                                          % (nwt // 2)})
-            except Exception as e:           # noqa
-                res["error"] = repr(e)
-
-        th = threading.Thread(target=leg, daemon=True)
-        th.start()
-        th.join(timeout=120.0)
-        sharded = dict(res) if res else {"error": "timed out after 120 s"}
-        if th.is_alive():
-            # a collective is stuck: the context is unusable from here on.  Emit the
-            # main result (already measured) and leave without touching RCCL again.
-            if rank == 0:
-                try:
-                    metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-                except Exception:
-                    metric = "walker-likelihood evals/sec"
-                k_us = stream_ms * 1e3 / (2 * args.steps)
-                alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-                print(json.dumps({
-                    "metric": metric, "value": world * NW_PER_GPU * args.steps / elapsed,
-                    "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                    "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                    "config": {"workload": "cfg2/cfg3: 8 passbands (NQ=2209), thick+alpha, 250 walkers/GPU, "
-                                           "emcee half-steps of 125", "collective": collective},
-                    "sharded_sampler": sharded,
-                    "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9,
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                 "note": "kernel + collective per launch slot (sharded-sampler leg hung)"}}),
-                    flush=True)
-            os._exit(0)
-
-    # parity spot check of what was just timed (rank-local, not in the timed region)
-    got = d_lnl[1].download(np.float64, half)
-    last = props[(2 * (args.steps - 1) + 1) % (2 * NSETS)]
+    # the chain is still a valid one: every rank holds the same finite state
+    pos_end, lnp_end, _ = smp.run_mcmc(None, 0, storechain=False)
+    assert np.all(np.isfinite(lnp_end))
 
     if rank == 0:
-        evals = world * NW_PER_GPU * args.steps
-        value = evals / elapsed
-        # ---- roofline probe: the dominant kernel (125-walker launch) enqueued
-        # back to back from C, HIP events on its stream
-        reps = args.probe_reps
-        ctx.lnlike_repeat_device(d_pars[0], half, d_lnl[0], d_status, 200)
-        ctx.sync()
-        p0, p1 = ctx.event(), ctx.event()
-        ctx.record(p0)
-        ctx.lnlike_repeat_device(d_pars[0], half, d_lnl[0], d_status, reps)
-        ctx.record(p1)
-        ctx.sync()
-        probe_us = ctx.elapsed_ms(p0, p1) * 1e3 / reps
-        # average launch duration over the timed region itself: HIP events on the
-        # launch stream around all 2*steps launches (at N=1 nothing else is on it)
-        k_us = stream_ms * 1e3 / (2 * args.steps) if world == 1 else probe_us
-        # 48 B per evaluation + per-launch tables 16*NQ + 16*NB
-        alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-        achieved = alg_bytes / (k_us * 1e-6) / 1e9
-        # exp-class ops per sample for thick+alpha on these walkers: count on the host
-        traffic, traffic_src = measured_traffic("k_lnlike<false, false, false")
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "k_lnlike<thick,alpha> n=125", "kernel_avg_us": k_us,
-                "kernel_probe_us": probe_us,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "samples_per_s_in_kernel": half * nq / (k_us * 1e-6),
-                "note": "latency-bound launch: 125 walkers x 2209 samples; the path is fp64 "
-                        "transcendental work, HBM fraction is << 1% by construction "
-                        "(SURVEY.md 8d)"}
-        # ---- the real thing: a dependent MCMC chain with the device-resident
-        # stretch-move sampler (proposal + likelihood + accept fused, 2 launches/step)
-        import mbb_emcee_amd as mbb
-        smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=7)
-        smp.run_mcmc(pos, 50, storechain=False)
-        ksteps = max(200, min(args.steps, 5000))
-        s0, s1 = ctx.event(), ctx.event()
-        ctx.sync()
-        ts = time.perf_counter()
-        ctx.record(s0)
-        smp.advance_async(ksteps)
-        ctx.record(s1)
-        ctx.sync()
-        t_wall = time.perf_counter() - ts
-        sampler = {"steps_per_s": ksteps / t_wall, "evals_per_s": NW_PER_GPU * ksteps / t_wall,
-                   "us_per_step_stream": ctx.elapsed_ms(s0, s1) * 1e3 / ksteps, "steps": ksteps,
-                   "note": "device-resident stretch move, 250 walkers, every half-step depends "
-                           "on the previous one; no host round trip inside the run"}
-        # ---- cfg5 (BASELINE.json configs[4]): 1000 independent SEDs x 250 walkers in
-        # one launch -- the regime where the kernel is VALU-bound, not latency-bound
-        cfg5 = None
-        if not args.no_cfg5:
-            from tools.bench_cfg5 import setup as cfg5_setup
-            like5, _, p5 = cfg5_setup(1000, NW_PER_GPU)
-            c5 = like5._sync_device()
-            n5 = p5.shape[0] * p5.shape[1]
-            flat5 = np.ascontiguousarray(p5.reshape(-1, 5))
-            dp5 = c5.alloc(flat5.nbytes); dp5.upload(flat5)
-            dl5, ds5 = c5.alloc(n5 * 8), c5.alloc(n5 * 4)
-            # (the first ~10 ms of sustained load run at a lower clock: warm up past that)
-            c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 20); c5.sync()
-            q0, q1 = c5.event(), c5.event()
-            c5.record(q0); c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 20); c5.record(q1); c5.sync()
-            ms5 = c5.elapsed_ms(q0, q1) / 20
-            smp5 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like5, seed=3)
-            smp5.run_mcmc(p5, 3, storechain=False)
-            c5.sync(); t5 = time.perf_counter()
-            smp5.advance_async(20); c5.sync()
-            t5 = (time.perf_counter() - t5) / 20
-            flops5, flops_src, valu5 = None, None, None
-            try:
-                import glob
-                ff = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_valu_cfg5*.json")))[-1]
-                pm5 = json.load(open(ff))
-                flops5 = pm5["fp64_flops_per_launch"]
-                valu5 = pm5.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
-                flops_src = os.path.relpath(ff, ROOT)
-            except Exception:
-                pass
-            cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
-                    "evals_per_launch": n5, "kernel_ms": ms5, "evals_per_s": n5 / ms5 * 1e3,
-                    "samples_per_s": n5 * nq / ms5 * 1e3,
-                    "sampler_ms_per_step": t5 * 1e3, "sampler_evals_per_s": n5 / t5,
-                    "fp64_tflops": (flops5 / (ms5 * 1e-3) / 1e12) if flops5 else None,
-                    "fp64_vector_peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                    "fp64_frac": (flops5 / (ms5 * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if flops5 else None,
-                    "flops_source": "%s (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 lanes)" % flops_src,
-                    # the roof that does bind this launch: every wave64 VALU instruction holds
-                    # its SIMD for 4 cycles; 1024 SIMDs at 2.4 GHz
-                    "valu_wave_instructions": valu5,
-                    "valu_issue_bound_ms": (valu5 * 4.0 / 1024.0 / 2.4e9 * 1e3) if valu5 else None,
-                    "valu_issue_frac": (valu5 * 4.0 / 1024.0 / 2.4e9 * 1e3 / ms5) if valu5 else None}
-        try:
-            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-        except Exception:
-            metric = "walker-likelihood evals/sec (+ MCMC steps/sec), 250 walkers x 8 bands"
-        out = {"metric": metric,
-               "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "cfg2: 8-band PACS+SPIRE+SCUBA2_850+Bolocam passband "
-                                      "integration (NQ=2209), thick+alpha, 250 walkers/GPU, "
-                                      "emcee half-steps of 125",
-                          "walkers_per_gpu": NW_PER_GPU, "bands": nb, "nq": nq,
-                          "launches_per_step": 2,
-                          "collective": collective},
-               "mcmc_steps_per_s": args.steps / elapsed,
-               "stream_ms_per_step": stream_ms / args.steps,
-               "device_sampler": sampler,
-               "sharded_sampler": sharded,
-               "cfg5": cfg5,
-               "roofline": roof}
-        if not args.no_cpu and world == 1:
-            cb, ref = cpu_baseline(like, flux, pos)
-            out["cpu_baseline"] = cb
-            # what the GPU computed for the last timed launch equals the oracle's value
-            refl = like.__class__.__call__(like, last)
-            assert np.array_equal(refl, got, equal_nan=True)
-            chk = like(pos)
-            err = np.abs(chk - ref) / np.maximum(1.0, np.abs(ref))
-            out["parity_max_err_vs_oracle"] = float(err.max())
-            assert err.max() < 1e-10
-        print(json.dumps(out))
+        out = dict(base)
+        out.update({"value": nwt * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
+                    "mcmc_steps_per_s": args.steps / elapsed,
+                    "stream_us_per_step": stream_ms * 1e3 / args.steps,
+                    "acceptance_fraction": float(np.mean(smp.naccepted)) / (20 + args.warmup + args.steps)})
+        k_us = stream_ms * 1e3 / (2 * args.steps)       # launch slot of the dominant kernel
+        kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
+        out["kernel_avg_us"] = k_us
+        if world == 1 and not args.no_extras:
+            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb))
+        elif world > 1:
+            alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
+            out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None,
+                               "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "note": "launch slot = kernel + exchange at N > 1; the roofline is reported at N = 1",
+                               "launch_slot_us": k_us,
+                               "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                                       "achieved_GBps": alg_bytes / (k_us * 1e-6) / 1e9, "peak_GBps": HBM_PEAK_GBS}}
+        emit(out)
     barrier()
     if world > 1:
-        if hung:                 # a stuck collective would also hang the HIP teardown
-            sys.stdout.flush()
-            os._exit(0)
-        if use_rccl:
+        if args.exchange == "rccl":
             ctx.comm_destroy()
         dist.destroy_process_group()
+
+
+def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
+    """Everything on the line besides the timed region (rank 0, one GPU)."""
+    import mbb_emcee_amd as mbb
+    out = {}
+    half = NW_PER_GPU // 2
+    pos = allw[:NW_PER_GPU]
+
+    # ---- M1, the boundary: synchronous likelihood.__call__, host arrays in and out
+    bnd = {}
+    for n in (half, NW_PER_GPU):
+        p = np.ascontiguousarray(pos[:n])
+        for _ in range(50):
+            like(p)
+        ts = []
+        for _ in range(400):
+            t0 = time.perf_counter(); like(p); ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        bnd["rows_%d" % n] = {"median_us": med * 1e6, "p90_us": float(np.percentile(ts, 90)) * 1e6,
+                              "evals_per_s": n / med, "calls": len(ts)}
+    bnd["note"] = ("SURVEY.md 8d M1: host float64[n,5] in -> host float64[n] out through likelihood.__call__ "
+                   "(what emcee calls per half-step, mbb_fit.py:80-81), PCIe inclusive, never `value`")
+    out["boundary"] = bnd
+
+    # ---- pipelined upper bound: independent launches on pre-computed proposals
+    NSETS = 8
+    props = proposals(pos, NSETS, seed=100)
+    d_pars = []
+    for p in props:
+        b = ctx.alloc(p.nbytes); b.upload(p); d_pars.append(b)
+    d_lnl = [ctx.alloc(half * 8) for _ in range(2)]
+    d_status = ctx.alloc(half * 4)
+    ksteps = max(200, min(args.steps, 2000))
+
+    def pstep(i):
+        for h in range(2):
+            ctx.lnlike_batch_device(d_pars[(2 * i + h) % (2 * NSETS)], half, d_lnl[h], d_status)
+    for i in range(100):
+        pstep(i)
+    ctx.sync()
+    p0, p1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(p0)
+    for i in range(ksteps):
+        pstep(i)
+    ctx.record(p1); ctx.sync()
+    tp = time.perf_counter() - t0
+    plain_us = ctx.elapsed_ms(p0, p1) * 1e3 / (2 * ksteps)
+    out["pipelined"] = {"evals_per_s": NW_PER_GPU * ksteps / tp, "steps": ksteps,
+                        "kernel_avg_us": plain_us,
+                        "note": "k_lnlike<thick,alpha,plain,staged> n=125 on device-resident, pre-computed "
+                                "proposals, independent launches back to back: an upper bound, not an MCMC"}
+    # what the GPU computed for the last of those launches equals a fresh evaluation
+    got = d_lnl[1].download(np.float64, half)
+    last = props[(2 * (ksteps - 1) + 1) % (2 * NSETS)]
+    assert np.array_equal(like(last), got, equal_nan=True)
+
+    # ---- the empirical roof of the sample arithmetic, measured now (SURVEY.md 8d (i))
+    sec, slots, roof_mhz = ctx.roof_probe(TRUTH, reps=40)
+    nchunk = ctx.info("nchunk")
+    slots_per_launch = half * nchunk * 64.0
+    roof_rate = slots / sec
+    kern_rate = slots_per_launch / (k_us * 1e-6)
+    arith = {"bound": "sample-arithmetic (empirical)", "unit": "quadrature samples/s (lane slots, padding included)",
+             "peak": roof_rate, "achieved": kern_rate, "frac": kern_rate / roof_rate,
+             "probe": "k_roof: 512 workgroups x 512 threads walk all %d chunks 40 times with one walker's "
+                      "constants -- the exp + two degree-7 polynomials per sample and nothing else" % nchunk,
+             "probe_seconds": sec, "probe_shader_clock_mhz": roof_mhz, "samples_per_launch": half * nq, "lane_slots_per_launch": slots_per_launch}
+
+    # ---- rooflines of the dominant kernel (the sampler's 125-walker launch)
+    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", "k_lnlike<false, false, true, true>")
+    roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
+    alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb      # SURVEY.md 8(d)
+    traffic, traffic_src = measured_traffic("k_lnlike<false, false, true, true>")
+    hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_ratio": (traffic / alg_bytes) if traffic else None, "traffic_source": traffic_src,
+           "algorithmic_bytes_per_launch": alg_bytes,
+           "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per launch.  The "
+                   "traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
+                   "kernel code reaching each of the 8 XCD L2s once per launch"}
+    if roof is None:
+        roof = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": None, "note": "no committed PMC summary found"}
+    roof["traffic"] = traffic
+    roof["kernel_avg_us"] = k_us
+    roof["sample_arithmetic"] = arith
+    roof["why_far_below"] = ("a 125-walker launch is latency: one workgroup per walker on 125 of 256 CUs; kernel "
+                             "arguments and the parameter rows, then the per-walker prologue (one dependent chain, "
+                             "about a third of the kernel), 9 chunks of samples per SIMD, the epilogue, and 1-2 us "
+                             "of dispatch; see cfg5 for the same kernel when the chip is full")
+    out["roofline"] = roof
+    out["roofline_hbm"] = hbm
+
+    # ---- cfg5 (BASELINE.json configs[4]): 1000 independent SEDs x 250 walkers in
+    # one launch -- the regime where the kernel is VALU-bound, not latency-bound
+    if not args.no_cfg5:
+        from tools.bench_cfg5 import setup as cfg5_setup
+        like5, _, p5 = cfg5_setup(1000, NW_PER_GPU)
+        c5 = like5._sync_device()
+        n5 = p5.shape[0] * p5.shape[1]
+        flat5 = np.ascontiguousarray(p5.reshape(-1, 5))
+        dp5 = c5.alloc(flat5.nbytes); dp5.upload(flat5)
+        dl5, ds5 = c5.alloc(n5 * 8), c5.alloc(n5 * 4)
+        # (the first ~10 ms of sustained load run at a lower clock: warm up past that)
+        c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 20); c5.sync()
+        q0, q1 = c5.event(), c5.event()
+        c5.record(q0); c5.lnlike_repeat_device(dp5, n5, dl5, ds5, 20); c5.record(q1); c5.sync()
+        ms5 = c5.elapsed_ms(q0, q1) / 20
+        smp5 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like5, seed=3)
+        smp5.run_mcmc(p5, 3, storechain=False)
+        c5.sync(); t5 = time.perf_counter()
+        smp5.advance_async(20); c5.sync()
+        t5 = (time.perf_counter() - t5) / 20
+        sec5, slots5, mhz5 = c5.roof_probe(TRUTH, reps=200)
+        pm5, pm5_src = measured_valu("pmc_valu_cfg5*.json", "k_lnlike<false, false, false, false>")
+        r5 = valu_roofline(pm5, pm5_src, ms5 * 1e-3, "k_lnlike<thick,alpha,plain> n=250000")
+        cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
+                "evals_per_launch": n5, "kernel_ms": ms5, "evals_per_s": n5 / ms5 * 1e3,
+                "samples_per_s": n5 * nq / ms5 * 1e3,
+                "sampler_ms_per_step": t5 * 1e3, "sampler_evals_per_s": n5 / t5,
+                "geometry": {"walkers_per_workgroup": c5.info("last_wpb"), "threads": c5.info("last_threads")},
+                "roofline": r5,
+                "sample_arithmetic": {"peak": slots5 / sec5, "achieved": n5 * nchunk * 64.0 / (ms5 * 1e-3),
+                                      "frac": n5 * nchunk * 64.0 / (ms5 * 1e-3) / (slots5 / sec5),
+                                      "unit": "quadrature samples/s (lane slots)",
+                                      "probe_shader_clock_mhz": mhz5, "probe_seconds": sec5}}
+        if pm5:
+            cfg5["valu_wave_instructions_per_walker"] = pm5["counters_per_launch"].get("SQ_INSTS_VALU", 0) / n5
+        out["cfg5"] = cfg5
+
+    if not args.no_cpu:
+        cb, ref = cpu_baseline(like, flux, pos)
+        out["cpu_baseline"] = cb
+        chk = like(pos)
+        err = np.abs(chk - ref) / np.maximum(1.0, np.abs(ref))
+        out["parity_max_err_vs_oracle"] = float(err.max())
+        assert err.max() < 1e-10
+    return out
 
 
 if __name__ == "__main__":

@@ -108,6 +108,15 @@ int mbb_lnlike_batch_device(mbb_ctx *ctx, const double *d_pars, int n,
 int mbb_lnlike_repeat_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
                              int32_t *d_status, int reps);
 
+/* Measurement helper (bench.py roofline): the sample arithmetic of
+ * fnu.pyx:9-108 alone -- every wave of a chip-filling grid walks all passband
+ * samples `reps` times with the constants of one parameter row; no prologue, no
+ * reductions.  lane_slots = samples evaluated including chunk padding; clock_mhz (may be
+ * NULL) = the shader clock the chip held meanwhile, s_memtime against the 100 MHz
+ * s_memrealtime over workgroup 0's loop.  Synchronous. */
+int mbb_roof_probe(mbb_ctx *ctx, const double pars[5], int reps, double *seconds,
+                   double *lane_slots, double *clock_mhz);
+
 /* ---- device-resident ensemble sampler ------------------------------------- */
 /* Replaces: emcee.EnsembleSampler(nwalkers, 5, like).run_mcmc(p0, nsteps) as
  * driven by mbb_fitter.run (mbb_fit.py:80-81, :533, :542): the affine-invariant

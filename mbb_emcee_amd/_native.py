@@ -33,6 +33,7 @@ SIGNATURES = {
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
     "mbb_lnlike_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "mbb_lnlike_repeat_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int]),
+    "mbb_roof_probe": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp, _dp]),
     "mbb_sampler_create": (C.c_int, [_vp, C.c_int, C.c_ulonglong, C.POINTER(_vp)]),
     "mbb_sampler_destroy": (C.c_int, [_vp, _vp]),
     "mbb_sampler_reset": (C.c_int, [_vp, _vp]),
@@ -239,6 +240,13 @@ class Context(object):
         _check(self.lib.mbb_lnlike_repeat_device(
             self.h, d_pars.ptr, int(n), d_lnl.ptr,
             d_status.ptr if d_status is not None else None, int(reps)))
+
+    def roof_probe(self, pars, reps=20):
+        """(seconds, lane_slots, clock MHz) of the sample-arithmetic-only kernel (measurement)."""
+        p = _f64(pars).reshape(5)
+        sec, slots, mhz = C.c_double(), C.c_double(), C.c_double()
+        _check(self.lib.mbb_roof_probe(self.h, _d(p), int(reps), C.byref(sec), C.byref(slots), C.byref(mhz)))
+        return sec.value, slots.value, mhz.value
 
     # ---- SED level -------------------------------------------------------------
     def sed_prologue(self, pars, opthin, noalpha, wavenorm, want_peak=False):

@@ -460,6 +460,195 @@ constexpr double kLn40 = 3.6888794541139363;       // e^-40 < 2^-57: 1 - e^-y is
 // each other on the passband grids.
 // SCALE = false: without the factor normfac -- the fused kernel applies it once per band
 // instead of once per sample (the Wien side is then kappa x^-alpha).
+// The two sides of a sample on their own, straight-line (no branch): the fused kernel
+// calls them for chunk pairs that lie wholly on one side of the merge point, so that
+// the compiler can interleave the two samples' chains and table reads.
+// Blackbody side, 0 < x <= 64, without the factor normfac.
+template <bool OPTHIN>
+__device__ __forceinline__ double fnu_bb_tab(const WalkerK &w, double x, double lx, const SampleTabs *tabs)
+{
+    const double bx = poly8_eval(tabs->b, x);
+    if (OPTHIN) {
+        return m_exp_t(w.bp2 * lx, tabs->e) * bx;                               // :24-25, :51
+    } else {
+        const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);  // :74, :105
+        return (y * poly8_eval(tabs->c, y)) * ((x * x) * bx);                   // :75-76, :106
+    }
+}
+
+// Wien side (x > xmerge), without the factor normfac: kappa x^-alpha    :48-49, :102-103
+__device__ __forceinline__ double fnu_wien_tab(const WalkerK &w, double lx, const SampleTabs *tabs)
+{
+    return w.kap * m_exp_t<true, false>(-w.alpha * lx, tabs->e);
+}
+
+// N samples of the blackbody side at once, their chains interleaved step by step: a
+// sample is one long dependent chain (power -> exp -> polynomial, ~30 fp64 operations
+// and two LDS look-ups deep), and a wave alone issues a dependent operation only every
+// ~9 cycles, so one sample at a time leaves the SIMD half idle unless five or more
+// waves share it (tools/probe_clock.py).  The compiler does not interleave such
+// chains by itself; the scheduling fences pin the order written here.  The values are
+// exactly those of fnu_bb_tab.
+#define MBB_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <bool OPTHIN, int N>
+__device__ __forceinline__ void fnu_bb_tab_n(const WalkerK &w, const double (&x)[N], const double (&lx)[N],
+                                             const SampleTabs *tabs, double (&f)[N])
+{
+    constexpr double kMagic8 = 844424930131968.0;          // 1.5 2^49: ulp 1/8 (poly8_eval)
+    constexpr double kMagicE = 6755399441055744.0;         // 1.5 2^52 (reduce_ln2_256)
+    double tb[N], arg[N], sh[N], r[N], q[N], bx[N], y[N];
+    const double *cb[N];
+    int n[N];
+    // b(x): interval and offset; the exponent of the power
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double s8 = x[i] + kMagic8;
+        cb[i] = tabs->b + 8 * __double2loint(s8);
+        tb[i] = x[i] - (s8 - kMagic8);
+        if (OPTHIN) arg[i] = fmin(fmax(w.bp2 * lx[i], -800.0), 800.0);
+        else arg[i] = fmax(fmin(w.beta * (lx[i] - w.lx0), kLn40), -800.0);
+    }
+    MBB_FENCE();
+    double c7[N], c6[N], c5[N], c4[N], c3[N], c2[N], c1[N], c0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        c7[i] = cb[i][7]; c6[i] = cb[i][6]; c5[i] = cb[i][5]; c4[i] = cb[i][4];
+        c3[i] = cb[i][3]; c2[i] = cb[i][2]; c1[i] = cb[i][1]; c0[i] = cb[i][0];
+        sh[i] = fma(arg[i], 3.69329930467574627e+02, kMagicE);
+        n[i] = __double2loint(sh[i]);
+    }
+    MBB_FENCE();
+    Exp2Entry te[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        te[i] = tabs->e[n[i] & (kExp2N - 1)];
+        const double nd = sh[i] - kMagicE;
+        r[i] = fma(nd, -2.70760617406228627e-03, arg[i]);
+    }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(sh[i] - kMagicE, -9.05877661658710765e-20, r[i]);
+    MBB_FENCE();
+    double r2[N], a0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r2[i] = r[i] * r[i]; a0[i] = fma(r[i], 1.0 / 6.0, 0.5); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { a0[i] = fma(r2[i], 1.0 / 24.0, a0[i]); bx[i] = fma(c7[i], tb[i], c6[i]); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = fma(r2[i], a0[i], r[i]); bx[i] = fma(bx[i], tb[i], c5[i]); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = fma(te[i].hi, q[i], te[i].lo); bx[i] = fma(bx[i], tb[i], c4[i]); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { q[i] = te[i].hi + q[i]; bx[i] = fma(bx[i], tb[i], c3[i]); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { y[i] = ldexp(q[i], n[i] >> 8); bx[i] = fma(bx[i], tb[i], c2[i]); }
+    MBB_FENCE();
+    if (OPTHIN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) bx[i] = fma(bx[i], tb[i], c1[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) bx[i] = fma(bx[i], tb[i], c0[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = y[i] * bx[i];           // x^(beta+2) b(x)      :24-25, :51
+    } else {
+        // c(y): interval and offset, its coefficients; the b chain goes on meanwhile
+        double tc[N];
+        const double *cc[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double s8 = y[i] + kMagic8;
+            cc[i] = tabs->c + 8 * __double2loint(s8);
+            tc[i] = y[i] - (s8 - kMagic8);
+            bx[i] = fma(bx[i], tb[i], c1[i]);
+        }
+        MBB_FENCE();
+        double d7[N], d6[N], d5[N], d4[N], d3[N], d2[N], d1[N], d0[N], cy[N], xx[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            d7[i] = cc[i][7]; d6[i] = cc[i][6]; d5[i] = cc[i][5]; d4[i] = cc[i][4];
+            d3[i] = cc[i][3]; d2[i] = cc[i][2]; d1[i] = cc[i][1]; d0[i] = cc[i][0];
+            bx[i] = fma(bx[i], tb[i], c0[i]);
+            xx[i] = x[i] * x[i];
+        }
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) { cy[i] = fma(d7[i], tc[i], d6[i]); xx[i] = xx[i] * bx[i]; }
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d5[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d4[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d3[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d2[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d1[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d0[i]);
+        MBB_FENCE();
+#pragma unroll
+        for (int i = 0; i < N; ++i) f[i] = (y[i] * cy[i]) * xx[i];    // (1 - e^-y) x^2 b(x)   :75-76, :106
+    }
+}
+
+// N samples of the Wien side at once (see fnu_bb_tab_n); the values of fnu_wien_tab.
+template <int N>
+__device__ __forceinline__ void fnu_wien_tab_n(const WalkerK &w, const double (&lx)[N], const SampleTabs *tabs,
+                                               double (&f)[N])
+{
+    constexpr double kMagicE = 6755399441055744.0;
+    double arg[N], sh[N], r[N], q[N];
+    int n[N];
+    Exp2Entry te[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        arg[i] = fmax(-w.alpha * lx[i], -800.0);
+        sh[i] = fma(arg[i], 3.69329930467574627e+02, kMagicE);
+        n[i] = __double2loint(sh[i]);
+    }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        te[i] = tabs->e[n[i] & (kExp2N - 1)];
+        r[i] = fma(sh[i] - kMagicE, -2.70760617406228627e-03, arg[i]);
+    }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = fma(sh[i] - kMagicE, -9.05877661658710765e-20, r[i]);
+    MBB_FENCE();
+    double r2[N], a0[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r2[i] = r[i] * r[i]; a0[i] = fma(r[i], 1.0 / 6.0, 0.5); }
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) a0[i] = fma(r2[i], 1.0 / 24.0, a0[i]);
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = fma(r2[i], a0[i], r[i]);
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = fma(te[i].hi, q[i], te[i].lo);
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = te[i].hi + q[i];
+    MBB_FENCE();
+#pragma unroll
+    for (int i = 0; i < N; ++i) f[i] = w.kap * ldexp(q[i], n[i] >> 8);
+}
+
 template <bool OPTHIN, bool NOALPHA, bool TAB = false, bool SCALE = true>
 __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
                                              const SampleTabs *tabs = nullptr)
@@ -470,17 +659,15 @@ __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double
     if constexpr (TAB) {
         // range clamps only where the argument can leave [-800, 800]
         if (!NOALPHA) {
-            if (x > w.xmerge)                                       // :48-49, :102-103
-                return (SCALE ? w.cpl : w.kap) * m_exp_t<true, false>(-w.alpha * lx, tabs->e);
+            if (x > w.xmerge) return (SCALE ? w.cbb : 1.0) * fnu_wien_tab(w, lx, tabs);
         }
-        double bx;
-        if (x <= 64.0) bx = poly8_eval(tabs->b, x);
-        else bx = x * m_exp_t<true, false>(-x, tabs->e);
+        if (x <= 64.0) return scaled(fnu_bb_tab<OPTHIN>(w, x, lx, tabs));
+        const double bx = x * m_exp_t<true, false>(-x, tabs->e);   // beyond the table: b(x) = x e^-x
         if (OPTHIN) {
-            return scaled(m_exp_t(w.bp2 * lx, tabs->e) * bx);                   // :24-25, :51
+            return scaled(m_exp_t(w.bp2 * lx, tabs->e) * bx);
         } else {
-            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);  // :74, :105
-            return scaled((y * poly8_eval(tabs->c, y)) * ((x * x) * bx));       // :75-76, :106
+            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);
+            return scaled((y * poly8_eval(tabs->c, y)) * ((x * x) * bx));
         }
     } else {
         if (!NOALPHA) {

@@ -128,6 +128,7 @@ struct mbb_ctx {
     long opt_wpb = 0, opt_threads = 0, opt_seg_chunks = 4, opt_debug = 0;
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
+    long opt_roof_wgs = 0, opt_roof_threads = 0;   // measurement: geometry of mbb_roof_probe
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
     long opt_bar_params = 1;  // host path: write the parameter rows into device memory through the BAR
     long opt_pack_tails = 1;  // band leftovers share chunks, one row of 16 lanes each (0: a chunk per leftover)
@@ -997,6 +998,51 @@ extern "C" int mbb_sed_integrate_batch(mbb_ctx *c, const double *pars, int n, in
     return MBB_OK;
 }
 
+// Measurement helper: the empirical roof of the sample arithmetic (k_roof).
+extern "C" int mbb_roof_probe(mbb_ctx *c, const double pars[5], int reps, double *seconds,
+                              double *lane_slots, double *clock_mhz)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!pars || reps <= 0 || !seconds || !lane_slots) return fail(MBB_ERR_ARG, "bad arguments");
+    if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
+    const int threads = c->opt_roof_threads > 0 ? (int)c->opt_roof_threads : 512;
+    const int grid = (int)(c->opt_roof_wgs > 0 ? c->opt_roof_wgs : 2) * c->cu_count;
+    if ((rc = ensure_sed(c, 1, (size_t)grid * threads + 2))) return rc;
+    if ((rc = run_prologue(c, pars, 1, c->opthin, c->noalpha, c->wavenorm, 0, nullptr))) return rc;
+    unsigned long long *d_clk = reinterpret_cast<unsigned long long *>(c->d_sed_out + (size_t)grid * threads);
+    LikeArgs a;
+    memset(&a, 0, sizeof a);
+    a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
+    a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
+    a.nchunk = c->nchunk;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int pass = 0; pass < 2; ++pass) {            // the first pass warms clocks and caches
+        HIPCHK(hipEventRecord(e0, c->stream));
+        dispatch_variant(c->opthin, c->noalpha, [&](auto OT, auto NA) {
+            hipLaunchKernelGGL((k_roof<decltype(OT)::value, decltype(NA)::value>), dim3(grid), dim3(threads),
+                               0, c->stream, a, c->d_sed_wk, reps, c->d_sed_out, d_clk);
+        });
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventSynchronize(e1));
+    }
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(hipEventDestroy(e0));
+    HIPCHK(hipEventDestroy(e1));
+    *seconds = ms * 1e-3;
+    *lane_slots = (double)grid * (threads / 64) * (double)reps * c->nchunk * 64.0;
+    if (clock_mhz) {
+        unsigned long long clk[2] = {0, 0};
+        HIPCHK(hipMemcpy(clk, d_clk, sizeof clk, hipMemcpyDeviceToHost));
+        *clock_mhz = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;
+    }
+    return MBB_OK;
+}
+
 extern "C" int mbb_fnu_eval(mbb_ctx *c, int opthin, int noalpha, const double *freq, int n,
                             double T, double beta, double x0, double alpha, double normfac,
                             double xmerge, double kappa, double *out)
@@ -1124,6 +1170,8 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
+    else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
+    else if (!strcmp(name, "roof_threads")) c->opt_roof_threads = value;
     else return fail(MBB_ERR_ARG, "unknown option");
     return MBB_OK;
 }

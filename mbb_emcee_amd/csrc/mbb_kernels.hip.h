@@ -16,13 +16,6 @@
 
 using namespace mbbd;
 
-// Table-driven exp/expm1 in the sample loop (mbb_math.hip.h); -DMBB_NO_EXP_TABLE
-// builds the polynomial-only variant for A/B measurements.
-#ifdef MBB_NO_EXP_TABLE
-constexpr bool kUseExpTable = false;
-#else
-constexpr bool kUseExpTable = true;
-#endif
 constexpr int kPolyBDoubles = (64 * 8 + 1) * 8;      // mbbh::kPolyBCount intervals x 8 coefficients
 constexpr int kPolyCDoubles = (40 * 8 + 1) * 8;      // mbbh::kPolyCCount
 
@@ -217,8 +210,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
     // (the host guarantees blockDim.x >= 16 W)
     if (const int j = tid >> 4; j < W) {
-        const int w = w0 + j;
         const bool lead = (tid & 15) == 0;                    // the lane that writes to LDS
+        const int w = w0 + j;
         WalkerK k;
         k.status = ROW_SKIP;
         k.pad = 0;
@@ -344,18 +337,18 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         const int s = us.x, c0 = us.y, c1 = us.z;
         double acc = 0.0;
         int c = c0;
-        for (; c + 2 <= c1; c += 2) {          // two independent chains in flight
+        for (; c + 2 <= c1; c += 2) {          // two chunks per step
             const int i0 = c * 64 + lane, i1 = i0 + 64;
             const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
             const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-            const double f0 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n0, l0, &tabs);
-            const double f1 = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, n1, l1, &tabs);
+            const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+            const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
             acc = fma(f0, q0, acc);
             acc = fma(f1, q1, acc);
         }
         if (c < c1) {
             const int i = c * 64 + lane;
-            const double f = fnu_sample<OPTHIN, NOALPHA, kUseExpTable, false>(k, T_nu(i), T_ln(i), &tabs);
+            const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
             acc = fma(f, T_wt(i), acc);
         }
         if (us.w == 0) {
@@ -534,6 +527,66 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (W > nwave)
         for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
     STAMP(6);
+}
+
+// Measurement only (bench.py, roofline): the sample arithmetic of phase 2 and nothing
+// else -- every wave of a chip-filling grid walks all passband chunks `reps` times with
+// one walker's constants; no prologue, no reductions, no epilogue.  Its samples/s is the
+// empirical roof the fused kernel's quadrature is priced against.
+template <bool OPTHIN, bool NOALPHA>
+__global__ void __launch_bounds__(1024) k_roof(const LikeArgs a, const WalkerK *wk, int reps, double *out,
+                                              unsigned long long *clk)
+{
+    // shader cycles (s_memtime) against the 100 MHz reference (s_memrealtime) over the whole
+    // loop of workgroup 0: the clock the chip holds under this load (MI355X_MICROARCH.md,
+    // "DVFS give-back" item 6); stored where nothing else reads it
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_pb[kPolyBDoubles];
+    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
+    const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
+    for (int i = tid; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+    for (int i = tid; i < kPolyBDoubles; i += nt) s_pb[i] = a.poly_b[i];
+    if (!OPTHIN)
+        for (int i = tid; i < kPolyCDoubles; i += nt) s_pc[i] = a.poly_c[i];
+    __syncthreads();
+    const SampleTabs tabs = {s_tab, s_pb, s_pc};
+    const WalkerK k = wk[0];
+    double acc = 0.0;
+    // Two samples per step, the next step's table values fetched before this step's
+    // arithmetic (`prefetch`): what the fused kernel's loop does.
+    const int npair = a.nchunk >> 1;
+    for (int r = 0; r < reps; ++r) {
+        double n0 = a.nu[lane], l0 = a.lnnu[lane], q0 = a.wt[lane];
+        double n1 = a.nu[64 + lane], l1 = a.lnnu[64 + lane], q1 = a.wt[64 + lane];
+        for (int pr = 0; pr < npair; ++pr) {
+            const int nx = (pr + 1 < npair) ? (pr + 1) * 128 + lane : lane;
+            const double pn0 = a.nu[nx], pl0 = a.lnnu[nx], pq0 = a.wt[nx];
+            const double pn1 = a.nu[nx + 64], pl1 = a.lnnu[nx + 64], pq1 = a.wt[nx + 64];
+            const double xs[2] = {k.hokt9 * n0, k.hokt9 * n1};
+            const double lxs[2] = {k.lhokt9 + l0, k.lhokt9 + l1};
+            const bool wien0 = !NOALPHA && xs[0] > k.xmerge, wien1 = !NOALPHA && xs[1] > k.xmerge;
+            const bool far = !(xs[0] <= 64.0) || !(xs[1] <= 64.0);
+            double fs[2];
+            if (__builtin_amdgcn_ballot_w64(wien0 || wien1 || far) == 0) {
+                fnu_bb_tab_n<OPTHIN, 2>(k, xs, lxs, &tabs, fs);
+            } else if (!NOALPHA && __builtin_amdgcn_ballot_w64(!(wien0 && wien1)) == 0) {
+                fnu_wien_tab_n<2>(k, lxs, &tabs, fs);
+            } else {
+                fs[0] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                fs[1] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+            }
+            acc = fma(fs[0], q0, acc);
+            acc = fma(fs[1], q1, acc);
+            n0 = pn0; l0 = pl0; q0 = pq0; n1 = pn1; l1 = pl1; q1 = pq1;
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + tid] = acc;
+    if (clk && blockIdx.x == 0 && tid == 0) {
+        asm volatile("" ::"v"(acc));
+        clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 // modified_blackbody.__init__ + max_wave for n rows, one lane per row.

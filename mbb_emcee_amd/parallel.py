@@ -10,38 +10,21 @@ a single collective.  Every rank runs the same sampler with the same random
 stream, so positions never have to be scattered -- the all-gather of lnprob is
 the only data-path communication.
 
-Two communicators:
+Communicators:
   RcclComm   -- ncclAllGather on device buffers through the C-ABI (the MI355X path)
-  TorchComm  -- torch.distributed all_gather on host tensors (gloo; used by the
-                CPU tests of the sharding logic, and usable as a slow fallback)
+  any object with ``rank``, ``world`` and ``allgather_host(x) -> concatenation over
+  ranks`` -- a host-side gather; the CPU tests of the sharding logic bring one built on
+  torch.distributed/gloo (tests/_dist_worker.py).  Nothing in this package imports torch.
 """
 import numpy as np
 
-__all__ = ["block_bounds", "RcclComm", "TorchComm", "ShardedLikelihood"]
+__all__ = ["block_bounds", "RcclComm", "ShardedLikelihood"]
 
 
 def block_bounds(n, world):
     """Rows per rank (ceil) and the [lo, hi) block of every rank."""
     per = (n + world - 1) // world
     return per, [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
-
-
-class TorchComm(object):
-    """Host-side all-gather through torch.distributed (any backend with CPU tensors)."""
-
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-
-    def allgather_host(self, x):
-        import torch
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        out = torch.empty(self.world * x.size, dtype=torch.float64)
-        self.dist.all_gather_into_tensor(out, torch.from_numpy(x), group=self.group)
-        return out.numpy()
 
 
 class RcclComm(object):
@@ -75,7 +58,7 @@ class ShardedLikelihood(object):
 
     ``like`` is this package's likelihood when ``comm`` is an RcclComm (the
     shard is evaluated by the fused kernel and gathered device-to-device), or
-    any callable ``(m, 5) -> float64[m]`` with a TorchComm.  Calling it with the
+    any callable ``(m, 5) -> float64[m]`` with a host-side communicator.  Calling it with the
     same ``(n, 5)`` array on every rank returns the same ``float64[n]`` everywhere.
     """
 

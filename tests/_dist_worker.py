@@ -11,11 +11,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+class TorchComm(object):
+    """Host-side all-gather through torch.distributed (gloo): the communicator protocol
+    of mbb_emcee_amd.parallel.ShardedLikelihood, kept with the tests so that the product
+    package has no torch dependency."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather_host(self, x):
+        import torch
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = torch.empty(self.world * x.size, dtype=torch.float64)
+        self.dist.all_gather_into_tensor(out, torch.from_numpy(x), group=self.group)
+        return out.numpy()
+
+
 def main():
     import torch.distributed as dist
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    from mbb_emcee_amd.parallel import ShardedLikelihood, TorchComm, block_bounds
+    from mbb_emcee_amd.parallel import ShardedLikelihood, block_bounds
     from mbb_emcee_amd.ensemble import EnsembleSampler
     from mbb_emcee_amd.response import response_set
     from oracle import oracle as O

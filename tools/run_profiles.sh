@@ -1,8 +1,9 @@
 #!/bin/bash
 # Collects the round's profile set on the GPU box: bash tools/run_profiles.sh <tag>
-# (bench line, rocprofv3 kernel stats, HBM traffic counters in two passes, VALU counters
-# of the 250 000-walker launch).  Output under gpurun_out/<tag>/; summaries are copied
-# to profiles/ by hand.
+# (bench line, rocprofv3 kernel stats of the same command, HBM traffic counters in two
+# passes, VALU counters of the bench workload's launches and of the 250 000-walker launch).
+# Output under gpurun_out/<tag>/; summaries are copied to profiles/ by hand.
+# Counter passes carry --kernel-trace only (no other trace domain next to --pmc).
 set -o pipefail
 tag=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,16 +11,20 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 export TMPDIR=/tmp
 cd $R
+VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
+SHORT="--steps 300 --warmup 50 --no-extras"
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py > $O/stats.log 2>&1 || exit 2
 echo "stats done"
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-cfg5 > $O/fetch.log 2>&1 || exit 3
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 200 --warmup 20 --no-cpu --no-cfg5 > $O/write.log 2>&1 || exit 4
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $SHORT > $O/fetch.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $SHORT > $O/write.log 2>&1 || exit 4
 echo "traffic done"
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_valu -- python3 tools/bench_cfg5.py --quick > $O/valu.log 2>&1 || exit 5
+timeout -k 10 300 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu_cfg2 -- python3 bench.py $SHORT > $O/valu_cfg2.log 2>&1 || exit 5
+timeout -k 10 400 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu -- python3 tools/bench_cfg5.py --quick > $O/valu.log 2>&1 || exit 6
 echo "valu done"
 python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null
-python3 tools/summarize_valu.py $O/pmc_valu $O/pmc_valu_cfg5.json > /dev/null
+python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" > /dev/null
+python3 tools/summarize_valu.py $O/pmc_valu $O/pmc_valu_cfg5.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 tools/bench_cfg5.py --quick" > /dev/null
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
 ls $O
