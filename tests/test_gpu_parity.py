@@ -7,7 +7,7 @@ lnL |d| <= 1e-10 max(1, |lnL|), -inf must match exactly.
 import numpy as np
 import pytest
 
-from conftest import VARIANTS, golden_bands, lnl_close
+from conftest import VARIANTS, golden_bands, lnl_close, rec_allclose, parity_record
 
 pytestmark = pytest.mark.gpu
 
@@ -31,14 +31,21 @@ def relerr(a, b):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))
 
 
+def rel_below(kind, a, b, tol):
+    """max relative error below tol, recorded in the parity report"""
+    e = relerr(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    parity_record(kind + " (rel)", e, tol)
+    assert e < tol, "%s: max relative error %g (tolerance %g)" % (kind, e, tol)
+
+
 # ------------------------------------------------------------------ G5: KATs
 def test_kat_thick(mbb):
     """reference tests/test_modified_blackbody.py:6-20"""
     m = mbb.modified_blackbody(10.0, 2.0, 800.0, 2.0, 45.0)
     assert m.has_alpha and not m.optically_thin
-    np.testing.assert_allclose(m(500), 45.0, atol=1e-4)
+    rec_allclose(m(500), 45.0, atol=1e-4, kind="reference KAT")
     wave = np.array([250.0, 350.0, 500.0, 850.0])
-    np.testing.assert_allclose(m(wave), [21.96268738, 39.53249977, 45.0, 22.06274444], rtol=1e-4)
+    rec_allclose(m(wave), [21.96268738, 39.53249977, 45.0, 22.06274444], rtol=1e-4, kind="reference KAT")
 
 
 def test_kat_thin(mbb):
@@ -46,7 +53,7 @@ def test_kat_thin(mbb):
     m = mbb.modified_blackbody(15.0, 1.8, 200.0, 3.0, 50.0, opthin=True)
     assert m.has_alpha and m.optically_thin and m.lambda0 is None
     wave = np.array([250.0, 350.0, 500.0, 850.0])
-    np.testing.assert_allclose(m(wave), [178.34976, 111.03026, 50.0, 10.880588], rtol=1e-4)
+    rec_allclose(m(wave), [178.34976, 111.03026, 50.0, 10.880588], rtol=1e-4, kind="reference KAT")
 
 
 def test_kat_thinthick(mbb):
@@ -54,18 +61,18 @@ def test_kat_thinthick(mbb):
     wave = np.array([500.0, 850.0, 1100.0, 2500.0])
     a = mbb.modified_blackbody(15.0, 1.8, 5.0, 3.0, 50.0, opthin=True)
     b = mbb.modified_blackbody(15.0, 1.8, 5.0, 3.0, 50.0, opthin=False)
-    np.testing.assert_allclose(a(wave), b(wave), rtol=1e-3)
+    rec_allclose(a(wave), b(wave), rtol=1e-3, kind="reference KAT")
 
 
 def test_kat_merge(mbb):
     """reference tests/test_modified_blackbody.py:50-69"""
     mb = mbb.modified_blackbody
     assert mb(20.0, 1.9, None, 3.5, 50.0, noalpha=True, opthin=True).wavemerge is None
-    np.testing.assert_allclose(mb(20.0, 1.9, None, 3.5, 50.0, opthin=True).wavemerge, 85.66065, rtol=1e-3)
-    np.testing.assert_allclose(mb(35.0, 2.2, None, 2.8, 50.0, opthin=True).wavemerge, 51.40211, rtol=1e-3)
+    rec_allclose(mb(20.0, 1.9, None, 3.5, 50.0, opthin=True).wavemerge, 85.66065, rtol=1e-3, kind="reference KAT")
+    rec_allclose(mb(35.0, 2.2, None, 2.8, 50.0, opthin=True).wavemerge, 51.40211, rtol=1e-3, kind="reference KAT")
     assert mb(20.0, 1.9, 250.0, 3.5, 50.0, noalpha=True).wavemerge is None
-    np.testing.assert_allclose(mb(20.0, 1.9, 250.0, 3.5, 50.0).wavemerge, 109.5506829, rtol=1e-3)
-    np.testing.assert_allclose(mb(40.0, 1.5, 600.0, 3.0, 50.0).wavemerge, 60.10021595, rtol=1e-3)
+    rec_allclose(mb(20.0, 1.9, 250.0, 3.5, 50.0).wavemerge, 109.5506829, rtol=1e-3, kind="reference KAT")
+    rec_allclose(mb(40.0, 1.5, 600.0, 3.0, 50.0).wavemerge, 60.10021595, rtol=1e-3, kind="reference KAT")
 
 
 def test_kat_spire250_flat(mbb):
@@ -73,7 +80,7 @@ def test_kat_spire250_flat(mbb):
     wheel = mbb.response_set()
     # a (nearly) flat SED: alpha-law side of a hot thin body is not flat, so use
     # the callable path with a constant, which is host-only, plus a GPU SED check
-    np.testing.assert_allclose(wheel["SPIRE_250um"](lambda x: 1), 1.011046, atol=1e-4)
+    rec_allclose(wheel["SPIRE_250um"](lambda x: 1), 1.011046, atol=1e-4, kind="reference KAT")
 
 
 def test_ctor_errors(mbb):
@@ -92,16 +99,17 @@ def test_prologue_scalars(ctx, g_sed, name, opthin, noalpha):
     ref = g_sed[name + "/scalars"]
     out, st = ctx.sed_prologue(pars, opthin, noalpha, 500.0, want_peak=True)
     assert np.all(st == 0)
-    assert relerr(out[:, 0], ref[:, 0]) < 1e-12                 # normfac
+    rel_below("normfac", out[:, 0], ref[:, 0], 1e-12)
     if not noalpha:
+        parity_record("xmerge (abs)", np.max(np.abs(out[:, 1] - ref[:, 1])), 1e-10)
         assert np.max(np.abs(out[:, 1] - ref[:, 1])) < 1e-10    # xmerge (atol)
-        assert relerr(out[:, 2], ref[:, 2]) < 1e-10             # kappa
-        assert relerr(out[:, 4], ref[:, 4]) < 1e-10             # wavemerge
+        rel_below("kappa", out[:, 2], ref[:, 2], 1e-10)
+        rel_below("wavemerge", out[:, 4], ref[:, 4], 1e-10)
     else:
         assert np.all(np.isnan(out[:, 1])) and np.all(np.isnan(out[:, 4]))
     if not opthin:
-        assert relerr(out[:, 3], ref[:, 3]) < 1e-14             # x0
-    assert relerr(out[:, 5], ref[:, 5]) < 1e-10                 # max_wave (brentq xtol)
+        rel_below("x0", out[:, 3], ref[:, 3], 1e-14)
+    rel_below("max_wave", out[:, 5], ref[:, 5], 1e-10)                 # (brentq xtol)
 
 
 # ------------------------------------------------------- G3: f_nu on a grid
@@ -112,15 +120,15 @@ def test_fnu_grid(ctx, g_sed, name, opthin, noalpha):
     ref = g_sed[name + "/fnu_grid"]
     out, st = ctx.sed_eval(pars, opthin, noalpha, 500.0, um_to_GHz / grid)
     assert np.all(st == 0)
-    assert relerr(out, ref) < SED_RTOL
+    rel_below("f_nu", out, ref, SED_RTOL)
     out1, _ = ctx.sed_eval(pars, opthin, noalpha, 500.0, np.array([um_to_GHz / 433.0]))
-    assert relerr(out1[:, 0], g_sed[name + "/fnu_scalar433"]) < SED_RTOL
+    rel_below("f_nu", out1[:, 0], g_sed[name + "/fnu_scalar433"], SED_RTOL)
 
 
 def test_fnu_wavenorm850(mbb, g_sed):
     m = mbb.modified_blackbody(25.0, 1.6, 150.0, 2.5, 12.0, wavenorm=850.0)
-    assert relerr(m(g_sed["wave_grid"]), g_sed["wn850/fnu_grid"]) < SED_RTOL
-    np.testing.assert_allclose(m(850.0), 12.0, rtol=1e-13)
+    rel_below("f_nu", m(g_sed["wave_grid"]), g_sed["wn850/fnu_grid"], SED_RTOL)
+    rec_allclose(m(850.0), 12.0, rtol=1e-13, kind="f_nu(wavenorm) = fnorm")
 
 
 @pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
@@ -133,7 +141,7 @@ def test_fnu_explicit_matches_pyx_signature(ctx, g_sed, name, opthin, noalpha):
         out = ctx.fnu_eval(opthin, noalpha, um_to_GHz / grid, pars[i, 0], pars[i, 1],
                            sc[i, 3] if not opthin else 1.0, pars[i, 3], sc[i, 0],
                            sc[i, 1] if not noalpha else 0.0, sc[i, 2] if not noalpha else 0.0)
-        assert relerr(out, g_sed[name + "/fnu_grid"][i]) < SED_RTOL
+        rel_below("f_nu", out, g_sed[name + "/fnu_grid"][i], SED_RTOL)
 
 
 # ----------------------------------------------------- G4: lnL, cfg 1/2/4
@@ -153,7 +161,7 @@ def test_lnlike_cfg1_delta(mbb, g_lnl, name, opthin, noalpha):
     lnl_close(got, g_lnl[k + "/lnl"])
     fin = np.isfinite(g_lnl[k + "/lnl"])
     mf = like.model_flux(pars[fin])
-    assert relerr(mf, g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+    rel_below("band flux", mf, g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
     # scalar call returns a Python float, row by row identical to the batch
     for i in (0, 3, 50, 55):
         v = like(pars[i])
@@ -166,11 +174,11 @@ def test_lnlike_cfg2_passbands(mbb, g_lnl, name, opthin, noalpha):
     k = "cfg2/" + name
     like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
     like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
-    np.testing.assert_allclose(like.uplims, g_lnl[k + "/uplim"], rtol=1e-15)
+    rec_allclose(like.uplims, g_lnl[k + "/uplim"], rtol=1e-15, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
     lnl_close(like(pars), g_lnl[k + "/lnl"])
     fin = np.isfinite(g_lnl[k + "/lnl"])
-    assert relerr(like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+    rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
 
 @pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
@@ -179,11 +187,11 @@ def test_lnlike_cfg4_covariance(mbb, g_lnl, name, opthin, noalpha):
     like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
     like.set_phot([str(b) for b in g_lnl["cfg4/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
     like.set_cov(g_lnl[k + "/cov"])
-    np.testing.assert_allclose(like.data_wave, g_lnl[k + "/eff_wave"], rtol=1e-14)
+    rec_allclose(like.data_wave, g_lnl[k + "/eff_wave"], rtol=1e-14, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
     lnl_close(like(pars), g_lnl[k + "/lnl"])
     fin = np.isfinite(g_lnl[k + "/lnl"])
-    assert relerr(like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin]) < FLUX_RTOL
+    rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
 
 def test_lnlike_priors_and_peak(mbb, g_lnl):
@@ -216,7 +224,7 @@ def test_max_wave(mbb, g_lnl):
     pars = g_lnl["cfg2/priors/pars"]
     ref = g_lnl["cfg2/priors_peak/max_wave"]
     for i in (0, 11, 50):
-        np.testing.assert_allclose(mbb.modified_blackbody(*pars[i]).max_wave(), ref[i], rtol=1e-10)
+        rec_allclose(mbb.modified_blackbody(*pars[i]).max_wave(), ref[i], rtol=1e-10, kind="max_wave")
 
 
 # ------------------------------------------- HIP vs oracle on fresh inputs
@@ -426,9 +434,9 @@ def test_device_sampler_matches_host_emulation(mbb, g_lnl):
     for t in range(3):
         hp, hl, acc = _host_stretch_step(like, hp, hl, seed, 0, t)
         nacc += acc
-        np.testing.assert_allclose(s.chain[:, t, :], hp, rtol=1e-13)
-        np.testing.assert_allclose(s.lnprobability[:, t], hl, rtol=1e-11, atol=1e-11)
-    np.testing.assert_allclose(pos, hp, rtol=1e-13)
+        rec_allclose(s.chain[:, t, :], hp, rtol=1e-13, kind="sampler vs host emulation")
+        rec_allclose(s.lnprobability[:, t], hl, rtol=1e-11, atol=1e-11, kind="sampler vs host emulation")
+    rec_allclose(pos, hp, rtol=1e-13, kind="sampler vs host emulation")
     assert np.array_equal(s.naccepted, nacc) and 0 < nacc.sum() < 3 * 64
     # the chain's lnprob is the likelihood of the chain's positions
     lnl_close(like(s.chain[:, -1, :]), s.lnprobability[:, -1])
@@ -437,7 +445,7 @@ def test_device_sampler_matches_host_emulation(mbb, g_lnl):
     hp2, hl2 = hp, hl
     for t in range(2):
         hp2, hl2, _ = _host_stretch_step(like, hp2, hl2, seed, 3, t)
-    np.testing.assert_allclose(pos2, hp2, rtol=1e-13)
+    rec_allclose(pos2, hp2, rtol=1e-13, kind="sampler vs host emulation")
     assert s.chain.shape == (64, 5, 5)
 
 
@@ -602,7 +610,7 @@ def test_multi_source_device_sampler(mbb, g_lnl):
             for w in range(half):
                 if lz[w] + new[w] - hl[s_begin + w] > lu[w]:
                     hp[s_begin + w] = q[w]; hl[s_begin + w] = new[w]
-        np.testing.assert_allclose(s2.chain[g, :, 0, :], hp, rtol=1e-13)
+        rec_allclose(s2.chain[g, :, 0, :], hp, rtol=1e-13, kind="sampler vs host emulation")
 
 
 def test_lds_staged_tables_identical(mbb, g_lnl):
@@ -653,9 +661,10 @@ def test_many_bands_and_covariance_vs_oracle(mbb, oracle, nbands):
         A = rng.normal(0, 1, (nbands, nbands))
         cov = np.diag(unc ** 2) + 1e-4 * np.median(unc) ** 2 * A.dot(A.T)
         like.set_cov(cov)
-        lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, cov=cov, **kw)(pars, nthreads=4), rtol=1e-9)
-        np.testing.assert_allclose(like.get_sed(pars[:7], wave), like.model_flux(pars[:7]), rtol=1e-13)
-        np.testing.assert_allclose(like.get_sed(pars[3], wave), like.model_flux(pars[3])[0], rtol=1e-13)
+        lnl_close(like(pars), oracle.OracleLikelihood(flux, unc, cov=cov, **kw)(pars, nthreads=4),
+                  kind="lnL (covariance)")
+        rec_allclose(like.get_sed(pars[:7], wave), like.model_flux(pars[:7]), rtol=1e-13, kind="f_nu vs band flux")
+        rec_allclose(like.get_sed(pars[3], wave), like.model_flux(pars[3])[0], rtol=1e-13, kind="f_nu vs band flux")
 
 
 def test_unit_table_balances_the_simds(mbb, g_lnl):
@@ -699,7 +708,7 @@ def test_mixed_delta_and_passband_bands_keep_their_order(mbb, oracle):
     orc = oracle.OracleLikelihood(flux, unc, bands=bands, has_uplim=[int(b) for b in like.has_uplims],
                                   uplim=like.uplims)
     ref, rflux = orc(pars, nthreads=4, return_flux=True)
-    np.testing.assert_allclose(like.model_flux(pars), rflux, rtol=1e-12)
+    rec_allclose(like.model_flux(pars), rflux, rtol=1e-12, kind="band flux")
     lnl_close(like(pars), ref)
     for wpb, thr in ((1, 64), (4, 256), (16, 256)):
         like.context.set_option("walkers_per_group", wpb); like.context.set_option("block_threads", thr)
@@ -741,14 +750,14 @@ def test_band_sizes_around_the_chunk_and_row_boundaries(mbb, oracle, tmp_path):
                                   has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
     ref, rflux = orc(pars, nthreads=4, return_flux=True)
     got, gflux = like(pars), like.model_flux(pars)
-    np.testing.assert_allclose(gflux, rflux, rtol=1e-12)
+    rec_allclose(gflux, rflux, rtol=1e-12, kind="band flux")
     lnl_close(got, ref)
     nfull = sum(n // 64 + (1 if n % 64 > 48 else 0) for n in sizes)
     nrows = sum(-(-(n % 64) // 16) for n in sizes if n % 64 <= 48)
     assert like.context.info("nchunk") == nfull + -(-nrows // 4)
     like.context.set_option("pack_tails", 0)
     like._dirty = True
-    np.testing.assert_allclose(like.model_flux(pars), gflux, rtol=2e-15)
+    rec_allclose(like.model_flux(pars), gflux, rtol=2e-15, kind="band flux")
     assert like.context.info("nchunk") == sum(-(-n // 64) for n in sizes)
     like.context.set_option("pack_tails", 1)
     like._dirty = True
@@ -815,9 +824,9 @@ def test_freq_integrate_vs_reference_quad(mbb, ctx, g_sed, name, opthin, noalpha
     for col, (lo, hi) in enumerate(((24.0, 3000.0), (42.5, 122.5))):
         out, st = ctx.sed_integrate(pars[sel], opthin, noalpha, 500.0, um_to_GHz / hi, um_to_GHz / lo)
         assert np.all(st == 0)
-        np.testing.assert_allclose(1e-17 * out, ref[sel, col], rtol=2e-7)
+        rec_allclose(1e-17 * out, ref[sel, col], rtol=2e-7, kind="freq_integrate")
     m = mbb.modified_blackbody(*pars[sel[3]], opthin=opthin, noalpha=noalpha)
-    np.testing.assert_allclose(m.freq_integrate(3000.0, 24.0), ref[sel[3], 0], rtol=2e-7)
+    rec_allclose(m.freq_integrate(3000.0, 24.0), ref[sel[3], 0], rtol=2e-7, kind="freq_integrate")
     with pytest.raises(ValueError):
         m.freq_integrate(0.0, 10.0)
 
@@ -829,10 +838,10 @@ def test_postprocess_chain(mbb, g_lnl, oracle):
     pk = pp.peak_wavelength(like, chain)
     assert pk.shape == (6, 10)
     for i, j in ((0, 0), (3, 7), (5, 9)):
-        np.testing.assert_allclose(pk[i, j], oracle.OracleSED(*chain[i, j]).max_wave(), rtol=1e-10)
+        rec_allclose(pk[i, j], oracle.OracleSED(*chain[i, j]).max_wave(), rtol=1e-10, kind="max_wave")
     L = pp.lir(like, chain, redshift=2.0, lumdist_mpc=15000.0)
     fi = pp.freq_integral(like, chain, 24.0, 3000.0)
-    np.testing.assert_allclose(L, 3.11749657e4 * 15000.0 ** 2 * fi, rtol=1e-14)
+    rec_allclose(L, 3.11749657e4 * 15000.0 ** 2 * fi, rtol=1e-14, kind="freq_integrate")
     # against a direct high-accuracy quadrature of the oracle SED
     from scipy.integrate import quad
     sed = oracle.OracleSED(*chain[2, 4])
@@ -840,7 +849,7 @@ def test_postprocess_chain(mbb, g_lnl, oracle):
     nu0, nu1, num = 299792.458 / 3000.0, 299792.458 / 24.0, 299792.458 / wm
     val = sum(quad(lambda f: float(sed.f_nu(f)[0]), a, b, epsrel=1e-12, limit=200)[0]
               for a, b in ((nu0, num), (num, nu1)))
-    np.testing.assert_allclose(fi[2, 4], 1e-17 * val, rtol=1e-10)
+    rec_allclose(fi[2, 4], 1e-17 * val, rtol=1e-10, kind="freq_integrate")
     md = pp.dustmass(like, chain, redshift=2.0, lumdist_mpc=15000.0)
     assert md.shape == (6, 10) and np.all(md > 0)
 
@@ -892,14 +901,14 @@ def test_full_size_cfg3_and_cfg5_properties(mbb, g_lnl, oracle):
     assert np.array_equal(like(w[perm]), l0[perm])                   # equivariant, bitwise
     mf = like.model_flux(w)
     w3 = w.copy(); w3[:, 4] *= 3.0
-    np.testing.assert_allclose(like.model_flux(w3), 3.0 * mf, rtol=3e-15)       # linear in fnorm
+    rec_allclose(like.model_flux(w3), 3.0 * mf, rtol=3e-15, kind="band flux")   # linear in fnorm
     chi = -0.5 * np.sum((like.data_flux - mf) ** 2 / like.data_flux_unc ** 2, axis=1)
-    np.testing.assert_allclose(l0, chi, rtol=1e-12, atol=1e-12)      # no wall is hit by these rows
+    rec_allclose(l0, chi, rtol=1e-12, atol=1e-12, kind="lnL identity")   # no wall is hit by these rows
     wb = w.copy(); wb[:, 1] = 20.5                                   # beta above its soft wall
     pen = -0.5 * (20.5 - 20.0) ** 2 / (0.02 * (20.0 - 0.1)) ** 2
     mfb = like.model_flux(wb)
     chib = -0.5 * np.sum((like.data_flux - mfb) ** 2 / like.data_flux_unc ** 2, axis=1)
-    np.testing.assert_allclose(like(wb), chib + pen, rtol=1e-12)
+    rec_allclose(like(wb), chib + pen, rtol=1e-12, kind="lnL identity")
     # ---- cfg5: 1000 sources x 250 walkers ----------------------------------------
     like5, truths, p0 = setup(1000, 250)
     big = like5(p0)
@@ -971,7 +980,7 @@ def test_random_configurations_vs_oracle(mbb, oracle, seed):
     like.context.set_option("block_threads", int(rng.choice([0, 64, 256, 640, 1024])))
     got = like(pars)
     like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
-    lnl_close(got, ref, rtol=1e-9 if cov is not None else 1e-10)
+    lnl_close(got, ref, kind="lnL (covariance)" if cov is not None else "lnL")
     assert np.array_equal(got, like(pars), equal_nan=True)
 
 
@@ -1007,8 +1016,10 @@ def test_wide_parameter_ranges_vs_oracle(mbb, oracle, opthin, noalpha):
     assert fin.sum() > 0.9 * n
     assert np.array_equal(np.isfinite(got), fin)
     ok = fin[:, None] & (rflux > 1e-280)
-    assert np.max(np.abs(gflux[ok] / rflux[ok] - 1.0)) < 1e-11          # 1e-12 + the oracle's brentq
-    lnl_close(got, ref, rtol=1e-9)          # (a row whose root find failed would have raised)
+    ferr = np.max(np.abs(gflux[ok] / rflux[ok] - 1.0))
+    parity_record("band flux (rel)", ferr, FLUX_RTOL)
+    assert ferr < FLUX_RTOL
+    lnl_close(got, ref)                     # (a row whose root find failed would have raised)
 
 
 def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
