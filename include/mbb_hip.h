@@ -184,7 +184,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * "zero_copy" (host path reads/writes pinned host memory from the kernel),
  * "spin_wait" (how mbb_lnlike_batch waits: 0 blocks on the stream, 1 polls it,
  * 2 -- the default -- watches the result slots in pinned memory, which are final
- * before the kernel's completion signal is), "bar_params" (host path writes the
+ * before the kernel's completion signal is; "spin_budget" = polls before it falls back
+ * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug". */

@@ -132,6 +132,8 @@ struct mbb_ctx {
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
     long opt_bar_params = 1;  // host path: write the parameter rows into device memory through the BAR
     long opt_pack_tails = 1;  // band leftovers share chunks, one row of 16 lanes each (0: a chunk per leftover)
+    long opt_spin_budget = 20000000L;   // polls of the result slots before falling back to the stream
+    long last_watch_seen = -1;          // last mbb_lnlike_batch: 1 results seen by the watch, 0 fell back, -1 no watch
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
@@ -326,8 +328,10 @@ extern "C" int mbb_set_gpriors(mbb_ctx *c, const int32_t has[6], const double me
     return MBB_OK;
 }
 
-// Wait for the context's stream; option "spin_wait" polls hipStreamQuery instead
-// of blocking (measured on MI355X: no faster, so off by default).
+// How mbb_lnlike_batch waits (option "spin_wait"): 0 blocks on the stream; 1 polls
+// hipStreamQuery (measured on MI355X: no faster than 0); 2, the default for zero-copy
+// batches of <= 8192 rows, watches the result slots in pinned host memory and falls back
+// to 0 when they have not all appeared within "spin_budget" polls.
 static const uint64_t kLnlSentinel = 0x7ff8dead5eed0001ull;
 static const int32_t kStatusSentinel = 0x7fffff01;
 
@@ -358,9 +362,13 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         HIPCHK(hipMalloc((void **)&c->d_pars, cap * 5 * sizeof(double)));
         HIPCHK(hipMalloc((void **)&c->d_lnl, cap * sizeof(double)));
         HIPCHK(hipMalloc((void **)&c->d_status, cap * sizeof(int32_t)));
-        HIPCHK(hipHostMalloc((void **)&c->h_pars, cap * 5 * sizeof(double), hipHostMallocMapped));
-        HIPCHK(hipHostMalloc((void **)&c->h_lnl, cap * sizeof(double), hipHostMallocMapped));
-        HIPCHK(hipHostMalloc((void **)&c->h_status, cap * sizeof(int32_t), hipHostMallocMapped));
+        // mapped AND coherent (fine-grained): the kernel's stores to the result slots must
+        // become visible to the polling host while the kernel is still running, whatever
+        // HIP_HOST_COHERENT defaults to
+        const unsigned hflags = hipHostMallocMapped | hipHostMallocCoherent;
+        HIPCHK(hipHostMalloc((void **)&c->h_pars, cap * 5 * sizeof(double), hflags));
+        HIPCHK(hipHostMalloc((void **)&c->h_lnl, cap * sizeof(double), hflags));
+        HIPCHK(hipHostMalloc((void **)&c->h_status, cap * sizeof(int32_t), hflags));
         // With a large BAR the host can store into (fine-grained) device memory directly:
         // posted writes, and the kernel then reads its parameter rows from local memory
         // instead of pulling them across PCIe.
@@ -385,7 +393,7 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         free_dev(c->d_mflux); free_host(c->h_mflux);
         c->d_mflux = nullptr; c->h_mflux = nullptr; c->cap_flux = 0;
         HIPCHK(hipMalloc((void **)&c->d_mflux, cap * sizeof(double)));
-        HIPCHK(hipHostMalloc((void **)&c->h_mflux, cap * sizeof(double), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&c->h_mflux, cap * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
         c->cap_flux = cap;
     }
     return MBB_OK;
@@ -592,6 +600,7 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
         // watches them: a walker's results are final the moment they appear, before the
         // end-of-kernel bookkeeping.  status is written after lnl by the same lane.
         const bool watch = c->opt_spin == 2 && !model_flux && n <= 8192;
+        c->last_watch_seen = -1;
         if (watch) {
             uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
             for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
@@ -601,14 +610,18 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
         const long t_c = now_ns();
         bool seen = false;
         if (watch) {
-            const volatile uint64_t *hl = reinterpret_cast<const volatile uint64_t *>(c->h_lnl);
-            const volatile int32_t *hs = c->h_status;
+            // acquire loads: the copies out of h_lnl / h_status below must not be satisfied
+            // from before the slot was seen to change
+            const uint64_t *hl = reinterpret_cast<const uint64_t *>(c->h_lnl);
+            const int32_t *hs = c->h_status;
             int i = 0;
-            for (long spins = 0; spins < 20000000L; ++spins) {        // ~ tens of ms, then give up
-                while (i < n && hl[i] != kLnlSentinel && hs[i] != kStatusSentinel) ++i;
+            for (long spins = 0; spins < c->opt_spin_budget; ++spins) {   // default ~ tens of ms, then give up
+                while (i < n && __atomic_load_n(&hl[i], __ATOMIC_ACQUIRE) != kLnlSentinel &&
+                       __atomic_load_n(&hs[i], __ATOMIC_ACQUIRE) != kStatusSentinel) ++i;
                 if (i == n) { seen = true; break; }
                 __builtin_ia32_pause();
             }
+            c->last_watch_seen = seen ? 1 : 0;
         }
         if (!seen && (rc = wait_stream(c))) return rc;
         c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
@@ -1167,6 +1180,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "debug")) c->opt_debug = value;
     else if (!strcmp(name, "stage_tables")) c->opt_stage = value;
     else if (!strcmp(name, "spin_wait")) c->opt_spin = value;
+    else if (!strcmp(name, "spin_budget")) c->opt_spin_budget = value < 0 ? 0 : value;
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
@@ -1185,6 +1199,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_prep_ns")) *value = c->t_prep_ns;
     else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;
     else if (!strcmp(name, "last_wait_ns")) *value = c->t_wait_ns;
+    else if (!strcmp(name, "last_watch_seen")) *value = c->last_watch_seen;
     else if (!strcmp(name, "simd_chunks_max")) *value = *std::max_element(c->simd_chunks, c->simd_chunks + 4);
     else if (!strcmp(name, "simd_chunks_min")) *value = *std::min_element(c->simd_chunks, c->simd_chunks + 4);
     else if (!strcmp(name, "nchunk")) *value = c->nchunk;
@@ -1220,6 +1235,7 @@ extern "C" int mbb_comm_init(mbb_ctx *c, int nranks, int rank, const char id[128
     int rc = use(c);
     if (rc) return rc;
     if (nranks < 1 || rank < 0 || rank >= nranks || !id) return fail(MBB_ERR_ARG, "bad rank layout");
+    if (c->comm) return fail(MBB_ERR_STATE, "this context already has a communicator (mbb_comm_destroy first)");
     if ((rc = load_rccl())) return rc;
     UniqueId u;
     memcpy(u.internal, id, 128);

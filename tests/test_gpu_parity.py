@@ -253,16 +253,49 @@ def test_vs_oracle_batch_sizes(mbb, oracle, g_lnl, name, opthin, noalpha, n):
     assert np.array_equal(sub, got[: max(1, n // 3)])
 
 
-def test_zero_copy_path_identical(mbb, g_lnl):
+def test_host_path_modes_identical(mbb, g_lnl):
+    """mbb_lnlike_batch gives bitwise the same answers however the rows travel and however
+    the host waits: explicit copies or zero-copy, parameter rows pushed through the BAR or
+    pulled from pinned memory, blocking on the stream (spin_wait 0), polling it (1) or
+    watching the result slots (2, the default).  The watch must actually see the results
+    (a silent fall-back would cost the whole spin budget per call), and when it is forced
+    to give up (spin_budget 0) the stream wait takes over with the same results.
+    Reference behaviour kept: likelihood.__call__ returns synchronously (likelihood.py:834)."""
     bands = [str(b) for b in g_lnl["cfg2/bands"]]
     like = mbb.likelihood(response=True)
     like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
     pars = g_lnl["cfg2/thick_walpha/pars"]
-    a = like(pars)
-    like.context.set_option("zero_copy", 1)
-    b = like(pars)
-    like.context.set_option("zero_copy", 0)
-    assert np.array_equal(a, b, equal_nan=True)
+    ctx = like.context
+    ref = like(pars)
+    assert np.isneginf(ref).any() and np.isfinite(ref).any()
+    assert ctx.info("last_watch_seen") == 1            # default path: the watch saw every slot
+    try:
+        for zero_copy in (1, 0):
+            for bar in (1, 0):
+                for spin in (2, 1, 0):
+                    ctx.set_option("zero_copy", zero_copy); ctx.set_option("bar_params", bar)
+                    ctx.set_option("spin_wait", spin)
+                    for n in (1, 125, len(pars)):
+                        got = like(pars[:n])
+                        assert np.array_equal(got, ref[:n], equal_nan=True), (zero_copy, bar, spin, n)
+                    seen = ctx.info("last_watch_seen")
+                    assert seen == (1 if (zero_copy and spin == 2) else -1), (zero_copy, bar, spin, seen)
+        # forced fall-back: no polls allowed, the results must come from the stream wait
+        ctx.set_option("zero_copy", 1); ctx.set_option("bar_params", 1); ctx.set_option("spin_wait", 2)
+        ctx.set_option("spin_budget", 0)
+        for n in (1, 125, len(pars)):
+            got = like(pars[:n])
+            assert np.array_equal(got, ref[:n], equal_nan=True)
+            assert ctx.info("last_watch_seen") == 0 and ctx.info("last_wait_ns") > 0
+        # a budget too small to outlast the kernel gives up as well, or sees everything: same numbers
+        ctx.set_option("spin_budget", 3)
+        assert np.array_equal(like(pars[:125]), ref[:125], equal_nan=True)
+        assert ctx.info("last_watch_seen") in (0, 1)
+    finally:
+        ctx.set_option("spin_budget", 20000000); ctx.set_option("spin_wait", 2)
+        ctx.set_option("zero_copy", 1); ctx.set_option("bar_params", 1)
+    assert np.array_equal(like(pars), ref, equal_nan=True)
+    assert ctx.info("last_watch_seen") == 1
 
 
 @pytest.mark.parametrize("wpb,threads", [(1, 64), (1, 1024), (3, 256), (16, 128), (64, 512)])
