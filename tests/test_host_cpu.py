@@ -320,3 +320,92 @@ def test_sharded_two_ranks_gloo():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "DIST_OK" in out.stdout
+
+
+# ------------------------------------------------- host-only table builders (C++), sanitizers
+def _hosttables_lib():
+    import _layout_checks as LC
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libmbb_hosttables.so"])
+    return LC, LC.load(os.path.join(ROOT, "oracle", "libmbb_hosttables.so"))
+
+
+def test_band_layout_properties():
+    """build_band_layout (mbb_emcee_amd/csrc/mbb_host_tables.cpp; what mbb_set_bands uploads):
+    the 18 band sizes around the row / chunk boundaries of the GPU test, delta-function
+    photometry, and 1000 random layouts -- every sample appears exactly once with its weight
+    and log, the units tile the chunks, the bands' slot ranges tile [0, npart), and every
+    band's slots sum to exactly the band's samples when the table is walked as the kernel
+    walks it."""
+    LC, lib = _hosttables_lib()
+    assert LC.run_all(lib, nrandom=1000) >= 1040
+
+
+def test_band_layout_rejects_bad_tables():
+    LC, lib = _hosttables_lib()
+    import ctypes as C
+    f = np.array([10.0, 20.0, -1.0]); w = np.ones(3)
+    cnt = np.zeros(9, dtype=np.int32); buf = np.zeros(640); ib = np.zeros(64, dtype=np.int32)
+
+    def call(freq, offsets, nb):
+        o = np.asarray(offsets, dtype=np.int32)
+        return lib.mbbh_band_layout(freq.ctypes.data_as(LC._dp), w.ctypes.data_as(LC._dp), o.ctypes.data_as(LC._ip),
+                                    nb, 4, 1, cnt.ctypes.data_as(LC._ip), buf.ctypes.data_as(LC._dp),
+                                    buf.ctypes.data_as(LC._dp), buf.ctypes.data_as(LC._dp), ib.ctypes.data_as(LC._ip),
+                                    ib.ctypes.data_as(LC._ip), ib.ctypes.data_as(LC._ip), 3, 4)
+    assert call(f, [0, 3], 1) == -4                 # non-positive frequency
+    assert call(f, [1, 3], 1) == -2                 # offsets[0] != 0
+    assert call(f, [0, 2, 2], 2) == -3              # empty band
+    assert call(f, [0, 2], 0) == -1
+    assert call(np.array([5.0, 6.0, 7.0]), [0, 3], 1) == 0
+
+
+def test_poly_tables_accuracy():
+    """The piecewise degree-7 polynomials of b(x) = x/expm1(x) and c(y) = (1 - e^-y)/y the
+    sample loop evaluates (mbb_math.hip.h, poly8_eval), rebuilt on the host and evaluated
+    by the same Horner recurrence in float64, against numpy longdouble: <= 3 ulp everywhere
+    on [0, 64] and [0, 40], interval edges and tiny arguments included."""
+    LC, lib = _hosttables_lib()
+    import ctypes as C
+    nb_, nc_, k_ = C.c_int(), C.c_int(), C.c_int()
+    lib.mbbh_poly_counts(C.byref(nb_), C.byref(nc_), C.byref(k_))
+    assert (nb_.value, nc_.value, k_.value) == (513, 321, 8)
+    b = np.zeros((nb_.value, 8)); c = np.zeros((nc_.value, 8))
+    lib.mbbh_poly_tables(b.ctypes.data_as(LC._dp), c.ctypes.data_as(LC._dp))
+    LD = np.longdouble
+    rng = np.random.RandomState(9)
+
+    def horner(tab, x):
+        sh = x + 844424930131968.0
+        i = (sh.view(np.int64) & 0xffffffff).astype(np.int64)
+        t = x - (sh - 844424930131968.0)
+        assert np.all(np.abs(t) <= 0.0625) and np.all(i == np.rint(8 * x))
+        p = tab[i, 7]
+        for k in range(6, -1, -1):
+            p = p * t + tab[i, k]
+        return p
+    for tab, xmax, fun in ((b, 64.0, lambda v: v / np.expm1(v)), (c, 40.0, lambda v: -np.expm1(-v) / v)):
+        edges = np.arange(1, int(8 * xmax)) / 8.0 + 0.0625
+        x = np.concatenate([rng.uniform(0, xmax, 20000), 10.0 ** rng.uniform(-15, 0, 4000), edges,
+                            np.nextafter(edges, 0), [xmax, 1e-300]])
+        ref = fun(x.astype(LD))
+        err = np.abs((horner(tab, x).astype(LD) - ref) / ref).astype(np.float64)
+        assert err.max() < 3 * 1.1102230246251565e-16, (xmax, err.max(), x[err.argmax()])
+        assert tab[0, 0] == 1.0
+
+
+def test_sanitizers():
+    """AddressSanitizer + UBSan over the host-only C++ of the product (band layout, polynomial
+    tables) and over the oracle: `make -C oracle asan`, then tests/_asan_worker.py with the
+    sanitizer runtimes preloaded (sanitizers run on the CPU build only)."""
+    libs = [subprocess.check_output(["gcc", "-print-file-name=" + n]).decode().strip()
+            for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(p) and os.path.exists(p) for p in libs):
+        pytest.skip("gcc's sanitizer runtimes are not installed")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
+    env = dict(os.environ, LD_PRELOAD=":".join(libs), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", MBB_ASAN_LAYOUTS="300")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_asan_worker.py")], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "ASAN_OK" in text and "ERROR: AddressSanitizer" not in text \
+        and "runtime error" not in text, text[-3000:]
