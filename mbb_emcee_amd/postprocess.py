@@ -7,13 +7,20 @@ steps that repeat the previous one.  Here every step of every walker is one row
 of a batched kernel call, so no de-duplication is needed.  Only the arithmetic
 is provided; the results object, its HDF5 layout and the cosmology
 (astropy) stay out of scope -- pass the luminosity distance in.
+
+Parity: peak wavelength and the frequency integral are checked against the
+reference's own numbers (tests/golden/sed.npz).  ``results.py`` itself cannot be
+imported here (astropy.units), so ``dustmass`` and ``predict_flux`` are PARITY
+UNPINNED: the tests hold them to independent identities instead (the implied flux
+density, the thick/thin ratio tau/(1 - e^-tau), scalings; predicted fluxes against
+``likelihood.model_flux`` / ``get_sed``, which are pinned).
 """
 import numpy as np
 
 from . import _native
 from .modified_blackbody import um_to_GHz
 
-__all__ = ["peak_wavelength", "freq_integral", "lir", "dustmass"]
+__all__ = ["peak_wavelength", "freq_integral", "lir", "dustmass", "predict_flux"]
 
 
 def _rows(chain):
@@ -80,3 +87,54 @@ def dustmass(like, chain, redshift, lumdist_mpc, kappa=2.64, kappa_wave=125.0):
         tau = (c[..., 2] / like.wavenorm) ** beta
         m = m * (-tau / np.expm1(-tau))
     return m
+
+
+def predict_flux(like, chain, spec, wavenorm=None):
+    """Predicted flux density [mJy] for every chain entry (results.py:895-944,
+    ``mbb_results._predict_flux``): ``spec`` is a wavelength in um (the SED there), the name
+    of a passband of the fit's filter wheel (the band flux through that response,
+    response.py:544-576), or a list mixing both -- the result then has a trailing axis of
+    that length.  All entries of the chain go through one batched call per kind.
+
+    The reference builds its SED here without passing the fit's ``wavenorm`` on
+    (results.py:931-934: the modified_blackbody default, 500 um, is used whatever the
+    fit was normalised at).  ``wavenorm=None`` uses the fit's own normalisation
+    wavelength, which is what the chain's fnorm refers to; pass 500.0 to reproduce the
+    reference literally for a fit with another wavenorm."""
+    rows, shape = _rows(chain)
+    single = isinstance(spec, str) or np.isscalar(spec)
+    specs = [spec] if single else list(spec)
+    wn = like.wavenorm if wavenorm is None else float(wavenorm)
+    out = np.empty((rows.shape[0], len(specs)))
+    names = [(i, str(s)) for i, s in enumerate(specs) if isinstance(s, str)]
+    waves = [(i, float(s)) for i, s in enumerate(specs) if not isinstance(s, str)]
+    for _, wv in waves:
+        if wv <= 0:
+            raise ValueError("Invalid wavelength {:f}".format(wv))
+    if names:
+        if not like.response_integrate:
+            raise Exception("Asked for response integration, but no response functions "
+                            "available from original fit")
+        for _, nm in names:
+            if nm not in like._responsewheel:
+                raise ValueError("Do not have response function matching {:s}".format(nm))
+        # the fused kernel's band-flux output for a one-off set of bands: a private
+        # likelihood on the same wheel and device, with dummy data
+        from .likelihood import likelihood
+        tmp = likelihood(opthin=like.opthin, noalpha=like.noalpha, wavenorm=wn, device=like._device)
+        tmp._responsewheel = like._responsewheel
+        tmp._response_integrate = True
+        tmp._lowlim = np.full(5, -np.inf)          # a chain entry is never gated here
+        tmp.set_phot([nm for _, nm in names], np.ones(len(names)), np.ones(len(names)))
+        fl = np.empty((rows.shape[0], len(names)))
+        for i0 in range(0, rows.shape[0], 1 << 20):
+            fl[i0:i0 + (1 << 20)] = tmp.model_flux(rows[i0:i0 + (1 << 20)])
+        for k, (i, _) in enumerate(names):
+            out[:, i] = fl[:, k]
+    if waves:
+        sed, st = like.context.sed_eval(rows, like.opthin, like.noalpha, wn,
+                                        um_to_GHz / np.array([wv for _, wv in waves]))
+        _native.raise_for_status(st)
+        for k, (i, _) in enumerate(waves):
+            out[:, i] = sed[:, k]
+    return out[:, 0].reshape(shape) if single else out.reshape(shape + (len(specs),))

@@ -884,7 +884,102 @@ def test_postprocess_chain(mbb, g_lnl, oracle):
               for a, b in ((nu0, num), (num, nu1)))
     rec_allclose(fi[2, 4], 1e-17 * val, rtol=1e-10, kind="freq_integrate")
     md = pp.dustmass(like, chain, redshift=2.0, lumdist_mpc=15000.0)
-    assert md.shape == (6, 10) and np.all(md > 0)
+    assert md.shape == (6, 10) and np.all(md > 0)       # identities: tests/test_host_cpu.py
+
+
+def test_predict_flux_over_a_chain(mbb, g_lnl, oracle):
+    """postprocess.predict_flux (results.py:895-944): predicted band fluxes through any
+    passband of the wheel and SED values at any wavelength for every chain entry, in
+    batched calls.  results.py cannot be imported (astropy), so this is held against the
+    pinned pieces: likelihood.model_flux for the fit's own bands, the oracle's response
+    integration for a band that was not fitted, and the oracle SED."""
+    from mbb_emcee_amd import postprocess as pp
+    like = _cfg2_like(mbb, g_lnl)
+    chain = g_lnl["cfg2/thick_walpha/pars"][:60].reshape(6, 10, 5)
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    own = pp.predict_flux(like, chain, bands)
+    assert own.shape == (6, 10, len(bands))
+    assert np.array_equal(own.reshape(60, -1), like.model_flux(chain.reshape(60, 5)))
+    one = pp.predict_flux(like, chain, "SPIRE_350um")
+    assert one.shape == (6, 10) and np.array_equal(one, own[..., bands.index("SPIRE_350um")])
+    # a passband of the wheel that was not part of the fit, and two wavelengths, mixed
+    mix = pp.predict_flux(like, chain, ["MAMBO2_1.2mm", 433.0, 1300.0])
+    r = like._responsewheel["MAMBO2_1.2mm"]
+    orc = oracle.OracleLikelihood(np.ones(1), np.ones(1), bands=[(r.wavelength, r._sedmult, r._normfac)],
+                                  lowlim=[-np.inf] * 5, has_uplim=[0] * 6, uplim=[np.inf] * 6)
+    _, rflux = orc(chain.reshape(60, 5), nthreads=2, return_flux=True)
+    rec_allclose(mix[..., 0].reshape(60), rflux[:, 0], rtol=FLUX_RTOL, kind="band flux")
+    for j, wv in ((1, 433.0), (2, 1300.0)):
+        ref = np.array([oracle.OracleSED(*row)(np.array([wv]))[0] for row in chain.reshape(60, 5)])
+        rec_allclose(mix[..., j].reshape(60), ref, rtol=SED_RTOL, kind="f_nu")
+    rec_allclose(pp.predict_flux(like, chain, 500.0), chain[..., 4], rtol=1e-13, kind="f_nu(wavenorm) = fnorm")
+    with pytest.raises(ValueError):
+        pp.predict_flux(like, chain, "NoSuchBand_1um")
+    with pytest.raises(ValueError):
+        pp.predict_flux(like, chain, -3.0)
+
+
+def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
+    """The three ways an emcee-style sampler can call the likelihood -- row by row
+    (emcee's plain map, mbb_fit.py:80-81 with threads=1), through a pool's map with a
+    wrapper object around the callable (emcee 2.x `pool=`, what threads>1 selects), and
+    vectorised (emcee 3 `vectorize=True`) -- give the same chain, value for value, with the
+    fused kernel evaluating a whole half-step per launch in the last two.  Then
+    mbb_fitter(sampler="emcee") against stand-ins with emcee 2's and emcee 3's constructor
+    signatures (emcee itself is not installed: SURVEY.md 8c)."""
+    like = _cfg2_like(mbb, g_lnl)
+    rng = np.random.RandomState(5)
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(20, 5)))
+
+    class Wrapper(object):                      # emcee's _function_wrapper
+        def __init__(self, f):
+            self.f = f
+
+        def __call__(self, x):
+            return self.f(x)
+    chains = []
+    for kw, fn in ((dict(vectorize=False), like), (dict(vectorize=False, pool=like), Wrapper(like)),
+                   (dict(vectorize=True), like)):
+        s = mbb.EnsembleSampler(20, 5, fn, seed=3, **kw)
+        pos, lnp, _ = s.run_mcmc(p0, 12)
+        chains.append((s.chain.copy(), s.lnprobability.copy()))
+        assert np.array_equal(lnp, like(pos))
+    for c, l in chains[1:]:
+        assert np.array_equal(c, chains[0][0]) and np.array_equal(l, chains[0][1])
+    # the pool adaptor evaluates all rows of a half-step in one launch
+    calls = []
+    orig = like.context.lnlike_batch
+    monkeypatch.setattr(like.context, "lnlike_batch", lambda p, **k: calls.append(len(p) // 5 if p.ndim == 1 else p.shape[0]) or orig(p, **k))
+    mbb.EnsembleSampler(20, 5, Wrapper(like), seed=3, vectorize=False, pool=like).run_mcmc(p0, 2)
+    assert calls == [20, 10, 10, 10, 10]
+    monkeypatch.undo()
+
+    # mbb_fitter(sampler="emcee") with emcee-2 and emcee-3 shaped stand-ins
+    import sys, types
+    for version in (2, 3):
+        fake = types.ModuleType("emcee")
+
+        class FakeSampler(mbb.EnsembleSampler):
+            def __init__(self, nwalkers, dim, lnpostfn, a=2.0, args=(), kwargs=None, threads=1, pool=None, **extra):
+                if version == 2 and extra:
+                    raise TypeError("__init__() got an unexpected keyword argument %r" % list(extra)[0])
+                self.how = "vectorize" if extra.get("vectorize") else ("pool" if pool is not None else "rows")
+                mbb.EnsembleSampler.__init__(self, nwalkers, dim, lnpostfn, a=a, pool=pool,
+                                             vectorize=bool(extra.get("vectorize")), seed=17)
+        fake.EnsembleSampler = FakeSampler
+        monkeypatch.setitem(sys.modules, "emcee", fake)
+        fit = mbb.mbb_fitter(nwalkers=20, response=True, sampler="emcee", seed=4)
+        assert fit.sampler.how == ("pool" if version == 2 else "vectorize")
+        assert fit.sampler.pool is (fit.like if version == 2 else None)
+        bands = [str(b) for b in g_lnl["cfg2/bands"]]
+        fit.set_data(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
+        p = fit.generate_initial_values([12.0, 1.8, 600.0, 3.0, 40.0], [1.0, 0.1, 30.0, 0.2, 2.0])
+        fit.run(5, 10, p, verbose=False)
+        assert fit.sampler.chain.shape == (20, 10, 5) and np.all(np.isfinite(fit.sampler.lnprobability))
+        if version == 2:
+            ch2 = fit.sampler.chain.copy()
+        else:
+            assert np.array_equal(ch2, fit.sampler.chain)      # pool-mapped == vectorised
 
 
 def test_cli_config1(mbb, tmp_path):

@@ -409,3 +409,48 @@ def test_sanitizers():
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "ASAN_OK" in text and "ERROR: AddressSanitizer" not in text \
         and "runtime error" not in text, text[-3000:]
+
+
+# ------------------------------------------------- dust mass (results.py:726-801), parity unpinned
+def test_dustmass_identities():
+    """postprocess.dustmass restates results.py:746-801, which cannot be imported here
+    (astropy.units): PARITY UNPINNED.  Held instead to what the formula means, computed by
+    a different route: (1) optically thin, the mass reproduces the flux density it was
+    derived from, S = M kappa_nu B_nu(T_rest) (1+z) / D_L^2, with the Planck function written
+    with exp, cgs constants spelled out here; (2) thick / thin = tau / (1 - e^-tau) with
+    tau = (lambda0 / wavenorm)^beta, -> 1 for tau -> 0 and -> tau for large tau;
+    (3) scalings with D_L, fnorm and kappa."""
+    import mbb_emcee_amd as mbb
+    from mbb_emcee_amd import postprocess as pp
+    rng = np.random.RandomState(8)
+    chain = np.column_stack([rng.uniform(15, 60, 200), rng.uniform(1.0, 2.5, 200), rng.uniform(50, 400, 200),
+                             rng.uniform(2, 4, 200), rng.uniform(5, 80, 200)]).reshape(20, 10, 5)
+    z, dl, kappa, kw = 2.3, 18900.0, 2.64, 125.0
+    thin = mbb.likelihood(opthin=True, wavenorm=850.0)
+    thick = mbb.likelihood(opthin=False, wavenorm=850.0)
+    m_thin = pp.dustmass(thin, chain, z, dl, kappa=kappa, kappa_wave=kw)
+    m_thick = pp.dustmass(thick, chain, z, dl, kappa=kappa, kappa_wave=kw)
+    assert m_thin.shape == (20, 10)
+    # (1) implied flux density, cgs
+    h, k, c = 6.6260693e-27, 1.38065e-16, 2.99792458e10
+    nu = c / (850.0e-4 / (1 + z))                                 # rest-frame Hz
+    T = chain[..., 0] * (1 + z)
+    B = 2 * h * nu ** 3 / c ** 2 / (np.exp(h * nu / (k * T)) - 1.0)
+    kap = 10.0 * kappa * (kw / (850.0 / (1 + z))) ** chain[..., 1]        # cm^2/g at nu, kappa ~ nu^beta
+    S = m_thin * 1.97792e41 * kap * B * (1 + z) / (dl * 3.0856775814913673e24) ** 2
+    np.testing.assert_allclose(S / 1e-26, chain[..., 4], rtol=1e-12)
+    # (2) the optical-depth correction
+    tau = (chain[..., 2] / 850.0) ** chain[..., 1]
+    np.testing.assert_allclose(m_thick / m_thin, tau / (1.0 - np.exp(-tau)), rtol=1e-12)
+    small = chain.copy(); small[..., 2] = 1e-3                    # tau -> 0
+    np.testing.assert_allclose(pp.dustmass(thick, small, z, dl), pp.dustmass(thin, small, z, dl), rtol=1e-4)
+    big = chain.copy(); big[..., 2] = 850.0 * 60.0                # tau >> 1
+    tb = 60.0 ** big[..., 1]
+    np.testing.assert_allclose(pp.dustmass(thick, big, z, dl) / pp.dustmass(thin, big, z, dl), tb, rtol=1e-12)
+    # (3) scalings
+    np.testing.assert_allclose(pp.dustmass(thin, chain, z, 2 * dl), 4 * m_thin, rtol=1e-14)
+    c2 = chain.copy(); c2[..., 4] *= 3.0
+    np.testing.assert_allclose(pp.dustmass(thin, c2, z, dl), 3 * m_thin, rtol=1e-14)
+    np.testing.assert_allclose(pp.dustmass(thin, chain, z, dl, kappa=2 * kappa), m_thin / 2, rtol=1e-14)
+    with pytest.raises(ValueError):
+        pp.dustmass(thin, chain, z, dl, kappa=0.0)
