@@ -12,8 +12,9 @@ device-resident stretch-move sampler advances 250 N walkers, two DEPENDENT launc
 per step (emcee's two half-steps, mbb_fit.py:80-81 / :533), each evaluating the
 fused likelihood of its half; with N > 1 ranks the ensemble is sharded (125 moving
 walkers per GPU per launch) and the moved state rows are exchanged after every
-launch -- an in-place ncclAllGather over RCCL, or the one-hop peer-write exchange
-(--exchange ipc).  Positions live in HBM for the whole run: there is no host round
+launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
+into every rank's copy through hipIpc mappings), or by an in-place ncclAllGather over
+RCCL (--exchange rccl; also the automatic fall-back).  Positions live in HBM for the whole run: there is no host round
 trip inside the timed region.  `value` = walker-likelihood evaluations per second of
 that real chain = 250 N K / t.
 
@@ -198,8 +199,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 250 000-walker launch")
     ap.add_argument("--no-extras", action="store_true", help="timed region only (profiler passes)")
-    ap.add_argument("--exchange", choices=("rccl", "ipc"), default="rccl",
-                    help="N > 1: how the moved state rows travel after each launch")
+    ap.add_argument("--exchange", choices=("auto", "rccl", "ipc"), default="auto",
+                    help="N > 1: how the moved state rows travel after each launch (auto: the one-hop "
+                         "peer-write exchange, RCCL all-gather if that cannot be brought up)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than devices (rehearsal of the N > 1 path on one GPU; "
                          "needs --exchange ipc; the line is marked invalid for scaling)")
@@ -213,7 +215,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo announces its connections on stdout; the line printed at the end must be the
+        # only thing there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     if N != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (N, world))
 
@@ -245,7 +258,7 @@ def main():
 
     from mbb_emcee_amd import _native
     ndev = max(1, _native.load().mbb_device_count())
-    if world > ndev and not (args.oversubscribe and args.exchange == "ipc"):
+    if world > ndev and not (args.oversubscribe and args.exchange in ("ipc", "auto")):
         fail(2, error="%d ranks on %d device(s): RCCL needs one device per rank" % (world, ndev),
              collective="unavailable: %d ranks on %d device(s)" % (world, ndev), valid_for_scaling=False)
     like, flux = make_likelihood(local_rank % ndev)     # one GPU per rank on a real node
@@ -254,66 +267,87 @@ def main():
     base["config"]["nq"] = nq
     half = NW_PER_GPU // 2
 
-    # ---- N > 1: the exchange of the moved state rows --------------------------------
-    collective = "none"
-    if world > 1:
+    # ---- N > 1: the exchange of the moved state rows; then one guarded rehearsal of
+    # exactly what the timed loop does.  "auto" tries the one-hop peer-write exchange and
+    # falls back to the RCCL all-gather if it cannot be set up or its rehearsal fails on
+    # any rank.  A collective that never returns is a failure of the run, not something to
+    # time around: the line says so and the exit status is non-zero.
+    import mbb_emcee_amd as mbb
+    allw = walkers(world)
+    nwt = NW_PER_GPU * world
+    modes = [args.exchange] if args.exchange != "auto" else ["ipc", "rccl"]
+    if world > ndev:
+        modes = ["ipc"]
+    if world == 1:
+        modes = ["none"]
+    collective, tried, smp = "none", [], None
+
+    def all_ok(ok):
+        if dist is None:
+            return bool(ok)
         import torch
-        ok, why = 1, ""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag[0]) == 1
+
+    for mode in modes:
+        ok, why = True, ""
         try:
-            if args.exchange == "ipc":
+            if mode == "ipc":
                 from mbb_emcee_amd import parallel
-                parallel.ipc_exchange_setup(ctx, rank, world, dist)
-                collective = ("one-hop peer writes: each rank stores its %d moved state rows x 6 f64 into every "
-                              "peer's buffer (hipIpc mappings) and raises a per-launch flag" % half)
-            else:
+                parallel.ipc_exchange_setup(ctx, rank, world, dist, max_rows=max(4096, nwt))
+                collective = ("one-hop peer writes: the lane that accepts a move stores the state row (6 f64) "
+                              "into every rank's copy of the ensemble (hipIpc mappings, system scope) and the "
+                              "launch's last walker raises a flag in every peer; no collective library")
+            elif mode == "rccl":
                 uid = [ctx.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 ctx.comm_init(world, rank, uid[0])
                 collective = "in-place ncclAllGather of %d state rows x 6 f64 per launch (RCCL via C-ABI)" % half
         except Exception as e:
-            ok, why = 0, repr(e)
-            print("rank %d: exchange set-up failed: %s" % (rank, why), file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            fail(3, error="exchange set-up failed on some rank" + (": " + why if why else ""),
-                 collective="unavailable: %s set-up failed" % args.exchange)
+            ok, why = False, "set-up: " + repr(e)
+        if not all_ok(ok):
+            tried.append("%s %s" % (mode, why or "set-up failed on another rank"))
+            try:
+                ctx.xchg_close() if mode == "ipc" else ctx.comm_destroy()
+            except Exception:
+                pass
+            continue
+        smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
+        state = {"ok": False, "err": None}
+
+        def rehearse():
+            try:
+                smp.run_mcmc(allw[:nwt], 20, storechain=False)
+                ctx.sync()
+                state["ok"] = True
+            except Exception as e:           # noqa
+                state["err"] = repr(e)
+
+        th = threading.Thread(target=rehearse, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        if th.is_alive():
+            fail(4, error="the exchange did not return within 120 s", collective_hung=True, hang=collective)
+        if all_ok(state["ok"]):
+            break
+        tried.append("%s rehearsal: %s" % (mode, state["err"] or "failed on another rank"))
+        smp = None
+        try:
+            ctx.sync()
+            ctx.xchg_close() if mode == "ipc" else (ctx.comm_destroy() if mode == "rccl" else None)
+        except Exception:
+            pass
+    if smp is None:
+        fail(3, error="no exchange could be brought up: " + "; ".join(tried),
+             collective="unavailable: " + "; ".join(tried))
+    mode_used = mode
     base["config"]["collective"] = collective
+    if tried:
+        base["config"]["collective_fallback_from"] = tried
     if world > ndev:
         base["valid_for_scaling"] = False
         base["config"]["note"] = "%d ranks share %d device(s): a rehearsal of the exchange, not a scaling point" % (world, ndev)
-
-    import mbb_emcee_amd as mbb
-    allw = walkers(world)
-    nwt = NW_PER_GPU * world
-    smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
-
-    # One guarded rehearsal of exactly what the timed loop does.  A collective that never
-    # returns is a failure of the run, not something to time around: say so and leave.
-    state = {"ok": False, "err": None}
-
-    def rehearse():
-        try:
-            smp.run_mcmc(allw[:nwt], 20, storechain=False)
-            ctx.sync()
-            state["ok"] = True
-        except Exception as e:           # noqa
-            state["err"] = repr(e)
-
-    th = threading.Thread(target=rehearse, daemon=True)
-    th.start()
-    th.join(timeout=120.0)
-    if th.is_alive():
-        fail(4, error="the exchange did not return within 120 s", collective_hung=True,
-             hang=collective)
-    if world > 1:
-        import torch
-        flag = torch.tensor([1 if state["ok"] else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            fail(5, error="sampler rehearsal failed on some rank: %s" % state["err"])
-    elif not state["ok"]:
-        fail(5, error="sampler rehearsal failed: %s" % state["err"])
 
     # ---- the timed region: K dependent MCMC steps --------------------------------
     smp.advance_async(args.warmup)
@@ -334,13 +368,25 @@ def main():
     # the chain is still a valid one: every rank holds the same finite state
     pos_end, lnp_end, _ = smp.run_mcmc(None, 0, storechain=False)
     assert np.all(np.isfinite(lnp_end))
+    ranks_agree = True
+    if dist is not None:                    # every rank must hold the same ensemble, bit for bit
+        import torch
+        import zlib
+        h = float(zlib.crc32(np.ascontiguousarray(pos_end).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp_end).tobytes()))
+        lo, hi = torch.tensor([h], dtype=torch.float64), torch.tensor([h], dtype=torch.float64)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(lo[0] == hi[0])
+        if not ranks_agree:
+            fail(6, error="the ranks' copies of the ensemble differ after the run", collective=collective)
 
     if rank == 0:
         out = dict(base)
         out.update({"value": nwt * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
                     "mcmc_steps_per_s": args.steps / elapsed,
                     "stream_us_per_step": stream_ms * 1e3 / args.steps,
-                    "acceptance_fraction": float(np.mean(smp.naccepted)) / (20 + args.warmup + args.steps)})
+                    # (sharded: the counts of this rank's own walkers)
+                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (20 + args.warmup + args.steps),
+                    "ranks_agree": ranks_agree})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # launch slot of the dominant kernel
         kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
         out["kernel_avg_us"] = k_us
@@ -357,8 +403,11 @@ def main():
         emit(out)
     barrier()
     if world > 1:
-        if args.exchange == "rccl":
+        ctx.sync()
+        if mode_used == "rccl":
             ctx.comm_destroy()
+        elif mode_used == "ipc":
+            ctx.xchg_close()
         dist.destroy_process_group()
 
 

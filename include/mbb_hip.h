@@ -188,7 +188,7 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
- * "virtual_ranks", "debug". */
+ * "virtual_ranks", "debug", "xchg_spin_max" (polls before a launch waiting for a peer gives up). */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
 int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 
@@ -205,6 +205,22 @@ int mbb_allgather_f64(mbb_ctx *ctx, const double *d_send, double *d_recv, int co
  * of their lnprob into d_all [nranks*n]; asynchronous on the context's stream */
 int mbb_lnlike_allgather_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
                                 int32_t *d_status, double *d_all);
+
+/* ---- multi-GPU, device-resident sampler: one-hop exchange of the moved walkers ----- */
+/* Replaces: emcee's multiprocessing pool (mbb_fit.py:80-81) for the device-resident
+ * sampler, without a collective library.  Every rank keeps the whole ensemble in a
+ * fine-grained buffer that all peers map (hipIpc*): the lane that accepts a move stores
+ * the new state row into every rank's copy, and the launch's last walker raises the
+ * launch number in every peer's flag word, which the next launch's prologue waits for.
+ * Set-up: mbb_xchg_open on every rank -> exchange the 64-byte handles by any side
+ * channel -> mbb_xchg_connect on every rank -> mbb_sampler_create (the sampler then lives
+ * in the exchange buffer; nwalkers <= max_rows).  The launcher must also synchronise
+ * the ranks between mbb_sampler_set_state and the first mbb_sampler_run / advance, and
+ * before a later set_state.  In this mode mbb_sampler_run fills chain / lnprob /
+ * naccepted for this rank's walkers only (pos_out and lnprob_out are complete). */
+int mbb_xchg_open(mbb_ctx *ctx, int nranks, int rank, int max_rows, unsigned char handle[64]);
+int mbb_xchg_connect(mbb_ctx *ctx, const unsigned char *handles /* nranks x 64 */);
+int mbb_xchg_close(mbb_ctx *ctx);
 
 #ifdef __cplusplus
 }

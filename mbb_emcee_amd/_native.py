@@ -59,6 +59,9 @@ SIGNATURES = {
     "mbb_event_destroy": (C.c_int, [_vp, _vp]),
     "mbb_set_option": (C.c_int, [_vp, C.c_char_p, C.c_long]),
     "mbb_get_info": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_long)]),
+    "mbb_xchg_open": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    "mbb_xchg_connect": (C.c_int, [_vp, C.c_char_p]),
+    "mbb_xchg_close": (C.c_int, [_vp]),
     "mbb_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mbb_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p]),
     "mbb_comm_destroy": (C.c_int, [_vp]),
@@ -325,6 +328,19 @@ class Context(object):
 
     def comm_destroy(self):
         _check(self.lib.mbb_comm_destroy(self.h))
+
+    def xchg_open(self, nranks, rank, max_rows):
+        """-> this rank's 64-byte handle (to be handed to every peer)"""
+        buf = C.create_string_buffer(64)
+        _check(self.lib.mbb_xchg_open(self.h, int(nranks), int(rank), int(max_rows), buf))
+        return buf.raw
+
+    def xchg_connect(self, handles):
+        blob = b"".join(handles)
+        _check(self.lib.mbb_xchg_connect(self.h, blob))
+
+    def xchg_close(self):
+        _check(self.lib.mbb_xchg_close(self.h))
 
     def lnlike_allgather_device(self, d_pars, n, d_lnl, d_status, d_all):
         _check(self.lib.mbb_lnlike_allgather_device(

@@ -143,6 +143,22 @@ struct mbb_ctx {
     // rccl
     ncclComm_t_ comm = nullptr;
     int nranks = 1, rank = 0;
+    // one-hop exchange (mbb_xchg_*): one fine-grained allocation per rank, mapped by all peers:
+    // [flags: 16 x u64][arrival counter][state rows: xcap x 6 doubles]
+    struct Xchg {
+        int n = 0, rank = 0, connected = 0;
+        size_t cap_rows = 0;
+        unsigned char *base = nullptr;            // own allocation
+        unsigned char *peer[16] = {};             // every rank's allocation as mapped here (own = base)
+        double **d_xpos = nullptr;                // device arrays of the ranks' state rows / flag words
+        unsigned long long **d_xflag = nullptr;
+        unsigned long long seq = 0;               // launches posted so far
+        long long spin_max = 4000000;
+        static constexpr size_t kHeader = 256;
+        double *pos6(int r) const { return reinterpret_cast<double *>(peer[r] + kHeader); }
+        unsigned long long *flags(int r) const { return reinterpret_cast<unsigned long long *>(peer[r]); }
+        unsigned int *count() const { return reinterpret_cast<unsigned int *>(base + 128); }
+    } x;
 };
 
 static int use(mbb_ctx *c)
@@ -188,6 +204,7 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
 }
 
 static void free_dev(void *p) { if (p) (void)hipFree(p); }
+static int xchg_free(mbb_ctx *c);
 static void free_host(void *p) { if (p) (void)hipHostFree(p); }
 
 extern "C" void mbb_ctx_destroy(mbb_ctx *c)
@@ -196,6 +213,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->x.base) (void)xchg_free(c);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
     free_dev(c->d_poly_b); free_dev(c->d_poly_c);
     free_dev(c->d_unit_tab); free_dev(c->d_band_rng); free_dev(c->d_tail_slot);
@@ -444,6 +462,7 @@ struct SamplerLaunch {
     int s_begin, c_begin, c_count, m_count, nw, step, half, nw_src;
     double stretch_a;
     unsigned long long seed;
+    unsigned long long xseq;      // > 0: one-hop exchange, number of this launch
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -453,6 +472,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (c->data_nb != c->nb) return fail(MBB_ERR_STATE, "data not set or band count mismatch");
     if (n <= 0) return MBB_OK;
     LikeArgs a;
+    a.xpos = nullptr; a.xflag = nullptr; a.xcount = nullptr; a.xn = 1; a.xrank = 0; a.xseq = 0; a.xspin_max = 0;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
     a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
     a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
@@ -509,6 +529,10 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.m_count = sl->m_count;
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
         a.nw_src = sl->nw_src;
+        if (sl->xseq) {
+            a.xpos = c->x.d_xpos; a.xflag = c->x.d_xflag; a.xcount = c->x.count();
+            a.xn = c->x.n; a.xrank = c->x.rank; a.xseq = sl->xseq; a.xspin_max = c->x.spin_max;
+        }
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
         a.s_begin = a.c_begin = a.c_count = a.m_count = a.nw = a.step = a.half = 0;
@@ -649,6 +673,7 @@ struct mbb_sampler_state {
     int nw = 0;            // walkers per source
     int nsrc = 1;          // independent ensembles advanced together
     double *d_pos6 = nullptr;
+    bool pos6_owned = true;              // false: the rows live in the context's exchange buffer
     unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
@@ -667,7 +692,14 @@ extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long s
     s->nsrc = c->nsrc > 0 ? c->nsrc : 1;
     s->seed = seed;
     const size_t R = (size_t)s->rows();
-    HIPCHK(hipMalloc((void **)&s->d_pos6, R * 6 * sizeof(double)));
+    if (c->x.connected) {
+        // sharded with the one-hop exchange: the ensemble lives where the peers can write it
+        if (R > c->x.cap_rows) { delete s; return fail(MBB_ERR_ARG, "more walkers than the exchange buffer holds"); }
+        s->d_pos6 = c->x.pos6(c->x.rank);
+        s->pos6_owned = false;
+    } else {
+        HIPCHK(hipMalloc((void **)&s->d_pos6, R * 6 * sizeof(double)));
+    }
     HIPCHK(hipMalloc((void **)&s->d_nacc, R * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void **)&s->d_err, sizeof(int)));
     HIPCHK(hipMemset(s->d_nacc, 0, R * sizeof(unsigned int)));
@@ -683,7 +715,8 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s) return MBB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
-    free_dev(s->d_pos6); free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6);
+    if (s->pos6_owned) free_dev(s->d_pos6);
+    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6);
     delete s;
     return MBB_OK;
 }
@@ -738,20 +771,23 @@ extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, co
 // before the next half-step.  Option "virtual_ranks" runs the G
 // shards one after another on this GPU without any collective -- the same result
 // by construction, used to test the sharded launch arithmetic on one device.
-struct ShardPlan { int shards, first, last, per; bool collective; };
+struct ShardPlan { int shards, first, last, per; bool collective, xchg; };
 
 static int shard_plan(const mbb_ctx *c, const mbb_sampler_state *s, ShardPlan &p)
 {
     const int half = s->nw / 2;
-    p.collective = c->comm != nullptr && c->nranks > 1;
-    p.shards = p.collective ? c->nranks : (int)(c->opt_vranks > 1 ? c->opt_vranks : 1);
+    const bool xchg = c->x.connected && !s->pos6_owned && c->x.n > 1;
+    p.collective = xchg || (c->comm != nullptr && c->nranks > 1);
+    const int granks = xchg ? c->x.n : c->nranks, grank = xchg ? c->x.rank : c->rank;
+    p.shards = p.collective ? granks : (int)(c->opt_vranks > 1 ? c->opt_vranks : 1);
     if (p.shards > 1 && s->nsrc > 1)
         return fail(MBB_ERR_ARG, "a sharded sampler run needs a single source");
     if (half % p.shards != 0)
         return fail(MBB_ERR_ARG, "nwalkers/2 must be a multiple of the number of ranks");
     p.per = half / p.shards;
-    p.first = p.collective ? c->rank : 0;
-    p.last = p.collective ? c->rank : p.shards - 1;
+    p.first = p.collective ? grank : 0;
+    p.last = p.collective ? grank : p.shards - 1;
+    p.xchg = xchg;
     return MBB_OK;
 }
 
@@ -784,14 +820,22 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.nacc = s->d_nacc + ((size_t)r * 2 + h) * nl;
                 // the RNG key advances over the whole life of the sampler, the chain index restarts
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+                sl.xseq = p.xchg ? ++c->x.seq : 0;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
             }
-            if (p.collective &&
+            if (p.collective && !p.xchg &&
                 (rc = allgather_bytes(c, s->d_pos6 + (size_t)hb * 6, (size_t)p.per * 6 * sizeof(double))))
                 return rc;
         }
     s->steps_done += (unsigned long long)nsteps;
-    if (p.collective) {          // every rank ends up with the whole chain and all counts
+    if (p.xchg) {
+        // the stream is done only when every peer's last launch has landed here too; chain
+        // and acceptance counts stay per rank (the caller gathers them if it wants them)
+        if (c->x.seq)
+            hipLaunchKernelGGL(k_xchg_wait, dim3(1), dim3(64), 0, c->stream, c->x.flags(c->x.rank), c->x.n,
+                               c->x.rank, c->x.seq, c->x.spin_max, s->d_err);
+        HIPCHK(hipGetLastError());
+    } else if (p.collective) {   // every rank ends up with the whole chain and all counts
         if (store && (rc = allgather_bytes(c, s->d_chain6, (size_t)nsteps * 2 * nl * 6 * sizeof(double)))) return rc;
         if ((rc = allgather_bytes(c, s->d_nacc, 2 * nl * sizeof(unsigned int)))) return rc;
     }
@@ -838,6 +882,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     HIPCHK(hipStreamSynchronize(c->stream));
     if (err) {
         HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+        if (err == 8) return fail(MBB_ERR_RCCL, "the exchange timed out: a peer did not post its launch");
         g_err = "lnprob returned NaN or the SED constructor rejected a proposal (row status " +
                 std::to_string(err) + ")";
         return MBB_ERR_ARG;
@@ -847,7 +892,8 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
     }
     // launch-local order -> rows: shard r, half h, launch index w = src * per + loc
-    for (int r = 0; r < p.shards; ++r)
+    // (one-hop exchange: only this rank's shard is here; the other rows are left untouched)
+    for (int r = p.xchg ? p.first : 0; r <= (p.xchg ? p.last : p.shards - 1); ++r)
         for (int h = 0; h < 2; ++h)
             for (size_t w = 0; w < nl; ++w) {
                 const int src = (int)(w / p.per), loc = (int)(w - (size_t)src * p.per);
@@ -1184,6 +1230,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
+    else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
     else if (!strcmp(name, "roof_threads")) c->opt_roof_threads = value;
     else return fail(MBB_ERR_ARG, "unknown option");
@@ -1211,10 +1258,82 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_smem")) *value = c->last_smem;
     else if (!strcmp(name, "last_stage")) *value = c->last_stage;
     else if (!strcmp(name, "device")) *value = c->device;
-    else if (!strcmp(name, "nranks")) *value = c->nranks;
-    else if (!strcmp(name, "rank")) *value = c->rank;
+    else if (!strcmp(name, "nranks")) *value = c->x.connected ? c->x.n : c->nranks;
+    else if (!strcmp(name, "rank")) *value = c->x.connected ? c->x.rank : c->rank;
+    else if (!strcmp(name, "xchg_launches")) *value = (long)c->x.seq;
     else return fail(MBB_ERR_ARG, "unknown info key");
     return MBB_OK;
+}
+
+// ---- one-hop exchange between the ranks of a sharded sampler run ----------------
+// (the direct exchange on the xGMI mesh instead of a ring
+// collective for a 6 KB message.)  Replaces emcee's pool, mbb_fit.py:80-81.
+static int xchg_free(mbb_ctx *c)
+{
+    for (int r = 0; r < c->x.n; ++r)
+        if (r != c->x.rank && c->x.peer[r]) (void)hipIpcCloseMemHandle(c->x.peer[r]);
+    free_dev(c->x.base);
+    free_dev(c->x.d_xpos);
+    free_dev(c->x.d_xflag);
+    c->x = mbb_ctx::Xchg();
+    return MBB_OK;
+}
+
+extern "C" int mbb_xchg_open(mbb_ctx *c, int nranks, int rank, int max_rows, unsigned char handle[64])
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks || max_rows <= 0 || !handle)
+        return fail(MBB_ERR_ARG, "bad exchange layout (at most 16 ranks)");
+    if (c->x.base) return fail(MBB_ERR_STATE, "this context already has an exchange (mbb_xchg_close first)");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    const size_t bytes = mbb_ctx::Xchg::kHeader + (size_t)max_rows * 6 * sizeof(double);
+    // fine-grained: peers' system-scope stores must be visible to this device's loads while
+    // kernels run on both sides
+    HIPCHK(hipExtMallocWithFlags((void **)&c->x.base, bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipMemset(c->x.base, 0, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, c->x.base);
+    if (e != hipSuccess) { free_dev(c->x.base); c->x.base = nullptr; return fail(MBB_ERR_HIP, "hipIpcGetMemHandle", e); }
+    memcpy(handle, &h, 64);
+    c->x.n = nranks; c->x.rank = rank; c->x.cap_rows = (size_t)max_rows; c->x.connected = 0; c->x.seq = 0;
+    c->x.peer[rank] = c->x.base;
+    return MBB_OK;
+}
+
+// handles: nranks x 64 bytes, entry r as returned by rank r's mbb_xchg_open (entry `rank` is ignored).
+// Every rank must have returned from mbb_xchg_open before any calls this.
+extern "C" int mbb_xchg_connect(mbb_ctx *c, const unsigned char *handles)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (!c->x.base || !handles) return fail(MBB_ERR_STATE, "mbb_xchg_open first");
+    if (c->x.connected) return fail(MBB_ERR_STATE, "exchange already connected");
+    for (int r = 0; r < c->x.n; ++r) {
+        if (r == c->x.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * 64, 64);
+        void *p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(MBB_ERR_HIP, "hipIpcOpenMemHandle", e);
+        c->x.peer[r] = (unsigned char *)p;
+    }
+    std::vector<double *> xp(c->x.n);
+    std::vector<unsigned long long *> xf(c->x.n);
+    for (int r = 0; r < c->x.n; ++r) { xp[r] = c->x.pos6(r); xf[r] = c->x.flags(r); }
+    if ((rc = upload(&c->x.d_xpos, xp))) return rc;
+    if ((rc = upload(&c->x.d_xflag, xf))) return rc;
+    c->x.connected = 1;
+    return MBB_OK;
+}
+
+extern "C" int mbb_xchg_close(mbb_ctx *c)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return xchg_free(c);
 }
 
 // ---- RCCL -------------------------------------------------------------------

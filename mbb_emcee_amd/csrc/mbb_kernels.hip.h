@@ -78,7 +78,28 @@ struct LikeArgs {
     int nsrc, rows_per_src, nw_src;
     double stretch_a;
     unsigned long long seed;
+    // ---- one-hop exchange of the moved state rows between the ranks of a sharded run
+    // (SAMPLER only; mbb_xchg_*).  Every rank holds the whole ensemble in a fine-grained
+    // buffer its peers have mapped (hipIpc*): a walker that moves is stored into every
+    // rank's copy by the lane that accepted it, system scope; the last walker of the
+    // launch to have done so raises this launch's number in every peer's flag word, and
+    // the next launch's prologue waits for all peers' flags before it reads a row.
+    double *const *xpos;              // [xn] every rank's pos6 (entry xrank is this rank's own), or nullptr
+    unsigned long long *const *xflag; // [xn] every rank's flag array [xn]; a rank writes word [xrank] of each
+    unsigned int *xcount;             // this rank's arrival counter (walkers of the launch done)
+    int xn, xrank;
+    unsigned long long xseq;          // number of this launch (1, 2, ...): waits for xseq - 1, posts xseq
+    long long xspin_max;              // polls before a waiting launch gives up (errflag = 8)
 };
+
+__device__ __forceinline__ double ld_sys(const double *p)      // system-scope load (bypasses L1)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(double *p, double v)    // system-scope (write-through) store
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (row, 2 step + half), key = seed.
 __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, unsigned int k1)
@@ -236,11 +257,33 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 if (pj >= a.c_count) pj = a.c_count - 1;
                 const double *srow = a.pos6 + (size_t)row * 6;
                 const double *crow = a.pos6 + (size_t)(src * a.nw_src + a.c_begin + pj) * 6;
+                const bool xchg = a.xpos != nullptr;
+                if (xchg && a.xseq > 1) {
+                    // the partner rows were moved by the previous launch, on any rank: wait
+                    // until every peer has posted that launch (lane l of the wave watches
+                    // peer l's word), bounded so that a lost peer cannot hang the GPU
+                    const unsigned long long *mine = a.xflag[a.xrank];
+                    const int l = tid & 63;
+                    // (a launch that already failed -- errflag set -- is not waited for again)
+                    long long spins = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8
+                                          ? a.xspin_max : 0;
+                    for (;;) {
+                        unsigned long long v = a.xseq;
+                        if (l < a.xn && l != a.xrank)
+                            v = __hip_atomic_load(mine + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (__builtin_amdgcn_ballot_w64(v + 1 < a.xseq) == 0) break;
+                        if (++spins > a.xspin_max) { atomicMax(a.errflag, 8); break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                }
+                double srow5 = 0.0;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const double cv = crow[i], sv = srow[i];
+                    const double cv = xchg ? ld_sys(crow + i) : crow[i], sv = xchg ? ld_sys(srow + i) : srow[i];
                     p[i] = cv - zz * (cv - sv);
                 }
+                srow5 = xchg ? ld_sys(srow + 5) : srow[5];
                 double lo[4];
                 vlog<true>(lo, p[0], p[2], zz, u3);
                 lT = lo[0]; lL = lo[1];
@@ -248,7 +291,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) prop[j * 8 + i] = p[i];
                     prop[j * 8 + 5] = 4.0 * lo[2];            // (dim - 1) ln z, dim = 5
-                    prop[j * 8 + 6] = srow[5];
+                    prop[j * 8 + 6] = srow5;
                     prop[j * 8 + 7] = lo[3];                  // ln u
                 }
             } else {
@@ -506,6 +549,36 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 for (int i = 0; i < 8; ++i) q[i] = FIRST ? q_first[i] : prop[j * 8 + i];
                 if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
                 const bool accept = (q[5] + r - q[6]) > q[7];
+                if (a.xpos != nullptr) {
+                    // sharded run: the new row goes into every rank's copy of the ensemble
+                    // (a rejected move changes nothing anywhere), then this walker is counted;
+                    // the last one of the launch tells every peer that the launch is complete
+                    if (accept) {
+                        for (int pr = 0; pr < a.xn; ++pr) {
+                            double *dst = a.xpos[pr] + (size_t)row * 6;
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) st_sys(dst + i, q[i]);
+                            st_sys(dst + 5, r);
+                        }
+                        atomicAdd(&a.nacc[w], 1u);
+                    }
+                    if (a.chain6) {
+                        double *crow = a.chain6 + (size_t)w * 6;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : ld_sys(srow + i);
+                        crow[5] = accept ? r : q[6];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the rows are out
+                    const unsigned int done = __hip_atomic_fetch_add(a.xcount, 1u, __ATOMIC_ACQ_REL,
+                                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    if (done + 1 == (unsigned int)a.n) {
+                        __hip_atomic_store(a.xcount, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int pr = 0; pr < a.xn; ++pr)
+                            if (pr != a.xrank)
+                                __hip_atomic_store(a.xflag[pr] + a.xrank, a.xseq, __ATOMIC_RELEASE,
+                                                   __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                } else {
                 if (accept) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) srow[i] = q[i];
@@ -518,6 +591,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
                     crow[5] = accept ? r : q[6];
                 }
+                }
             }
             if (lnl_out) *lnl_out = r;
             if (status_out) *status_out = a.debug ? (st | ((FIRST ? pad_first : wk[j].pad) << 8)) : st;
@@ -527,6 +601,23 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (W > nwave)
         for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
     STAMP(6);
+}
+
+// Sharded run, one-hop exchange: holds the stream until every peer has posted launch
+// number `seq` (its moved rows are then all in this rank's copy of the ensemble).  One wave.
+__global__ void k_xchg_wait(const unsigned long long *mine, int xn, int xrank, unsigned long long seq,
+                            long long spin_max, int *errflag)
+{
+    const int l = threadIdx.x;
+    long long spins = 0;
+    for (;;) {
+        unsigned long long v = seq;
+        if (l < xn && l != xrank) v = __hip_atomic_load(mine + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__builtin_amdgcn_ballot_w64(v < seq) == 0) break;
+        if (++spins > spin_max) { atomicMax(errflag, 8); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // Measurement only (bench.py, roofline): the sample arithmetic of phase 2 and nothing

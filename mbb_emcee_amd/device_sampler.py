@@ -111,10 +111,16 @@ class DeviceEnsembleSampler(object):
     def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, storechain=True, **unused):
         """N stretch-move steps from pos0 [nw, 5]; returns (pos, lnprob, rstate)."""
         ctx, h = self._handle()
+        # sharded with the one-hop exchange (parallel.ipc_exchange_setup): the ranks are
+        # held together around set_state, because a peer's kernel writes into this rank's
+        # copy of the ensemble
+        barrier = getattr(ctx, "xchg_barrier", None)
         if pos0 is None:
             if self._last is None:
                 raise ValueError("Cannot have pos0=None if run_mcmc has never been called.")
         else:
+            if barrier:
+                ctx.sync(); barrier()
             p0 = np.ascontiguousarray(pos0, dtype=np.float64)
             want = (self.nsources, self.k, 5) if self.nsources > 1 else (self.k, 5)
             if p0.shape != want:
@@ -129,13 +135,16 @@ class DeviceEnsembleSampler(object):
                     ctx.h, h, _native._d(p0), _native._d(l0) if l0 is not None else None))
             except _native.NativeError as e:
                 raise ValueError(str(e))
+            if barrier:
+                barrier()
         N = int(N)
         lead = (self.nsources, self.k) if self.nsources > 1 else (self.k,)
-        chain = np.empty(lead + (N, 5)) if storechain else None
-        lnp = np.empty(lead + (N,)) if storechain else None
+        # (zeros: sharded with the one-hop exchange only this rank's walkers are filled in)
+        chain = np.zeros(lead + (N, 5)) if storechain else None
+        lnp = np.zeros(lead + (N,)) if storechain else None
         pos = np.empty(lead + (5,))
         lnprob = np.empty(lead)
-        nacc = np.empty(lead)
+        nacc = np.zeros(lead)
         rc = ctx.lib.mbb_sampler_run(ctx.h, h, N, self.a,
                                      _native._d(chain) if storechain else None,
                                      _native._d(lnp) if storechain else None,

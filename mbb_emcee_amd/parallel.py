@@ -18,7 +18,7 @@ Communicators:
 """
 import numpy as np
 
-__all__ = ["block_bounds", "RcclComm", "ShardedLikelihood"]
+__all__ = ["block_bounds", "RcclComm", "ShardedLikelihood", "ipc_exchange_setup"]
 
 
 def block_bounds(n, world):
@@ -95,3 +95,28 @@ class ShardedLikelihood(object):
         for r, (a, b) in enumerate(bounds):
             out[a:b] = full[r * per:r * per + (b - a)]
         return out
+
+
+def ipc_exchange_setup(ctx, rank, world, side_channel, max_rows=4096):
+    """Bring up the one-hop exchange of the device-resident sampler (include/mbb_hip.h,
+    mbb_xchg_*) on this rank's context: every rank keeps the whole ensemble in a buffer
+    its peers map through hipIpc and the kernel itself stores a moved walker into every
+    copy -- no collective library, one xGMI hop per moved row.
+
+    side_channel: how the 64-byte handles travel and how the ranks are held together
+    between host-side steps.  Either a torch.distributed-like module (``all_gather_object``
+    + ``barrier``; the launcher's gloo group) or any object with
+    ``allgather_bytes(b) -> [b_0, ..., b_{world-1}]`` and ``barrier()``.
+    Afterwards ``DeviceEnsembleSampler(nwalkers <= max_rows, ...)`` on this context runs
+    sharded; its ``barrier`` hook is set from the side channel."""
+    handle = ctx.xchg_open(world, rank, max_rows)
+    if hasattr(side_channel, "allgather_bytes"):
+        handles = side_channel.allgather_bytes(handle)
+    else:
+        handles = [None] * world
+        side_channel.all_gather_object(handles, handle)
+    side_channel.barrier()                 # every rank has its buffer before anyone maps it
+    ctx.xchg_connect([bytes(h) for h in handles])
+    side_channel.barrier()
+    ctx.xchg_barrier = side_channel.barrier
+    return ctx

@@ -1,0 +1,78 @@
+"""Worker of the two-process test of the one-hop exchange (tests/test_gpu_parity.py::
+test_one_hop_exchange_two_processes_one_gpu): both processes run on the SAME GPU (IPC
+mappings work within a device), each moves its share of every half-ensemble and stores
+the moved rows into the other's copy; chain, final state and acceptance counts must be
+bitwise those of the unsharded device sampler."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import mbb_emcee_amd as mbb
+    from mbb_emcee_amd import parallel
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lnlike.npz"))
+    bands = [str(b) for b in g["cfg2/bands"]]
+
+    def make():
+        like = mbb.likelihood(response=True, device=0)
+        like.set_phot(bands, g["cfg2/thick_walpha/flux"], g["cfg2/thick_walpha/unc"])
+        return like
+    nw, nsteps = 48, 12
+    rng = np.random.RandomState(3)                     # the same on every rank
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(nw, 5)))
+    # the unsharded run, on a context of its own
+    ref_like = make()
+    ref = mbb.DeviceEnsembleSampler(nw, 5, ref_like, seed=21)
+    rpos, rlnp, _ = ref.run_mcmc(p0, nsteps)
+    rchain, rlnpc, racc = ref.chain.copy(), ref.lnprobability.copy(), ref.naccepted.copy()
+    rpos2, rlnp2, _ = ref.run_mcmc(None, 5)
+    # the sharded run
+    like = make()
+    ctx = like._sync_device()
+    parallel.ipc_exchange_setup(ctx, rank, world, dist, max_rows=256)
+    assert ctx.info("nranks") == world and ctx.info("rank") == rank
+    smp = mbb.DeviceEnsembleSampler(nw, 5, like, seed=21)
+    pos, lnp, _ = smp.run_mcmc(p0, nsteps)
+    half, per = nw // 2, nw // 2 // world
+    mine = np.r_[rank * per:(rank + 1) * per, half + rank * per:half + (rank + 1) * per]
+    assert np.array_equal(pos, rpos) and np.array_equal(lnp, rlnp), "final state differs on rank %d" % rank
+    assert np.array_equal(smp.chain[mine], rchain[mine]), "chain differs on rank %d" % rank
+    assert np.array_equal(smp.lnprobability[mine], rlnpc[mine])
+    assert np.array_equal(smp.naccepted[mine], racc[mine])
+    others = np.setdiff1d(np.arange(nw), mine)
+    assert not smp.chain[others].any()                 # left untouched for the caller to gather
+    assert ctx.info("xchg_launches") == 2 * nsteps
+    # continuing the chain, and the asynchronous form the benchmark uses
+    pos2, lnp2, _ = smp.run_mcmc(None, 5)
+    assert np.array_equal(pos2, rpos2) and np.array_equal(lnp2, rlnp2)
+    dist.barrier()
+    smp.advance_async(40)
+    ctx.sync()
+    ref.advance_async(40)
+    ref_like.context.sync()
+    a, la, _ = smp.run_mcmc(None, 0)
+    b, lb, _ = ref.run_mcmc(None, 0)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+    # the whole chain, gathered by the caller over the side channel
+    full = smp.chain.copy()
+    import torch
+    t = torch.from_numpy(full)
+    dist.all_reduce(t)                                 # disjoint rows, zeros elsewhere: the sum is the gather
+    assert np.array_equal(t.numpy()[:, :nsteps], rchain)
+    dist.barrier()
+    ctx.xchg_close()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("XCHG_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -1180,3 +1180,22 @@ def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
     s.run_mcmc(p0, 12)
     assert np.array_equal(s.chain, ref.chain[:, :12])
     ctx.comm_destroy()
+
+
+def test_one_hop_exchange_two_processes_one_gpu():
+    """The sharded device sampler with the one-hop peer-write exchange (mbb_xchg_*): two
+    processes on this one GPU map each other's copy of the ensemble through hipIpc, each
+    moves its block of every half-ensemble and stores the moved rows into both copies;
+    chains, final state and counts are bitwise those of the unsharded run
+    (tests/_xchg_worker.py).  On a multi-GPU node the same protocol crosses xGMI instead of
+    staying inside one device; that part cannot be exercised on a one-GPU box."""
+    import os, subprocess, sys, socket
+    from conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "_xchg_worker.py")]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "XCHG_OK" in text, text[-4000:]
