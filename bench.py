@@ -480,10 +480,10 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
              "probe_seconds": sec, "probe_shader_clock_mhz": roof_mhz, "samples_per_launch": half * nq, "lane_slots_per_launch": slots_per_launch}
 
     # ---- rooflines of the dominant kernel (the sampler's 125-walker launch)
-    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", "k_lnlike<false, false, true, true>")
+    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", "k_lnlike<false, false, 1, true>")
     roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
     alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-    traffic, traffic_src = measured_traffic("k_lnlike<false, false, true, true>")
+    traffic, traffic_src = measured_traffic("k_lnlike<false, false, 1, true>")
     hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
            "traffic_ratio": (traffic / alg_bytes) if traffic else None, "traffic_source": traffic_src,
@@ -525,7 +525,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
         smp5.advance_async(20); c5.sync()
         t5 = (time.perf_counter() - t5) / 20
         sec5, slots5, mhz5 = c5.roof_probe(TRUTH, reps=200)
-        pm5, pm5_src = measured_valu("pmc_valu_cfg5*.json", "k_lnlike<false, false, false, false>")
+        pm5, pm5_src = measured_valu("pmc_valu_cfg5*.json", "k_lnlike<false, false, 0, false>")
         r5 = valu_roofline(pm5, pm5_src, ms5 * 1e-3, "k_lnlike<thick,alpha,plain> n=250000")
         cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
                 "evals_per_launch": n5, "kernel_ms": ms5, "evals_per_s": n5 / ms5 * 1e3,

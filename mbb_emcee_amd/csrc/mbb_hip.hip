@@ -137,7 +137,7 @@ struct mbb_ctx {
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
-    size_t lds_granted[16] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[24] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -150,8 +150,7 @@ struct mbb_ctx {
         size_t cap_rows = 0;
         unsigned char *base = nullptr;            // own allocation
         unsigned char *peer[16] = {};             // every rank's allocation as mapped here (own = base)
-        double **d_xpos = nullptr;                // device arrays of the ranks' state rows / flag words
-        unsigned long long **d_xflag = nullptr;
+        XchgArgs *d_args = nullptr;               // the kernel's view (device memory)
         unsigned long long seq = 0;               // launches posted so far
         long long spin_max = 4000000;
         static constexpr size_t kHeader = 256;
@@ -472,7 +471,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (c->data_nb != c->nb) return fail(MBB_ERR_STATE, "data not set or band count mismatch");
     if (n <= 0) return MBB_OK;
     LikeArgs a;
-    a.xpos = nullptr; a.xflag = nullptr; a.xcount = nullptr; a.xn = 1; a.xrank = 0; a.xseq = 0; a.xspin_max = 0;
+    a.xargs = nullptr;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
     a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
     a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
@@ -529,27 +528,23 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.m_count = sl->m_count;
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
         a.nw_src = sl->nw_src;
-        if (sl->xseq) {
-            a.xpos = c->x.d_xpos; a.xflag = c->x.d_xflag; a.xcount = c->x.count();
-            a.xn = c->x.n; a.xrank = c->x.rank; a.xseq = sl->xseq; a.xspin_max = c->x.spin_max;
-        }
+        if (sl->xseq) a.xargs = c->x.d_args;
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
         a.s_begin = a.c_begin = a.c_count = a.m_count = a.nw = a.step = a.half = 0;
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
-        const int vi = (c->opthin ? 8 : 0) | (c->noalpha ? 4 : 0) | (sl ? 2 : 0) | (stage ? 1 : 0);
+        const int smode = !sl ? 0 : (sl->xseq ? 2 : 1);
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 6 + smode * 2 + (stage ? 1 : 0);
         vi_of_kernel = vi;
-        static void (*const table[16])(const LikeArgs) = {
-            k_lnlike<false, false, false, false>, k_lnlike<false, false, false, true>,
-            k_lnlike<false, false, true, false>,  k_lnlike<false, false, true, true>,
-            k_lnlike<false, true, false, false>,  k_lnlike<false, true, false, true>,
-            k_lnlike<false, true, true, false>,   k_lnlike<false, true, true, true>,
-            k_lnlike<true, false, false, false>,  k_lnlike<true, false, false, true>,
-            k_lnlike<true, false, true, false>,   k_lnlike<true, false, true, true>,
-            k_lnlike<true, true, false, false>,   k_lnlike<true, true, false, true>,
-            k_lnlike<true, true, true, false>,    k_lnlike<true, true, true, true>};
+#define MBB_VARIANTS(OT, NA)                                                                        \
+    k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
+        k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>
+        static void (*const table[24])(const LikeArgs) = {
+            MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
+            MBB_VARIANTS(true, true)};
+#undef MBB_VARIANTS
         kern = table[vi];
     }
     if (static_lds(c) + smem_total > 60 * 1024) {
@@ -807,6 +802,16 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     if (rc) return rc;
     const int nw = s->nw, half = nw / 2;
     const size_t nl = (size_t)s->nsrc * p.per;              // walkers per launch
+    if (p.xchg) {
+        // the kernel's view of the exchange for this run, in stream order before its launches
+        // (pageable source: staged by the runtime before the call returns)
+        XchgArgs xa;
+        memset(&xa, 0, sizeof xa);
+        for (int r = 0; r < c->x.n; ++r) { xa.xpos[r] = c->x.pos6(r); xa.xflag[r] = c->x.flags(r); }
+        xa.xcount = c->x.count(); xa.xn = c->x.n; xa.xrank = c->x.rank;
+        xa.xseq0 = c->x.seq; xa.xspin_max = c->x.spin_max;
+        HIPCHK(hipMemcpyAsync(c->x.d_args, &xa, sizeof xa, hipMemcpyHostToDevice, c->stream));
+    }
     SamplerLaunch sl;
     sl.pos6 = s->d_pos6; sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw;
     sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
@@ -1273,8 +1278,7 @@ static int xchg_free(mbb_ctx *c)
     for (int r = 0; r < c->x.n; ++r)
         if (r != c->x.rank && c->x.peer[r]) (void)hipIpcCloseMemHandle(c->x.peer[r]);
     free_dev(c->x.base);
-    free_dev(c->x.d_xpos);
-    free_dev(c->x.d_xflag);
+    free_dev(c->x.d_args);
     c->x = mbb_ctx::Xchg();
     return MBB_OK;
 }
@@ -1319,11 +1323,7 @@ extern "C" int mbb_xchg_connect(mbb_ctx *c, const unsigned char *handles)
         if (e != hipSuccess) return fail(MBB_ERR_HIP, "hipIpcOpenMemHandle", e);
         c->x.peer[r] = (unsigned char *)p;
     }
-    std::vector<double *> xp(c->x.n);
-    std::vector<unsigned long long *> xf(c->x.n);
-    for (int r = 0; r < c->x.n; ++r) { xp[r] = c->x.pos6(r); xf[r] = c->x.flags(r); }
-    if ((rc = upload(&c->x.d_xpos, xp))) return rc;
-    if ((rc = upload(&c->x.d_xflag, xf))) return rc;
+    HIPCHK(hipMalloc((void **)&c->x.d_args, sizeof(XchgArgs)));
     c->x.connected = 1;
     return MBB_OK;
 }

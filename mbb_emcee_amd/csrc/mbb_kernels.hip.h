@@ -22,6 +22,22 @@ constexpr int kPolyCDoubles = (40 * 8 + 1) * 8;      // mbbh::kPolyCCount
 // ---------------------------------------------------------------------------
 // kernel arguments
 // ---------------------------------------------------------------------------
+// One-hop exchange of the moved state rows between the ranks of a sharded run.  Every rank
+// holds the whole ensemble in a fine-grained buffer its peers have mapped (hipIpc*): a
+// walker that moves is stored into every rank's copy by the lane that accepted it, system
+// scope; the last walker of the launch to have done so raises this launch's number in
+// every peer's flag word, and the next launch's prologue waits for all peers' flags
+// before it reads a row.  Lives in device memory, written once per enqueued run.
+struct XchgArgs {
+    double *xpos[16];               // every rank's pos6 (entry xrank is this rank's own)
+    unsigned long long *xflag[16];  // every rank's flag array [xn]; a rank writes word [xrank] of each
+    unsigned int *xcount;           // this rank's arrival counter (walkers of the launch done)
+    int xn, xrank;
+    unsigned long long xseq0;       // launches posted before this run: launch (step, half) is
+                                    // number xseq0 + 2 step + half + 1, waits for the one before
+    long long xspin_max;            // polls before a waiting launch gives up (errflag = 8)
+};
+
 struct LikeArgs {
     // passband tables, chunk-padded: band b owns chunks; every chunk is 64 samples
     const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
@@ -78,18 +94,11 @@ struct LikeArgs {
     int nsrc, rows_per_src, nw_src;
     double stretch_a;
     unsigned long long seed;
-    // ---- one-hop exchange of the moved state rows between the ranks of a sharded run
-    // (SAMPLER only; mbb_xchg_*).  Every rank holds the whole ensemble in a fine-grained
-    // buffer its peers have mapped (hipIpc*): a walker that moves is stored into every
-    // rank's copy by the lane that accepted it, system scope; the last walker of the
-    // launch to have done so raises this launch's number in every peer's flag word, and
-    // the next launch's prologue waits for all peers' flags before it reads a row.
-    double *const *xpos;              // [xn] every rank's pos6 (entry xrank is this rank's own), or nullptr
-    unsigned long long *const *xflag; // [xn] every rank's flag array [xn]; a rank writes word [xrank] of each
-    unsigned int *xcount;             // this rank's arrival counter (walkers of the launch done)
-    int xn, xrank;
-    unsigned long long xseq;          // number of this launch (1, 2, ...): waits for xseq - 1, posts xseq
-    long long xspin_max;              // polls before a waiting launch gives up (errflag = 8)
+    // ---- one-hop exchange between the ranks of a sharded run (SMODE 2 only; mbb_xchg_*):
+    // kept out of the argument block -- every launch of every variant pays for the size of
+    // that block (48 bytes more, crossing 512, cost the single-GPU sampler 2.7 % per step:
+    // tools/lat_kernarg.hip, profiles/r02/lat_kernarg.txt)
+    const XchgArgs *xargs;
 };
 
 __device__ __forceinline__ double ld_sys(const double *p)      // system-scope load (bypasses L1)
@@ -125,9 +134,14 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 //   phase 3: band sums in fixed order, then one lane per walker forms lnL
 // Summation order depends only on the band tables, never on the batch, so a
 // walker's result is bitwise independent of which launch / GPU evaluates it.
-template <bool OPTHIN, bool NOALPHA, bool SAMPLER, bool STAGE>
+// SMODE: 0 the likelihood of given rows; 1 the stretch-move half-step; 2 the half-step of a
+// sharded run with the one-hop exchange (its own instantiation: carried as run-time
+// branches and extra arguments in the single-GPU sampler kernel it cost that kernel 0.75 us
+// per launch).
+template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
+    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
     __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
@@ -257,25 +271,29 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 if (pj >= a.c_count) pj = a.c_count - 1;
                 const double *srow = a.pos6 + (size_t)row * 6;
                 const double *crow = a.pos6 + (size_t)(src * a.nw_src + a.c_begin + pj) * 6;
-                const bool xchg = a.xpos != nullptr;
-                if (xchg && a.xseq > 1) {
-                    // the partner rows were moved by the previous launch, on any rank: wait
-                    // until every peer has posted that launch (lane l of the wave watches
-                    // peer l's word), bounded so that a lost peer cannot hang the GPU
-                    const unsigned long long *mine = a.xflag[a.xrank];
-                    const int l = tid & 63;
-                    // (a launch that already failed -- errflag set -- is not waited for again)
-                    long long spins = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8
-                                          ? a.xspin_max : 0;
-                    for (;;) {
-                        unsigned long long v = a.xseq;
-                        if (l < a.xn && l != a.xrank)
-                            v = __hip_atomic_load(mine + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (__builtin_amdgcn_ballot_w64(v + 1 < a.xseq) == 0) break;
-                        if (++spins > a.xspin_max) { atomicMax(a.errflag, 8); break; }
-                        __builtin_amdgcn_s_sleep(8);
+                constexpr bool xchg = XCHG;
+                if (xchg) {
+                    const XchgArgs &x = *a.xargs;
+                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)a.step + (unsigned)a.half + 1ull;
+                    if (xseq > 1) {
+                        // the partner rows were moved by the previous launch, on any rank: wait
+                        // until every peer has posted that launch (lane l of the wave watches
+                        // peer l's word), bounded so that a lost peer cannot hang the GPU
+                        // (a launch that already failed -- errflag set -- is not waited for again)
+                        const unsigned long long *mine = x.xflag[x.xrank];
+                        const int l = tid & 63;
+                        long long spins = __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8
+                                              ? x.xspin_max : 0;
+                        for (;;) {
+                            unsigned long long v = xseq;
+                            if (l < x.xn && l != x.xrank)
+                                v = __hip_atomic_load(mine + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            if (__builtin_amdgcn_ballot_w64(v + 1 < xseq) == 0) break;
+                            if (++spins > x.xspin_max) { atomicMax(a.errflag, 8); break; }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
                 }
                 double srow5 = 0.0;
 #pragma unroll
@@ -453,9 +471,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *lnl_first = nullptr;
     int32_t *status_first = nullptr;
     double q_first[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // SAMPLER: the proposal record
+    int row_first = 0;                                               // SAMPLER: the walker's state row
     if (SAMPLER && wave < W) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) q_first[i] = prop[wave * 8 + i];
+        const int wf = w0 + wave, srcf = wf / a.m_count;
+        row_first = srcf * a.nw_src + a.s_begin + (wf - srcf * a.m_count);
     }
     if (wave < W) {
         st_first = wk[wave].status;
@@ -541,21 +562,23 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             int32_t *status_out = FIRST ? status_first : (a.status ? a.status + w : nullptr);
             if (SAMPLER) {
                 // accept with probability min(1, z^(dim-1) P(q)/P(s))
-                const int src = w / a.m_count;
-                const int row = src * a.nw_src + a.s_begin + (w - src * a.m_count);
+                int row = row_first;
+                if (!FIRST) { const int src = w / a.m_count; row = src * a.nw_src + a.s_begin + (w - src * a.m_count); }
                 double *srow = a.pos6 + (size_t)row * 6;
                 double q[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) q[i] = FIRST ? q_first[i] : prop[j * 8 + i];
                 if (st >= 2 || r != r) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
                 const bool accept = (q[5] + r - q[6]) > q[7];
-                if (a.xpos != nullptr) {
+                if (XCHG) {
                     // sharded run: the new row goes into every rank's copy of the ensemble
                     // (a rejected move changes nothing anywhere), then this walker is counted;
                     // the last one of the launch tells every peer that the launch is complete
+                    const XchgArgs &x = *a.xargs;
+                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)a.step + (unsigned)a.half + 1ull;
                     if (accept) {
-                        for (int pr = 0; pr < a.xn; ++pr) {
-                            double *dst = a.xpos[pr] + (size_t)row * 6;
+                        for (int pr = 0; pr < x.xn; ++pr) {
+                            double *dst = x.xpos[pr] + (size_t)row * 6;
 #pragma unroll
                             for (int i = 0; i < 5; ++i) st_sys(dst + i, q[i]);
                             st_sys(dst + 5, r);
@@ -569,13 +592,13 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         crow[5] = accept ? r : q[6];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the rows are out
-                    const unsigned int done = __hip_atomic_fetch_add(a.xcount, 1u, __ATOMIC_ACQ_REL,
+                    const unsigned int done = __hip_atomic_fetch_add(x.xcount, 1u, __ATOMIC_ACQ_REL,
                                                                      __HIP_MEMORY_SCOPE_AGENT);
                     if (done + 1 == (unsigned int)a.n) {
-                        __hip_atomic_store(a.xcount, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (int pr = 0; pr < a.xn; ++pr)
-                            if (pr != a.xrank)
-                                __hip_atomic_store(a.xflag[pr] + a.xrank, a.xseq, __ATOMIC_RELEASE,
+                        __hip_atomic_store(x.xcount, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int pr = 0; pr < x.xn; ++pr)
+                            if (pr != x.xrank)
+                                __hip_atomic_store(x.xflag[pr] + x.xrank, xseq, __ATOMIC_RELEASE,
                                                    __HIP_MEMORY_SCOPE_SYSTEM);
                     }
                 } else {

@@ -16,9 +16,17 @@ from mbb_emcee_amd import _native
 import mbb_emcee_amd as mbb
 
 
+_ALL_SIGNATURES = dict(_native.SIGNATURES)
+
+
 def build_side(libpath):
     _native._lib = None
     _native.LIB_PATH = os.path.abspath(libpath)
+    # an older build may lack entry points added since: bind what it has
+    import ctypes
+    probe = ctypes.CDLL(_native.LIB_PATH)
+    _native.SIGNATURES.clear()
+    _native.SIGNATURES.update({k: v for k, v in _ALL_SIGNATURES.items() if hasattr(probe, k)})
     from bench import make_likelihood, walkers, NW_PER_GPU
     from tools.bench_cfg5 import setup
     like, flux = make_likelihood(0)
