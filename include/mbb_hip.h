@@ -188,7 +188,9 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
- * "virtual_ranks", "debug", "xchg_spin_max" (polls before a launch waiting for a peer gives up). */
+ * "virtual_ranks", "debug", "persistent_sampler" (1: a single-GPU sampler run of up to one
+ * walker per CU is ONE launch, its half-steps handing over inside the kernel -- same chains,
+ * measured slower than the default 0, one launch per half-step), "xchg_spin_max" (polls before a launch waiting for a peer gives up). */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
 int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 

@@ -246,7 +246,7 @@ __device__ inline float thick_merge_root_f32(float alpha, float beta, float lx0,
 template <bool ROW, bool PB>
 __device__ inline double thick_merge_root(double alpha, double beta, double lx0, int &status,
                                           double &xroot, double &yroot, double (&pb)[4],
-                                          int *iters = nullptr)
+                                          int *iters = nullptr, double *kappa = nullptr)
 {
     const double xlo = 2.0 + alpha, xhi = 3.0 + alpha + beta;
     const float kLn2 = 0.693147180559945309f;
@@ -258,17 +258,22 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
     PSTAMP(11, u);
     status = ROW_NOCONV;
     xroot = 0.0; yroot = 0.0;
+    if (PB && kappa) *kappa = __builtin_nan("");
     for (int it = 0; it < 80; ++it) {
         double x, y, em, E;
+        double k0 = 0.0;                  // PB: kappa at this evaluation point
         if (PB && it == 0) {
-            double o1[5];
-            vexp<ROW, 0x08u>(o1, u, beta * (u - lx0), pb[0], pb[1], pb[2]);
+            // kappa = x^(3+alpha) (1 - e^-y) / expm1(x) (modified_blackbody.py:326-328) needs
+            // three more exps of the same x and y: they ride in this evaluation's two rounds
+            double o1[6];
+            vexp<ROW, 0x08u>(o1, u, beta * (u - lx0), pb[0], pb[1], pb[2], (3.0 + alpha) * u);
             x = o1[0]; y = o1[1]; pb[0] = o1[2]; pb[1] = o1[3]; pb[2] = o1[4];
             PSTAMP(12, x + y + pb[0] + pb[1] + pb[2]);
-            double o2[3];
-            vexp<ROW, 0x06u>(o2, -x, y, -pb[0]);
+            double o2[5];
+            vexp<ROW, 0x1Eu>(o2, -x, y, -pb[0], -y, x);
             em = o2[0]; E = o2[1]; pb[3] = o2[2];
             PSTAMP(13, em + E + pb[3]);
+            k0 = m_div(o1[5] * -o2[3], o2[4]);
         } else {
             double o1[2];
             vexp<ROW, 0x00u>(o1, u, beta * (u - lx0));
@@ -284,7 +289,7 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
         const double g = x - om * A;
         const double dg = x * (1.0 - em * A) - om * beta * beta * dh * y;
         if (iters) *iters = it + 1;
-        if (g == 0.0) { xroot = x; yroot = y; status = ROW_OK; break; }
+        if (g == 0.0) { xroot = x; yroot = y; status = ROW_OK; if (PB && kappa && it == 0) *kappa = k0; break; }
         if (g < 0.0) ulo = u; else uhi = u;
         const double step = m_div(-g, dg);          // dg > 0 around the root
         if (fabs(step) <= 1e-6) {
@@ -294,6 +299,11 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
             const double bs = beta * step;
             yroot = y * (1.0 + bs * (1.0 + bs * (0.5 + bs * (1.0 / 6.0))));
             status = ROW_OK;
+            // kappa is stationary at the root: d ln kappa / du = s(u) = A - x/(1 - e^-x) =
+            // -g/(1 - e^-x), zero there (it IS the merge condition), so over the step
+            // ln kappa changes by s step + s' step^2/2 = s step/2 (s = -s' step to first
+            // order): kappa(root) = kappa(u) (1 + s step / 2), error O(step^3) < 1e-18
+            if (PB && kappa && it == 0) *kappa = k0 * (1.0 - 0.5 * step * m_div(g, om));
             break;
         }
         double un = u + step;
@@ -385,15 +395,20 @@ __device__ inline int sed_prologue(double T, double beta, double alpha, double f
         } else {
             double xm, ym;
             double pb[4] = {beta * (lxnorm - lx0), xnorm, alpha * lxnorm, 0.0};
-            const double um = thick_merge_root<ROW, true>(alpha, beta, lx0, status, xm, ym, pb, iters); // :286-322
+            double kfast;
+            const double um = thick_merge_root<ROW, true>(alpha, beta, lx0, status, xm, ym, pb, iters, &kfast); // :286-322
             PSTAMP(14, um + xm + ym);
             const double bbnorm = m_div(fnorm * pb[1], -pb[3] * (xnorm * xnorm * xnorm));
             s.xmerge = xm;
             // -xm^(3+alpha) expm1(-(xm/x0)^beta) / expm1(xm)          :326-328
-            double o3[3];
-            vexp<ROW, 0x06u>(o3, (3.0 + alpha) * um, -ym, xm);
-            PSTAMP(15, o3[0] + o3[1] + o3[2]);
-            s.kappa = m_div(o3[0] * -o3[1], o3[2]);
+            if (kfast == kfast) {
+                s.kappa = kfast;         // the usual case: one evaluation, kappa came with it
+            } else {
+                double o3[3];
+                vexp<ROW, 0x06u>(o3, (3.0 + alpha) * um, -ym, xm);
+                s.kappa = m_div(o3[0] * -o3[1], o3[2]);
+            }
+            PSTAMP(15, s.kappa);
             if (xnorm > xm)                                         // :331-333
                 s.normfac = m_div(fnorm * pb[2], s.kappa);
             else

@@ -128,6 +128,7 @@ struct mbb_ctx {
     long opt_wpb = 0, opt_threads = 0, opt_seg_chunks = 4, opt_debug = 0;
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
+    long opt_persist = 0;     // 1: single-GPU sampler runs are ONE launch (measured slower: see k_lnlike, SMODE 3)
     long opt_roof_wgs = 0, opt_roof_threads = 0;   // measurement: geometry of mbb_roof_probe
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
     long opt_bar_params = 1;  // host path: write the parameter rows into device memory through the BAR
@@ -137,7 +138,7 @@ struct mbb_ctx {
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
-    size_t lds_granted[24] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[32] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -462,6 +463,8 @@ struct SamplerLaunch {
     double stretch_a;
     unsigned long long seed;
     unsigned long long xseq;      // > 0: one-hop exchange, number of this launch
+    int persist;                  // > 0: this many half-steps in one launch (k_lnlike SMODE 3)
+    unsigned int *gbar;           // its arrival counters
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -472,6 +475,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.xargs = nullptr;
+    a.persist = 0; a.gbar = nullptr;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
     a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
     a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
@@ -529,19 +533,21 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
         a.nw_src = sl->nw_src;
         if (sl->xseq) a.xargs = c->x.d_args;
+        a.persist = sl->persist; a.gbar = sl->gbar;
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
         a.s_begin = a.c_begin = a.c_count = a.m_count = a.nw = a.step = a.half = 0;
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
-        const int smode = !sl ? 0 : (sl->xseq ? 2 : 1);
-        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 6 + smode * 2 + (stage ? 1 : 0);
+        const int smode = !sl ? 0 : (sl->persist ? 3 : (sl->xseq ? 2 : 1));
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 8 + smode * 2 + (stage ? 1 : 0);
         vi_of_kernel = vi;
 #define MBB_VARIANTS(OT, NA)                                                                        \
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
-        k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>
-        static void (*const table[24])(const LikeArgs) = {
+        k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>,           \
+        k_lnlike<OT, NA, 3, false>, k_lnlike<OT, NA, 3, true>
+        static void (*const table[32])(const LikeArgs) = {
             MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
             MBB_VARIANTS(true, true)};
 #undef MBB_VARIANTS
@@ -671,6 +677,7 @@ struct mbb_sampler_state {
     bool pos6_owned = true;              // false: the rows live in the context's exchange buffer
     unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
+    unsigned int *d_gbar = nullptr;      // arrival counters of the one-launch run (8 x 128 bytes)
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
@@ -697,6 +704,7 @@ extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long s
     }
     HIPCHK(hipMalloc((void **)&s->d_nacc, R * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void **)&s->d_err, sizeof(int)));
+    HIPCHK(hipMalloc((void **)&s->d_gbar, 1024));
     HIPCHK(hipMemset(s->d_nacc, 0, R * sizeof(unsigned int)));
     HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
     *out = s;
@@ -711,7 +719,7 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     if (!s) return MBB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s->pos6_owned) free_dev(s->d_pos6);
-    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6);
+    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar);
     delete s;
     return MBB_OK;
 }
@@ -815,6 +823,27 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     SamplerLaunch sl;
     sl.pos6 = s->d_pos6; sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw;
     sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
+    sl.xseq = 0; sl.persist = 0; sl.gbar = nullptr;
+    // Option "persistent_sampler" 1 -- one GPU, one ensemble, at most one walker per CU: the
+    // whole run in ONE launch per 4096 steps (k_lnlike SMODE 3: every workgroup is resident,
+    // the half-steps hand over inside the kernel).  Off by default: measured slower.
+    int wpb_1 = 0, thr_1 = 0;
+    pick_geometry(c, (int)nl, wpb_1, thr_1);
+    if (c->opt_persist && p.shards == 1 && !p.collective && s->nsrc == 1 && (int)nl <= c->cu_count && nsteps > 0 &&
+        wpb_1 == 1) {
+        for (int t0 = 0; t0 < nsteps; t0 += 4096) {
+            const int nt = std::min(4096, nsteps - t0);
+            HIPCHK(hipMemsetAsync(s->d_gbar, 0, 1024, c->stream));
+            sl.s_begin = 0; sl.c_begin = half; sl.step = t0; sl.half = 0;
+            sl.persist = 2 * nt; sl.gbar = s->d_gbar;
+            sl.chain6 = store ? s->d_chain6 + ((size_t)t0 * 2 * nl) * 6 : nullptr;
+            sl.nacc = s->d_nacc;
+            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
+            if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+        }
+        s->steps_done += (unsigned long long)nsteps;
+        return MBB_OK;
+    }
     for (int t = 0; t < nsteps; ++t)
         for (int h = 0; h < 2; ++h) {
             const int hb = h ? half : 0;
@@ -888,6 +917,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     if (err) {
         HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
         if (err == 8) return fail(MBB_ERR_RCCL, "the exchange timed out: a peer did not post its launch");
+        if (err == 9) return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step");
         g_err = "lnprob returned NaN or the SED constructor rejected a proposal (row status " +
                 std::to_string(err) + ")";
         return MBB_ERR_ARG;
@@ -1236,6 +1266,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
+    else if (!strcmp(name, "persistent_sampler")) c->opt_persist = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
     else if (!strcmp(name, "roof_threads")) c->opt_roof_threads = value;
     else return fail(MBB_ERR_ARG, "unknown option");

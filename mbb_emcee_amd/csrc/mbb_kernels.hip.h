@@ -88,6 +88,8 @@ struct LikeArgs {
     int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
     int s_begin, c_begin, c_count, m_count, nw;
     int step, half;
+    int persist;              // SMODE 3: half-steps in this launch (step = number of the first step)
+    unsigned int *gbar;       // SMODE 3: eight arrival counters, 128 bytes apart, zero at launch
     // ---- independent sources sharing the band tables (cfg5): flux/ivar are
     // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
     // [nsrc][nw_src][6] and a launch covers nsrc * c_count walkers
@@ -108,6 +110,14 @@ __device__ __forceinline__ double ld_sys(const double *p)      // system-scope l
 __device__ __forceinline__ void st_sys(double *p, double v)    // system-scope (write-through) store
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_dev(const double *p)      // device-scope: sc1 load, L2-served
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_dev(double *p, double v)    // device-scope: sc1 store, through to L2
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Philox4x32-10 (Salmon et al. 2011), counter = (row, 2 step + half), key = seed.
@@ -137,11 +147,21 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 // SMODE: 0 the likelihood of given rows; 1 the stretch-move half-step; 2 the half-step of a
 // sharded run with the one-hop exchange (its own instantiation: carried as run-time
 // branches and extra arguments in the single-GPU sampler kernel it cost that kernel 0.75 us
-// per launch).
+// per launch); 3 a whole run of half-steps in ONE launch (single GPU, single source, one
+// walker per workgroup, every workgroup resident): the tables are staged once and the
+// dependence between half-steps is carried by a fence-free hand-off inside the kernel
+// instead of a kernel boundary -- the moved row goes out with write-through (sc1) stores
+// from one lane, that lane then adds to its XCD's arrival counter, and the next half-step's
+// prologue wave polls the eight counters and reads its rows with sc1 loads
+// (MI355X_MICROARCH.md, "Valid forms"; tools/lat_grid_barrier.hip: 2.5 us per hand-off).
+// Measured (tools/probe_persist.py): 21.2 us per step against 15.5 with one launch per
+// half-step -- the body of a half-step is 7.6 us either way and a dependent kernel
+// boundary costs this launch train far less than the hand-off -- so the host uses it only
+// on request (option "persistent_sampler" 1); chains are bitwise the same.
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
-    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2;
+    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, PERSIST = SMODE == 3;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
     __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
@@ -242,6 +262,18 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     int4 us_first = make_int4(0, 0, 0, 0);
     if (wave < nunit) us_first = a.unit_tab[wave % nun];
 
+    // PERSIST: a.persist half-steps in this launch; otherwise one pass with the launch's values
+    unsigned xcc = 0;
+    if (PERSIST) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u; }
+    const int niter = PERSIST ? a.persist : 1;
+    for (int it = 0; it < niter; ++it) {
+    const int L_step = PERSIST ? a.step + (it >> 1) : a.step, L_half = PERSIST ? (it & 1) : a.half;
+    const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) : a.s_begin;
+    const int L_c_begin = PERSIST ? (L_half ? 0 : a.c_count) : a.c_begin;
+    const unsigned long long L_seed = PERSIST ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1) : a.seed;
+    double *const L_chain6 = (PERSIST && a.chain6) ? a.chain6 + (size_t)it * a.n * 6 : a.chain6;
+    unsigned int *const L_nacc = PERSIST ? a.nacc + (size_t)L_half * a.n : a.nacc;
+
     // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
     // (the host guarantees blockDim.x >= 16 W)
     if (const int j = tid >> 4; j < W) {
@@ -258,9 +290,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // mbb_fit.py:533/:542): z ~ g(z) on [1/a, a], partner from the other
                 // half, proposal q = c - z (c - s)
                 const int src = w / a.m_count, loc = w - src * a.m_count;
-                const int row = src * a.nw_src + a.s_begin + loc;
-                unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * a.step + a.half), 0u, 0u};
-                philox4x32(c4, (unsigned int)a.seed, (unsigned int)(a.seed >> 32));
+                const int row = src * a.nw_src + L_s_begin + loc;
+                unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * L_step + L_half), 0u, 0u};
+                philox4x32(c4, (unsigned int)L_seed, (unsigned int)(L_seed >> 32));
                 const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) *
                                   (1.0 / 9007199254740992.0);
                 const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
@@ -270,11 +302,27 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 int pj = (int)(u2 * (double)a.c_count);
                 if (pj >= a.c_count) pj = a.c_count - 1;
                 const double *srow = a.pos6 + (size_t)row * 6;
-                const double *crow = a.pos6 + (size_t)(src * a.nw_src + a.c_begin + pj) * 6;
+                const double *crow = a.pos6 + (size_t)(src * a.nw_src + L_c_begin + pj) * 6;
+                if (PERSIST && it > 0) {
+                    // every walker of the previous half-step must have stored its row: the eight
+                    // arrival counters (one per XCD) add up to n per completed half-step.  Only
+                    // this wave reads state rows, so no workgroup barrier is needed after the poll.
+                    const unsigned target = (unsigned)it * (unsigned)a.n;
+                    const int l = tid & 63;
+                    long long spins = 0;
+                    for (;;) {
+                        unsigned v = 0;
+                        if (l < 8) v = __hip_atomic_load(a.gbar + l * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+                        if (__builtin_amdgcn_ballot_w64(l == 0 && v < target) == 0) break;
+                        if (++spins > (1ll << 22)) { atomicMax(a.errflag, 9); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
                 constexpr bool xchg = XCHG;
                 if (xchg) {
                     const XchgArgs &x = *a.xargs;
-                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)a.step + (unsigned)a.half + 1ull;
+                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)L_step + (unsigned)L_half + 1ull;
                     if (xseq > 1) {
                         // the partner rows were moved by the previous launch, on any rank: wait
                         // until every peer has posted that launch (lane l of the wave watches
@@ -298,10 +346,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 double srow5 = 0.0;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const double cv = xchg ? ld_sys(crow + i) : crow[i], sv = xchg ? ld_sys(srow + i) : srow[i];
+                    const double cv = xchg ? ld_sys(crow + i) : (PERSIST ? ld_dev(crow + i) : crow[i]);
+                    const double sv = xchg ? ld_sys(srow + i) : (PERSIST ? ld_dev(srow + i) : srow[i]);
                     p[i] = cv - zz * (cv - sv);
                 }
-                srow5 = xchg ? ld_sys(srow + 5) : srow[5];
+                srow5 = xchg ? ld_sys(srow + 5) : (PERSIST ? ld_dev(srow + 5) : srow[5]);
                 double lo[4];
                 vlog<true>(lo, p[0], p[2], zz, u3);
                 lT = lo[0]; lL = lo[1];
@@ -476,7 +525,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #pragma unroll
         for (int i = 0; i < 8; ++i) q_first[i] = prop[wave * 8 + i];
         const int wf = w0 + wave, srcf = wf / a.m_count;
-        row_first = srcf * a.nw_src + a.s_begin + (wf - srcf * a.m_count);
+        row_first = srcf * a.nw_src + L_s_begin + (wf - srcf * a.m_count);
     }
     if (wave < W) {
         st_first = wk[wave].status;
@@ -563,7 +612,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             if (SAMPLER) {
                 // accept with probability min(1, z^(dim-1) P(q)/P(s))
                 int row = row_first;
-                if (!FIRST) { const int src = w / a.m_count; row = src * a.nw_src + a.s_begin + (w - src * a.m_count); }
+                if (!FIRST) { const int src = w / a.m_count; row = src * a.nw_src + L_s_begin + (w - src * a.m_count); }
                 double *srow = a.pos6 + (size_t)row * 6;
                 double q[8];
 #pragma unroll
@@ -575,7 +624,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     // (a rejected move changes nothing anywhere), then this walker is counted;
                     // the last one of the launch tells every peer that the launch is complete
                     const XchgArgs &x = *a.xargs;
-                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)a.step + (unsigned)a.half + 1ull;
+                    const unsigned long long xseq = x.xseq0 + 2ull * (unsigned)L_step + (unsigned)L_half + 1ull;
                     if (accept) {
                         for (int pr = 0; pr < x.xn; ++pr) {
                             double *dst = x.xpos[pr] + (size_t)row * 6;
@@ -583,10 +632,10 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                             for (int i = 0; i < 5; ++i) st_sys(dst + i, q[i]);
                             st_sys(dst + 5, r);
                         }
-                        atomicAdd(&a.nacc[w], 1u);
+                        atomicAdd(&L_nacc[w], 1u);
                     }
-                    if (a.chain6) {
-                        double *crow = a.chain6 + (size_t)w * 6;
+                    if (L_chain6) {
+                        double *crow = L_chain6 + (size_t)w * 6;
 #pragma unroll
                         for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : ld_sys(srow + i);
                         crow[5] = accept ? r : q[6];
@@ -601,15 +650,32 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                                 __hip_atomic_store(x.xflag[pr] + x.xrank, xseq, __ATOMIC_RELEASE,
                                                    __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                } else if (PERSIST) {
+                    // the row goes out write-through, the stores are waited for, then this
+                    // walker is counted on its XCD's counter: the next half-step starts from that
+                    if (accept) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) st_dev(srow + i, q[i]);
+                        st_dev(srow + 5, r);
+                        atomicAdd(&L_nacc[w], 1u);
+                    }
+                    if (L_chain6) {
+                        double *crow = L_chain6 + (size_t)w * 6;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : ld_dev(srow + i);
+                        crow[5] = accept ? r : q[6];
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(a.gbar + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else {
                 if (accept) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) srow[i] = q[i];
                     srow[5] = r;
-                    atomicAdd(&a.nacc[w], 1u);                 // no-return atomic: nothing waits on it
+                    atomicAdd(&L_nacc[w], 1u);                 // no-return atomic: nothing waits on it
                 }
-                if (a.chain6) {
-                    double *crow = a.chain6 + (size_t)w * 6;
+                if (L_chain6) {
+                    double *crow = L_chain6 + (size_t)w * 6;
 #pragma unroll
                     for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : srow[i];
                     crow[5] = accept ? r : q[6];
@@ -623,6 +689,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (wave < W) epilogue(wave, std::true_type{});
     if (W > nwave)
         for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
+    }   // half-steps of a persistent run
     STAMP(6);
 }
 

@@ -1199,3 +1199,43 @@ def test_one_hop_exchange_two_processes_one_gpu():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "XCHG_OK" in text, text[-4000:]
+
+
+def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
+    """The single-GPU device sampler can run all its half-steps in ONE launch (option
+    "persistent_sampler"; k_lnlike SMODE 3: the dependence between half-steps is a fence-free
+    hand-off inside the kernel; measured slower than a launch per half-step, so off by
+    default, but it is the same chain and a test of that hand-off on every step).  Chain,
+    lnprob, final state and acceptance counts are bitwise those of the form with one launch
+    per half-step, for every model variant, with and without a stored chain, across several
+    consecutive runs, and with more walkers than fit the one-launch form (fall-back)."""
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    rng = np.random.RandomState(12)
+    for name, opthin, noalpha in VARIANTS:
+        k = "cfg2/" + name
+        res = []
+        for persistent in (1, 0):
+            like = mbb.likelihood(response=True, opthin=opthin, noalpha=noalpha)
+            like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+            like.context.set_option("persistent_sampler", persistent)
+            p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(4).normal(size=(250, 5)))
+            s = mbb.DeviceEnsembleSampler(250, 5, like, seed=77)
+            a = s.run_mcmc(p0, 40)
+            b = s.run_mcmc(None, 25, storechain=False)
+            s.advance_async(30); like.context.sync()
+            c = s.run_mcmc(None, 7)
+            res.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y), name
+        assert res[0][6].shape == (250, 47, 5) and 0.1 < res[0][8].mean() / 102 < 0.9
+    # 600 walkers: 300 per half-step, more than one per CU -> the per-half-step form takes over
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(600, 5)))
+    out = []
+    for persistent in (1, 0):
+        like.context.set_option("persistent_sampler", persistent)
+        s = mbb.DeviceEnsembleSampler(600, 5, like, seed=5)
+        out.append(s.run_mcmc(p0, 6)[:2] + (s.chain.copy(),))
+    for x, y in zip(out[0], out[1]):
+        assert np.array_equal(x, y)
