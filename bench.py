@@ -59,7 +59,7 @@ N_SIMD = 1024                  # 256 CUs x 4
 CLOCK_HZ = 2.4e9
 # tools/issue_cost.hip, profiles/r02/issue_cost_v1.txt: cycles one wave64 VALU
 # instruction holds its SIMD, four waves per SIMD
-CYC_FP64, CYC_OTHER = 4.3, 4.0
+CYC_FP64, CYC_OTHER = 4.3, 4.0        # (32-bit ops alone: 2.5; beside fp64 work: ~3.7-4)
 
 
 def walkers(nranks):
@@ -183,7 +183,7 @@ def valu_roofline(pm, pm_src, kernel_s, label):
             "fp64_share_of_valu": f64 / valu if valu else None,
             "valu_issue_bound_us": issue_s * 1e6, "valu_issue_frac": issue_s / kernel_s,
             "issue_cost_model": "fp64 %.1f / other %.1f cycles per wave instruction per SIMD, %d SIMDs at "
-                                "%.1f GHz (profiles/r02/issue_cost_v1.txt)" % (CYC_FP64, CYC_OTHER, N_SIMD, CLOCK_HZ / 1e9),
+                                "%.1f GHz (profiles/r02/issue_cost_v2.txt)" % (CYC_FP64, CYC_OTHER, N_SIMD, CLOCK_HZ / 1e9),
             "kernel_us": kernel_s * 1e6, "counters_source": pm_src}
 
 
@@ -527,6 +527,11 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
         sec5, slots5, mhz5 = c5.roof_probe(TRUTH, reps=200)
         pm5, pm5_src = measured_valu("pmc_valu_cfg5*.json", "k_lnlike<false, false, 0, false>")
         r5 = valu_roofline(pm5, pm5_src, ms5 * 1e-3, "k_lnlike<thick,alpha,plain> n=250000")
+        if r5 and mhz5 > 0:
+            # the chip does not hold 2.4 GHz under this load (tools/probe_clock.py): the same
+            # bound at the clock the sample-arithmetic probe measured just now
+            r5["shader_clock_mhz_under_load"] = mhz5
+            r5["valu_issue_frac_at_that_clock"] = r5["valu_issue_frac"] * (CLOCK_HZ / 1e6) / mhz5
         cfg5 = {"workload": "1000 sources x 250 walkers, 8 bands, NQ=2209, thick+alpha, one launch",
                 "evals_per_launch": n5, "kernel_ms": ms5, "evals_per_s": n5 / ms5 * 1e3,
                 "samples_per_s": n5 * nq / ms5 * 1e3,
