@@ -187,6 +187,11 @@ def valu_roofline(pm, pm_src, kernel_s, label):
             "kernel_us": kernel_s * 1e6, "counters_source": pm_src}
 
 
+def ensemble_crc(pos, lnp):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(pos).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp).tobytes())
+
+
 def emit(obj):
     print(json.dumps(obj), flush=True)
 
@@ -318,9 +323,10 @@ def main():
 
         def rehearse():
             try:
-                smp.run_mcmc(allw[:nwt], 20, storechain=False)
+                pos_r, lnp_r, _ = smp.run_mcmc(allw[:nwt], 60, storechain=False)
                 ctx.sync()
-                state["ok"] = True
+                state["crc"] = ensemble_crc(pos_r, lnp_r)
+                state["ok"] = bool(np.all(np.isfinite(lnp_r)))
             except Exception as e:           # noqa
                 state["err"] = repr(e)
 
@@ -329,7 +335,17 @@ def main():
         th.join(timeout=120.0)
         if th.is_alive():
             fail(4, error="the exchange did not return within 120 s", collective_hung=True, hang=collective)
-        if all_ok(state["ok"]):
+        agree = True
+        if all_ok(state["ok"]) and dist is not None:
+            # the ranks' copies of the ensemble must be the same bits after the rehearsal
+            import torch
+            lo = torch.tensor([float(state["crc"])], dtype=torch.float64)
+            hi = lo.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            agree = bool(lo[0] == hi[0])
+            if not agree:
+                state["err"] = "the ranks' copies of the ensemble differ after 60 steps"
+        if all_ok(state["ok"] and agree):
             break
         tried.append("%s rehearsal: %s" % (mode, state["err"] or "failed on another rank"))
         smp = None
@@ -371,8 +387,7 @@ def main():
     ranks_agree = True
     if dist is not None:                    # every rank must hold the same ensemble, bit for bit
         import torch
-        import zlib
-        h = float(zlib.crc32(np.ascontiguousarray(pos_end).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp_end).tobytes()))
+        h = float(ensemble_crc(pos_end, lnp_end))
         lo, hi = torch.tensor([h], dtype=torch.float64), torch.tensor([h], dtype=torch.float64)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ranks_agree = bool(lo[0] == hi[0])
@@ -385,7 +400,7 @@ def main():
                     "mcmc_steps_per_s": args.steps / elapsed,
                     "stream_us_per_step": stream_ms * 1e3 / args.steps,
                     # (sharded: the counts of this rank's own walkers)
-                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (20 + args.warmup + args.steps),
+                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps),
                     "ranks_agree": ranks_agree})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # launch slot of the dominant kernel
         kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half

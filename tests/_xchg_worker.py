@@ -68,6 +68,21 @@ def main():
     dist.all_reduce(t)                                 # disjoint rows, zeros elsewhere: the sum is the gather
     assert np.array_equal(t.numpy()[:, :nsteps], rchain)
     dist.barrier()
+    # a peer that stops taking part must surface as an error on the others, not as a hang:
+    # rank 1 sits this run out, rank 0's second launch waits for rank 1's flag, gives up
+    # after xchg_spin_max polls and the run reports it
+    ctx.set_option("xchg_spin_max", 20000)
+    if rank == 0:
+        smp2 = mbb.DeviceEnsembleSampler(nw, 5, like, seed=3)
+        smp2.barrier = None
+        saved, ctx.xchg_barrier = ctx.xchg_barrier, None      # rank 1 will not be at the barriers either
+        try:
+            smp2.run_mcmc(p0, 3)
+            raise AssertionError("a run without its peer must not succeed")
+        except Exception as e:
+            assert "timed out" in str(e), str(e)
+        ctx.xchg_barrier = saved
+    dist.barrier()
     ctx.xchg_close()
     dist.destroy_process_group()
     if rank == 0:
