@@ -335,64 +335,75 @@ def main():
         th.join(timeout=120.0)
         if th.is_alive():
             fail(4, error="the exchange did not return within 120 s", collective_hung=True, hang=collective)
-        agree = True
-        if all_ok(state["ok"]) and dist is not None:
-            # the ranks' copies of the ensemble must be the same bits after the rehearsal
+        def ranks_agree_on(crc):
+            """every rank must hold the same ensemble, bit for bit"""
+            if dist is None:
+                return True
             import torch
-            lo = torch.tensor([float(state["crc"])], dtype=torch.float64)
+            lo = torch.tensor([float(crc)], dtype=torch.float64)
             hi = lo.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            agree = bool(lo[0] == hi[0])
-            if not agree:
-                state["err"] = "the ranks' copies of the ensemble differ after 60 steps"
-        if all_ok(state["ok"] and agree):
-            break
-        tried.append("%s rehearsal: %s" % (mode, state["err"] or "failed on another rank"))
-        smp = None
+            return bool(lo[0] == hi[0])
+
+        def teardown():
+            try:
+                ctx.sync()
+                ctx.xchg_close() if mode == "ipc" else (ctx.comm_destroy() if mode == "rccl" else None)
+            except Exception:
+                pass
+
+        if not all_ok(state["ok"]):
+            tried.append("%s rehearsal: %s" % (mode, state["err"] or "failed on another rank"))
+            smp = None
+            teardown()
+            continue
+        if not ranks_agree_on(state["crc"]):
+            tried.append("%s rehearsal: the ranks' copies of the ensemble differ after 60 steps" % mode)
+            smp = None
+            teardown()
+            continue
+
+        # ---- the timed region: K dependent MCMC steps ----------------------------
+        smp.advance_async(args.warmup)
+        ctx.sync(); barrier()
+        e0, e1 = ctx.event(), ctx.event()
+        t0 = time.perf_counter()
+        ctx.record(e0)
+        smp.advance_async(args.steps)
+        ctx.record(e1)
+        ctx.sync(); barrier()
+        elapsed = time.perf_counter() - t0
+        stream_ms = ctx.elapsed_ms(e0, e1)
+        if dist is not None:
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        # the chain is still a valid one: every rank holds the same finite state
         try:
-            ctx.sync()
-            ctx.xchg_close() if mode == "ipc" else (ctx.comm_destroy() if mode == "rccl" else None)
-        except Exception:
-            pass
+            pos_end, lnp_end, _ = smp.run_mcmc(None, 0, storechain=False)
+            fine = bool(np.all(np.isfinite(lnp_end)))
+            crc = ensemble_crc(pos_end, lnp_end)
+        except Exception as e:
+            fine, crc, state["err"] = False, rank, repr(e)
+        if all_ok(fine) and ranks_agree_on(crc):
+            break
+        # a number measured on an exchange that lost or mixed up rows is not a number
+        tried.append("%s timed run: %s" % (mode, "the ranks' copies of the ensemble differ afterwards"
+                                                 if fine else (state["err"] or "non-finite state")))
+        smp = None
+        teardown()
     if smp is None:
-        fail(3, error="no exchange could be brought up: " + "; ".join(tried),
+        fail(3, error="no exchange gave a valid run: " + "; ".join(tried),
              collective="unavailable: " + "; ".join(tried))
     mode_used = mode
+    ranks_agree = True
     base["config"]["collective"] = collective
     if tried:
         base["config"]["collective_fallback_from"] = tried
     if world > ndev:
         base["valid_for_scaling"] = False
         base["config"]["note"] = "%d ranks share %d device(s): a rehearsal of the exchange, not a scaling point" % (world, ndev)
-
-    # ---- the timed region: K dependent MCMC steps --------------------------------
-    smp.advance_async(args.warmup)
-    ctx.sync(); barrier()
-    e0, e1 = ctx.event(), ctx.event()
-    t0 = time.perf_counter()
-    ctx.record(e0)
-    smp.advance_async(args.steps)
-    ctx.record(e1)
-    ctx.sync(); barrier()
-    elapsed = time.perf_counter() - t0
-    stream_ms = ctx.elapsed_ms(e0, e1)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    # the chain is still a valid one: every rank holds the same finite state
-    pos_end, lnp_end, _ = smp.run_mcmc(None, 0, storechain=False)
-    assert np.all(np.isfinite(lnp_end))
-    ranks_agree = True
-    if dist is not None:                    # every rank must hold the same ensemble, bit for bit
-        import torch
-        h = float(ensemble_crc(pos_end, lnp_end))
-        lo, hi = torch.tensor([h], dtype=torch.float64), torch.tensor([h], dtype=torch.float64)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        ranks_agree = bool(lo[0] == hi[0])
-        if not ranks_agree:
-            fail(6, error="the ranks' copies of the ensemble differ after the run", collective=collective)
 
     if rank == 0:
         out = dict(base)
