@@ -346,6 +346,10 @@ def main():
             return bool(lo[0] == hi[0])
 
         def teardown():
+            nonlocal smp
+            smp = None                      # (the sampler lives in the exchange buffer: it goes first)
+            import gc
+            gc.collect()
             try:
                 ctx.sync()
                 ctx.xchg_close() if mode == "ipc" else (ctx.comm_destroy() if mode == "rccl" else None)
@@ -430,6 +434,9 @@ def main():
     barrier()
     if world > 1:
         ctx.sync()
+        smp = None
+        import gc
+        gc.collect()
         if mode_used == "rccl":
             ctx.comm_destroy()
         elif mode_used == "ipc":

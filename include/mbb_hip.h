@@ -219,7 +219,8 @@ int mbb_lnlike_allgather_device(mbb_ctx *ctx, const double *d_pars, int n, doubl
  * in the exchange buffer; nwalkers <= max_rows).  The launcher must also synchronise
  * the ranks between mbb_sampler_set_state and the first mbb_sampler_run / advance, and
  * before a later set_state.  In this mode mbb_sampler_run fills chain / lnprob /
- * naccepted for this rank's walkers only (pos_out and lnprob_out are complete). */
+ * naccepted for this rank's walkers only (pos_out and lnprob_out are complete).
+ * mbb_xchg_close is refused while a sampler created under the exchange is alive. */
 int mbb_xchg_open(mbb_ctx *ctx, int nranks, int rank, int max_rows, unsigned char handle[64]);
 int mbb_xchg_connect(mbb_ctx *ctx, const unsigned char *handles /* nranks x 64 */);
 int mbb_xchg_close(mbb_ctx *ctx);

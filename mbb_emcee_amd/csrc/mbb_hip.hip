@@ -148,6 +148,7 @@ struct mbb_ctx {
     // [flags: 16 x u64][arrival counter][state rows: xcap x 6 doubles]
     struct Xchg {
         int n = 0, rank = 0, connected = 0;
+        int users = 0;                            // samplers whose state rows live in this buffer
         size_t cap_rows = 0;
         unsigned char *base = nullptr;            // own allocation
         unsigned char *peer[16] = {};             // every rank's allocation as mapped here (own = base)
@@ -699,6 +700,7 @@ extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long s
         if (R > c->x.cap_rows) { delete s; return fail(MBB_ERR_ARG, "more walkers than the exchange buffer holds"); }
         s->d_pos6 = c->x.pos6(c->x.rank);
         s->pos6_owned = false;
+        ++c->x.users;
     } else {
         HIPCHK(hipMalloc((void **)&s->d_pos6, R * 6 * sizeof(double)));
     }
@@ -719,6 +721,7 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     if (!s) return MBB_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s->pos6_owned) free_dev(s->d_pos6);
+    else if (c->x.users > 0) --c->x.users;
     free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar);
     delete s;
     return MBB_OK;
@@ -1363,6 +1366,7 @@ extern "C" int mbb_xchg_close(mbb_ctx *c)
 {
     int rc = use(c);
     if (rc) return rc;
+    if (c->x.users > 0) return fail(MBB_ERR_STATE, "a sampler still lives in the exchange buffer (mbb_sampler_destroy first)");
     HIPCHK(hipStreamSynchronize(c->stream));
     return xchg_free(c);
 }

@@ -83,6 +83,16 @@ def main():
             assert "timed out" in str(e), str(e)
         ctx.xchg_barrier = saved
     dist.barrier()
+    try:
+        ctx.xchg_close()
+        raise AssertionError("closing the exchange under a live sampler must be refused")
+    except Exception as e:
+        assert "sampler still lives" in str(e), str(e)
+    del smp
+    if rank == 0:
+        del smp2
+    import gc
+    gc.collect()
     ctx.xchg_close()
     dist.destroy_process_group()
     if rank == 0:
