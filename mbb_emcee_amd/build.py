@@ -13,8 +13,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "mbb_host_tables.cpp")      # host-only table builders
-DEPS = [SRC, SRC_HOST, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
+SRC_FLOW = os.path.join(HERE, "csrc", "mbb_flow.hip")             # the one-launch sampler kernel, own flags
+FLOW_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
+DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
+        os.path.join(HERE, "csrc", "mbb_walker_consts.inc"),
         os.path.join(HERE, "csrc", "mbb_device.hip.h"),
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),
         os.path.join(HERE, "csrc", "mbb_kernels.hip.h"),
@@ -37,15 +40,29 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB, SRC, SRC_HOST, "-ldl"]
+    # three objects (the two device translation units in parallel), then one link
+    common = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + list(extra_flags)
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        common.append("-Rpass-analysis=kernel-resource-usage")
+    objdir = os.path.join(HERE, "csrc", "_obj" + obj_tag)
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(SRC, os.path.join(objdir, "mbb_hip.o"), []),
+            (SRC_FLOW, os.path.join(objdir, "mbb_flow.o"), FLOW_FLAGS),
+            (SRC_HOST, os.path.join(objdir, "mbb_host_tables.o"), [])]
+    procs = []
+    for src, obj, flags in jobs:
+        cmd = common + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out or LIB] +
+                          [obj for _, obj, _ in jobs] + ["-ldl"])
     return LIB
 
 

@@ -1,0 +1,18 @@
+// mbb_flow.hip -- the one-launch look-ahead sampler run (k_lnlike, SMODE 5) in a translation unit
+// of its own, because it wants other code generation than the rest of the library: the kernel
+// is a loop over half-steps around two long dependent chains, and with the default pipeline the
+// compiler hoists every loop-invariant value out of that loop, runs out of registers and
+// reloads the spilled values inside the chains (172 bytes of scratch per lane).  Built with
+//   -mllvm -sink-insts-to-avoid-spills -mllvm -disable-machine-licm
+// it needs no scratch at all (mbb_emcee_amd/build.py).  The other kernels keep the default
+// flags: measured, they gain nothing from these.
+#include "mbb_kernels.hip.h"
+
+#define MBB_FLOW_INST(OT, NA)                                            \
+    template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
+    template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);
+MBB_FLOW_INST(false, false)
+MBB_FLOW_INST(false, true)
+MBB_FLOW_INST(true, false)
+MBB_FLOW_INST(true, true)
+#undef MBB_FLOW_INST

@@ -25,6 +25,16 @@
 #include "../../include/mbb_hip.h"
 #include "mbb_device.hip.h"
 #include "mbb_kernels.hip.h"
+
+// SMODE 5 is instantiated in mbb_flow.hip (its own compiler flags)
+#define MBB_FLOW_EXT(OT, NA)                                                    \
+    extern template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
+    extern template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);
+MBB_FLOW_EXT(false, false)
+MBB_FLOW_EXT(false, true)
+MBB_FLOW_EXT(true, false)
+MBB_FLOW_EXT(true, true)
+#undef MBB_FLOW_EXT
 #include "mbb_host_tables.h"
 
 static_assert(kPolyBDoubles == mbbh::kPolyBCount * (mbbh::kPolyDeg + 1), "poly table size");
@@ -138,7 +148,13 @@ struct mbb_ctx {
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
-    size_t lds_granted[32] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals one launch ahead (SMODE 4)
+    unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
+    long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
+    long opt_la_debug = 0;
+    long opt_la_waves = 0;
+    long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
+    size_t lds_granted[48] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -456,6 +472,26 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
     if (threads < 16 * wpb) threads = ((16 * wpb + 63) / 64) * 64;
 }
 
+// Look-ahead sampler runs: how the workgroups that work ahead are shaped.  One row of 16 lanes
+// per candidate proposal -- 2 per walker of a half (k_lnlike SMODE 4), 4 in a one-launch run,
+// where a row keeps to one half (SMODE 5) -- `rows` of them per wave, `aw` such waves per
+// workgroup.  A constructor is one dependent chain and a wave alone on its SIMD runs it fastest,
+// so the candidates are spread as thinly as the CUs the movers leave free allow.
+static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, bool one_launch, int &rows, int &aw,
+                           int &n_ahead)
+{
+    const int pairs = (one_launch ? 4 : 2) * half, free_cus = c->cu_count - movers;
+    static const int plan[5][2] = {{1, 4}, {2, 4}, {4, 4}, {4, 8}, {4, 16}};
+    rows = 1; aw = 4;
+    for (int i = 0; i < 5; ++i) {
+        rows = plan[i][0]; aw = std::min(plan[i][1], threads / 64);
+        if ((pairs + rows * aw - 1) / (rows * aw) <= free_cus) break;
+    }
+    if (c->opt_la_rows > 0) rows = (int)(c->opt_la_rows == 4 ? 4 : (c->opt_la_rows == 2 ? 2 : 1));
+    if (c->opt_la_waves > 0) aw = (int)std::min<long>(c->opt_la_waves, threads / 64);
+    n_ahead = (pairs + rows * aw - 1) / (rows * aw);
+}
+
 struct SamplerLaunch {
     double *pos6, *chain6;
     unsigned int *nacc;
@@ -466,6 +502,9 @@ struct SamplerLaunch {
     unsigned long long xseq;      // > 0: one-hop exchange, number of this launch
     int persist;                  // > 0: this many half-steps in one launch (k_lnlike SMODE 3)
     unsigned int *gbar;           // its arrival counters
+    double *spec;                 // != nullptr: look-ahead run (k_lnlike SMODE 4), records + state
+    int spec_cfg;                 // LikeArgs::spec_cfg
+    bool spec_first;              // the run's first launch: nobody moves
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -495,7 +534,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
 #ifdef MBB_STAMPS
     a.stamps = c->d_stamps;
 #endif
-    const int grid = (n + wpb - 1) / wpb;
+    int grid = (n + wpb - 1) / wpb;
     const size_t cov_bytes = c->has_cov ? 8 * (size_t)c->nb * c->nb : 0;
     const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->npart + 8 * (size_t)c->nb + 16) +
                              16 * (size_t)c->nb + 8 * ((size_t)c->nb + 2) + 64 * (size_t)wpb;
@@ -535,20 +574,40 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.nw_src = sl->nw_src;
         if (sl->xseq) a.xargs = c->x.d_args;
         a.persist = sl->persist; a.gbar = sl->gbar;
+        if (sl->spec) {
+            a.xargs = nullptr;
+            if (sl->persist) a.flow_serial = ++c->flow_serial;
+            // first the workgroups that prepare the next half-step -- one row of 16 lanes per
+            // (walker, candidate), `rows` of them per wave, `aw` such waves per workgroup -- then
+            // the movers.  A constructor is one dependent chain: a wave alone on its SIMD runs it
+            // fastest, so the candidates are spread as thinly as the CUs the movers leave free allow.
+            int rows, aw, n_ahead;
+            lookahead_plan(c, grid, threads, sl->c_count, sl->persist > 0, rows, aw, n_ahead);
+            a.spec = sl->spec;
+            a.spec_cfg = sl->spec_cfg | (rows << 8) | (aw << 16);
+            a.n_ahead = n_ahead;
+            if (sl->persist && a.n_ahead + grid > c->cu_count)
+                return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
+            grid = a.n_ahead + (sl->spec_first ? 0 : grid);
+            if ((c->opt_la_debug & 1) && !sl->spec_first) { grid -= a.n_ahead; a.n_ahead = 0; }     // timing only: movers alone
+            if (c->opt_la_debug & 2) a.spec_cfg |= 8;                          // timing only: movers exit at once
+            c->last_grid = grid;
+        }
     } else {
         a.pos6 = nullptr; a.chain6 = nullptr; a.nacc = nullptr; a.errflag = nullptr;
         a.s_begin = a.c_begin = a.c_count = a.m_count = a.nw = a.step = a.half = 0;
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
-        const int smode = !sl ? 0 : (sl->persist ? 3 : (sl->xseq ? 2 : 1));
-        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 8 + smode * 2 + (stage ? 1 : 0);
+        const int smode = !sl ? 0 : (sl->spec ? (sl->persist ? 5 : 4) : (sl->persist ? 3 : (sl->xseq ? 2 : 1)));
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 12 + smode * 2 + (stage ? 1 : 0);
         vi_of_kernel = vi;
 #define MBB_VARIANTS(OT, NA)                                                                        \
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
         k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>,           \
-        k_lnlike<OT, NA, 3, false>, k_lnlike<OT, NA, 3, true>
-        static void (*const table[32])(const LikeArgs) = {
+        k_lnlike<OT, NA, 3, false>, k_lnlike<OT, NA, 3, true>, k_lnlike<OT, NA, 4, false>,          \
+        k_lnlike<OT, NA, 4, true>, k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>
+        static void (*const table[48])(const LikeArgs) = {
             MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
             MBB_VARIANTS(true, true)};
 #undef MBB_VARIANTS
@@ -679,6 +738,7 @@ struct mbb_sampler_state {
     unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
     unsigned int *d_gbar = nullptr;      // arrival counters of the one-launch run (8 x 128 bytes)
+    double *d_spec = nullptr;            // look-ahead run: records [rows][2][kSpecRec] + state [2][rows][8]
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
@@ -722,7 +782,7 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s->pos6_owned) free_dev(s->d_pos6);
     else if (c->x.users > 0) --c->x.users;
-    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar);
+    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar); free_dev(s->d_spec);
     delete s;
     return MBB_OK;
 }
@@ -827,6 +887,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     sl.pos6 = s->d_pos6; sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw;
     sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
     sl.xseq = 0; sl.persist = 0; sl.gbar = nullptr;
+    sl.spec = nullptr; sl.spec_cfg = 0; sl.spec_first = false;
     // Option "persistent_sampler" 1 -- one GPU, one ensemble, at most one walker per CU: the
     // whole run in ONE launch per 4096 steps (k_lnlike SMODE 3: every workgroup is resident,
     // the half-steps hand over inside the kernel).  Off by default: measured slower.
@@ -844,6 +905,66 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
             if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
         }
+        s->steps_done += (unsigned long long)nsteps;
+        return MBB_OK;
+    }
+    // Option "lookahead_sampler" (default 1) -- one GPU, one ensemble, one walker per workgroup:
+    // every launch carries extra workgroups that prepare the NEXT half-step's proposals (draw,
+    // SED constructor, penalties) for both outcomes of each partner's pending move, so that a
+    // mover's workgroup starts from a finished record instead of the ~4 us dependent chain of
+    // the constructor (k_lnlike SMODE 4).  Same draws, same arithmetic: chains are bitwise
+    // those of the plain launch train.  One extra launch per run prepares its first half-step.
+    if (c->opt_lookahead && p.shards == 1 && !p.collective && s->nsrc == 1 && nsteps > 0 && wpb_1 == 1 &&
+        (int)nl + (2 * (int)nl + 63) / 64 <= c->cu_count && s->rows() <= kPolyBDoubles / 8) {
+        const size_t R = (size_t)s->rows();
+        if (!s->d_spec) HIPCHK(hipMalloc((void **)&s->d_spec, spec_words(R) * sizeof(double)));
+        int la_rows, la_aw, la_ahead;
+        lookahead_plan(c, (int)nl, thr_1, half, true, la_rows, la_aw, la_ahead);
+        if (c->opt_flow && la_ahead + (int)nl <= c->cu_count) {
+            // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
+            // resident, the tables are staged once, a row's half-step starts when the rows it
+            // depends on are done (no launch boundary, no grid-wide barrier)
+            sl.spec = s->d_spec;
+            for (int t0 = 0; t0 < nsteps; t0 += 4096) {
+                const int nt = std::min(4096, nsteps - t0);
+                hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
+                                   s->d_pos6, s->d_spec, (int)R);
+                HIPCHK(hipGetLastError());
+                sl.s_begin = 0; sl.c_begin = half; sl.step = t0; sl.half = 0;
+                sl.persist = 2 * nt;
+                sl.chain6 = store ? s->d_chain6 + ((size_t)t0 * 2 * nl) * 6 : nullptr;
+                sl.nacc = s->d_nacc;
+                sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
+                sl.spec_cfg = 0; sl.spec_first = false;
+                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+            }
+            s->steps_done += (unsigned long long)nsteps;
+            return MBB_OK;
+        }
+        hipLaunchKernelGGL(k_spec_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
+                           s->d_pos6, s->d_spec, (int)R);
+        HIPCHK(hipGetLastError());
+        int cur[2] = {0, 0};                                  // slot of each half's current state
+        sl.spec = s->d_spec;
+        sl.chain6 = nullptr; sl.nacc = s->d_nacc;
+        const unsigned long long key0 = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + 1ull);
+        // the launch "before" the first one: second half moving at step -1, nobody actually moves
+        sl.s_begin = half; sl.c_begin = 0; sl.step = -1; sl.half = 1;
+        sl.seed = key0 - 0x9E3779B97F4A7C15ull;
+        sl.spec_cfg = cur[1] | (cur[0] << 1) | 4; sl.spec_first = true;
+        if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+        sl.spec_first = false;
+        for (int t = 0; t < nsteps; ++t)
+            for (int h = 0; h < 2; ++h) {
+                sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half;
+                sl.step = t; sl.half = h;
+                sl.chain6 = store ? s->d_chain6 + (((size_t)t * 2 + h) * nl) * 6 : nullptr;
+                sl.nacc = s->d_nacc + (size_t)h * nl;
+                sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
+                sl.spec_cfg = cur[h] | (cur[1 - h] << 1);
+                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+                cur[h] ^= 1;
+            }
         s->steps_done += (unsigned long long)nsteps;
         return MBB_OK;
     }
@@ -1270,6 +1391,11 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "persistent_sampler")) c->opt_persist = value;
+    else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
+    else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
+    else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
+    else if (!strcmp(name, "lookahead_waves")) c->opt_la_waves = value;
+    else if (!strcmp(name, "lookahead_debug")) c->opt_la_debug = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
     else if (!strcmp(name, "roof_threads")) c->opt_roof_threads = value;
     else return fail(MBB_ERR_ARG, "unknown option");

@@ -66,7 +66,11 @@ struct LikeArgs {
     uint32_t has_uplim;       // bit i
     uint32_t has_gprior;      // bit i
     // batch
-    const double *pars;       // [n*5]
+    union {
+        const double *pars;   // [n*5]  (SMODE 0)
+        unsigned long long flow_serial;   // SMODE 5: number of this launch in the context's life, in the
+                              // check words of the records (a record left by an earlier run never fits)
+    };
     int n;
     int wpb;                  // walkers per block
     int debug;                // status carries root-finder iterations << 8
@@ -88,8 +92,13 @@ struct LikeArgs {
     int *errflag;             // set to a row status >= 2 if lnprob is NaN / invalid
     int s_begin, c_begin, c_count, m_count, nw;
     int step, half;
-    int persist;              // SMODE 3: half-steps in this launch (step = number of the first step)
-    unsigned int *gbar;       // SMODE 3: eight arrival counters, 128 bytes apart, zero at launch
+    // (arguments of variants that never meet share storage, so that the block stays at 480
+    // bytes for every variant)
+    int persist;              // SMODE 3, 5: half-steps in this launch (step = number of the first step)
+    union {
+        unsigned int *gbar;   // SMODE 3: eight arrival counters, 128 bytes apart, zero at launch
+        double *spec;         // SMODE 4, 5: the look-ahead run's device state, see spec_* below
+    };
     // ---- independent sources sharing the band tables (cfg5): flux/ivar are
     // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
     // [nsrc][nw_src][6] and a launch covers nsrc * c_count walkers
@@ -100,8 +109,65 @@ struct LikeArgs {
     // kept out of the argument block -- every launch of every variant pays for the size of
     // that block (48 bytes more, crossing 512, cost the single-GPU sampler 2.7 % per step:
     // tools/lat_kernarg.hip, profiles/r02/lat_kernarg.txt)
-    const XchgArgs *xargs;
+    union {
+        const XchgArgs *xargs;
+        // ---- look-ahead half-steps (SMODE 4, 5): see k_lnlike
+        struct {
+            int spec_cfg;     // bit 0: slot of the moving half's state, bit 1: of the other half's,
+                              // bit 2: a run's first launch (works ahead for itself, moves nothing)
+                              // (bits 0-2: SMODE 4 only);
+                              // bits 8-15: candidates per wave (1, 2 or 4 rows of 16 lanes),
+                              // bits 16-23: waves of a workgroup working ahead that take candidates
+            int n_ahead;      // workgroups 0 .. n_ahead-1 work ahead (dispatched first: theirs is the
+                              // longer path), the rest move walkers
+        };
+    };
 };
+#ifndef MBB_STAMPS
+static_assert(sizeof(LikeArgs) == 480, "the argument block: every launch of every variant pays for its size");
+#endif
+constexpr int kSpecRec = 32;  // doubles per record: WalkerK (13), proposal (5), 4 ln z, ln u, the two penalties
+// Device state of a look-ahead run, one allocation of 8-byte words (nw = state rows).
+// SMODE 4: records [nw][2][kSpecRec] at 0, state [2][nw][8] at 64 nw, accept flags [2][nw] at 80 nw.
+// SMODE 5 (FlowView): everything a row publishes is indexed by the number m of the move it
+// belongs to, mod kFlowSlots -- a mover more than four half-steps ahead of the slowest waits, so
+// four slots are never overwritten under a reader:
+//   rec   [nw][kFlowSlots][2][kFlowRec]  the proposal records of move m, one per candidate: word
+//                   2c is element c of the record (the order of SMODE 4's), word 2c + 1 is
+//                   (half-step of the move + 1) XOR that element's bits -- a reader takes an element
+//                   when the pair fits, whenever and in whatever order the two stores arrive, so
+//                   the writer neither waits for its stores nor raises a flag after them
+//   st    [kFlowSlots][nw][8]            the row after move m (slot 0: as the run found it)
+//   seq   [nw]      the half-step after the last one whose row has LANDED in st (0: none)
+//   rseq  [nw][2]   the same for the records, per candidate
+//   done  [8][16]   moves completed per half-step mod 8 (the lag guard)
+//   mseq  [nw][kFlowSlots]  2 x (half-step of move m + 1) + (it was accepted): written the moment
+//                   the move is decided, before the row itself
+constexpr int kFlowSlots = 4, kFlowRecN = 22, kFlowRec = 48;
+struct FlowView {
+    double *rec, *st;
+    unsigned long long *seq, *rseq, *done, *mseq;
+};
+__host__ __device__ constexpr size_t spec_words(size_t nw)
+{
+    return nw * ((size_t)kFlowSlots * 2 * kFlowRec + kFlowSlots * 8 + 3 + kFlowSlots) + 8 * 16;
+}
+__device__ __forceinline__ FlowView flow_view(double *spec, int nw)
+{
+    FlowView v;
+    v.rec = spec;
+    v.st = spec + (size_t)nw * kFlowSlots * 2 * kFlowRec;
+    v.seq = reinterpret_cast<unsigned long long *>(v.st + (size_t)nw * kFlowSlots * 8);
+    v.rseq = v.seq + nw;
+    v.done = v.rseq + (size_t)2 * nw;
+    v.mseq = v.done + 8 * 16;
+    return v;
+}
+// SMODE 5: moves of half h (0: rows [0, n/2), 1: the rest) completed before half-step j; the
+// state after a row's m-th move lives in slot m mod kFlowSlots and is there once the row's word
+// says flow_seq(h, m)
+__host__ __device__ constexpr int flow_cnt(int h, int j) { return (j - h + 1) > 0 ? (j - h + 1) >> 1 : 0; }
+__host__ __device__ constexpr int flow_seq(int h, int m) { return m > 0 ? h + 2 * m - 1 : 0; }
 
 __device__ __forceinline__ double ld_sys(const double *p)      // system-scope load (bypasses L1)
 {
@@ -137,6 +203,28 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
     }
 }
 
+// The stretch move's proposal c - z (c - s), one rounding per coordinate wherever it is formed.
+__device__ __forceinline__ double stretch_q(double cv, double sv, double zz)
+{
+    return __builtin_fma(-zz, cv - sv, cv);
+}
+
+// Philox draw of state row `row` at half-step (step, half): z of the stretch move, the
+// partner's index in the other half, the uniform of the accept test.
+__device__ __forceinline__ void stretch_draw(int row, int step, int half, unsigned long long seed,
+                                             double stretch_a, int c_count, double &zz, int &pj, double &u3)
+{
+    unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * step + half), 0u, 0u};
+    philox4x32(c4, (unsigned int)seed, (unsigned int)(seed >> 32));
+    const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
+    u3 = ((double)c4[3] + 0.5) * (1.0 / 4294967296.0);
+    const double sq = (stretch_a - 1.0) * u1 + 1.0;
+    zz = sq * sq / stretch_a;
+    pj = (int)(u2 * (double)c_count);
+    if (pj >= c_count) pj = c_count - 1;
+}
+
 // Block = blockDim.x/64 waves working on `wpb` consecutive walkers.
 //   phase 1: prologue, one row of 16 lanes per walker     -> LDS
 //   phase 2: (walker, segment) units dealt round-robin to waves; a lane strides
@@ -161,7 +249,8 @@ __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, u
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
-    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, PERSIST = SMODE == 3;
+    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, FLOW = SMODE == 5, PERSIST = SMODE == 3 || FLOW,
+                   SPEC = SMODE == 4 || FLOW;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
     __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
@@ -188,7 +277,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
-    const int w0 = blockIdx.x * W;
+    const int w0 = (SMODE >= 4 ? (int)blockIdx.x - a.n_ahead : (int)blockIdx.x) * W;
     // The compiler fetches kernel arguments where they are first used, one exposed
     // scalar-cache round trip (~200 cycles) each; on the latency path that is a
     // dozen of them.  Ask for the hot ones here so that they arrive in one batch.
@@ -197,6 +286,13 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]);
     PIN(a.unit_tab); PIN(a.lnl); PIN(a.status); PIN(a.model_flux); PIN(a.invcov); PIN(a.nsrc);
     PIN(a.debug); PIN(a.flux); PIN(a.ivar); PIN(a.rows_per_src);
+    if constexpr (SMODE >= 4) {
+        // a mover starts from loads, not from arithmetic: everything its first instructions need
+        PIN(a.spec); PIN(a.n_ahead); PIN(a.spec_cfg); PIN(a.s_begin); PIN(a.c_begin); PIN(a.c_count);
+        PIN(a.step); PIN(a.half); PIN(a.seed); PIN(a.stretch_a); PIN(a.nw); PIN(a.poly_b); PIN(a.poly_c);
+        PIN(a.nu); PIN(a.lnnu); PIN(a.wt); PIN(a.nchunk); PIN(a.band_rng); PIN(a.nb); PIN(a.wpb);
+        PIN(a.nunit); PIN(a.npart); PIN(a.pos6); PIN(a.nacc); PIN(a.chain6); PIN(a.errflag);
+    }
 #undef PIN
 #ifdef MBB_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();   // before the kernarg arrives
@@ -214,36 +310,90 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // stage what the later phases need in LDS and pull their first segment's samples
     // and the index table into this CU's L1, so that nothing after the barrier waits
     // on L2; without spare waves every wave stages first.
+    if (SPEC && (a.spec_cfg & 8) && (int)blockIdx.x >= a.n_ahead) return;
     const int pwaves = min(nwave, (16 * W + 63) >> 6);
-    if (wave >= pwaves || pwaves == nwave) {
+    if ((!SPEC || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
         const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
         const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
-        for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
-        {
-            const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
-            double2 *lb = reinterpret_cast<double2 *>(s_pb);
-            for (int i = t0; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
-            if (!OPTHIN) {
-                const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
-                double2 *lc = reinterpret_cast<double2 *>(s_pc);
-                for (int i = t0; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
+        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+        const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
+        const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
+        const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
+        double2 *lb = reinterpret_cast<double2 *>(s_pb);
+        double2 *lc = reinterpret_cast<double2 *>(s_pc);
+        double2 *l0 = reinterpret_cast<double2 *>(s_nu);
+        double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
+        double2 *l2 = reinterpret_cast<double2 *>(s_wt);
+        constexpr int nB = kPolyBDoubles / 2, nC = OPTHIN ? 0 : kPolyCDoubles / 2;
+        const int n2 = STAGE ? a.nchunk * 32 : 0;              // double2 elements per passband array
+        if constexpr (!SPEC) {
+            // table by table, a sweep at a time: the copy trickles along beside the constructor
+            // (asked for all at once it fills the CU's load queue and the constructor wave's own
+            // few loads wait behind it: +15 % on the 125-walker launch)
+            for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+            for (int i = t0; i < nB; i += nt) lb[i] = gb[i];
+            for (int i = t0; i < nC; i += nt) lc[i] = gc[i];
+            for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
+            for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
+            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        } else {
+            // A mover of a look-ahead run has no constructor to hide the copy behind (it ran a
+            // launch ago), so every table is asked for before the first one is stored: one
+            // exposed round trip for the lot (~3500 cycles at the start of a launch, when nothing
+            // is in L2 yet) instead of one per table and sweep.  Up to three sweeps per table go
+            // through registers; what is left (few staging threads, long tables) follows in
+            // plain loops.  The loads are pinned in front of the stores: left alone the compiler
+            // sinks each load into the branch of its store and waits for it there.
+#define MBB_PIN2(v) asm volatile("" : "+v"(v.x), "+v"(v.y))
+            // (After that first round trip the copy is bound by the rate at which the CU's address
+            // unit takes loads -- 64 bytes a cycle, 16 cycles per full wave -- so lanes past the
+            // end of a table ask for nothing.)
+            const int i0 = t0, i1 = t0 + nt, i2 = t0 + 2 * nt;
+            const double2 z2 = make_double2(0.0, 0.0);
+            double2 ve = z2, vb0 = z2, vb1 = z2, vb2 = z2, vc0 = z2, vc1 = z2;
+            double2 p00 = z2, p01 = z2, p10 = z2, p11 = z2, p20 = z2, p21 = z2, fiv = z2;
+            int2 brv = make_int2(0, 0);
+            if (STAGE) {
+                if (i0 < n2) { p00 = g0[i0]; p10 = g1[i0]; p20 = g2[i0]; }
+                if (i1 < n2) { p01 = g0[i1]; p11 = g1[i1]; p21 = g2[i1]; }
             }
+            if (i0 < kExp2N) ve = reinterpret_cast<const double2 *>(kExp2Tab)[i0];
+            if (i0 < nB) vb0 = gb[i0];
+            if (i1 < nB) vb1 = gb[i1];
+            if (i2 < nB) vb2 = gb[i2];
+            if (!OPTHIN) {
+                if (i0 < nC) vc0 = gc[i0];
+                if (i1 < nC) vc1 = gc[i1];
+            }
+            if (t0 < nb) { fiv = make_double2(a.flux[t0], a.ivar[t0]); brv = a.band_rng[t0]; }
+            if (STAGE) { MBB_PIN2(p00); MBB_PIN2(p10); MBB_PIN2(p20); MBB_PIN2(p01); MBB_PIN2(p11); MBB_PIN2(p21); }
+            MBB_PIN2(ve); MBB_PIN2(vb0); MBB_PIN2(vb1); MBB_PIN2(vb2);
+            if (!OPTHIN) { MBB_PIN2(vc0); MBB_PIN2(vc1); }
+            MBB_PIN2(fiv);
+#undef MBB_PIN2
+            if (STAGE) {
+                if (i0 < n2) { l0[i0] = p00; l1[i0] = p10; l2[i0] = p20; }
+                if (i1 < n2) { l0[i1] = p01; l1[i1] = p11; l2[i1] = p21; }
+            }
+            if (i0 < kExp2N) reinterpret_cast<double2 *>(s_tab)[i0] = ve;
+            if (i0 < nB) lb[i0] = vb0;
+            if (i1 < nB) lb[i1] = vb1;
+            if (i2 < nB) lb[i2] = vb2;
+            if (!OPTHIN) {
+                if (i0 < nC) lc[i0] = vc0;
+                if (i1 < nC) lc[i1] = vc1;
+            }
+            if (t0 < nb) { s_flux[t0] = fiv.x; s_ivar[t0] = fiv.y; s_band[t0] = brv; }
+            for (int i = t0 + nt; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+            for (int i = t0 + 3 * nt; i < nB; i += nt) lb[i] = gb[i];
+            for (int i = t0 + 2 * nt; i < nC; i += nt) lc[i] = gc[i];
+            for (int i = t0 + 2 * nt; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+            for (int b = t0 + nt; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
         }
-        for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
-        for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
         if (a.cov_in_lds)
             for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
-        if (STAGE) {
-            // passband tables -> LDS, 16 B per lane
-            const int n2 = a.nchunk * 32;                      // double2 elements per array
-            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
-            const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
-            const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
-            double2 *l0 = reinterpret_cast<double2 *>(s_nu);
-            double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
-            double2 *l2 = reinterpret_cast<double2 *>(s_wt);
-            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-        } else if (wave >= pwaves) {
+        if (!STAGE && wave >= pwaves) {
             const int u = wave;
             if (u < W * nun) {
                 const int4 us = a.unit_tab[u % nun];
@@ -262,10 +412,243 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     int4 us_first = make_int4(0, 0, 0, 0);
     if (wave < nunit) us_first = a.unit_tab[wave % nun];
 
+    // ---- SMODE 4, the workgroups that work ahead -------------------------------------------
+    // Row (16 lanes) `pair` = (walker of the half that moves NEXT, candidate): the walker's
+    // proposal for the next half-step, its SED constants and penalties, under the assumption
+    // that its partner -- one of this launch's movers -- stays (candidate 0) or moves to the
+    // proposal it is being tested on right now (candidate 1; re-derived here from the same
+    // draw and the same rows, so it is the value the mover's own record holds).  Everything
+    // read is state no workgroup of this launch writes: movers write the other slot.
+    if constexpr (SPEC) {
+        if ((int)blockIdx.x < a.n_ahead) {
+            const int rpw = (a.spec_cfg >> 8) & 0xff, aw = (a.spec_cfg >> 16) & 0xff;
+            const int pair = ((int)blockIdx.x * aw + wave) * rpw + (lane >> 4);
+            const bool first = !FLOW && ((a.spec_cfg >> 2) & 1);   // SMODE 4, nobody is moving: candidate 0 only
+            // SMODE 5: a row of lanes keeps to one half of the ensemble, every other half-step
+            // (a proposal takes about a half-step to prepare; what can be fetched before the
+            // decision it waits for is fetched during the half-step in between)
+            const int wh = FLOW ? (pair >> 1) & 1 : 0;
+            const bool active = wave < aw && (lane >> 4) < rpw && pair < (FLOW ? 4 : 2) * a.c_count && !(first && (pair & 1));
+            const int loc = FLOW ? pair >> 2 : pair >> 1, cand = pair & 1;
+            double *lst = s_pb;
+            if constexpr (!FLOW) {
+                // the ensemble as this launch found it -> LDS (the polynomial table's place, which
+                // these workgroups do not use): every row from the slot nobody writes in this launch
+                const double2 *g = reinterpret_cast<const double2 *>(a.spec + (size_t)a.nw * 2 * kSpecRec);
+                double2 *l = reinterpret_cast<double2 *>(lst);
+                for (int i = tid; i < a.nw * 4; i += (int)blockDim.x) {
+                    const int row = i >> 2;
+                    const bool mov = row >= a.s_begin && row < a.s_begin + a.c_count;
+                    const int slot = mov ? (a.spec_cfg & 1) : ((a.spec_cfg >> 1) & 1);
+                    l[i] = g[(size_t)slot * a.nw * 4 + i];
+                }
+            } else if (wave >= aw) {
+                return;                                       // SMODE 5: nothing is shared, spare waves leave
+            }
+            // SMODE 5: half-step j of the run is prepared as soon as the rows it starts from are
+            // there -- the state as of the start of half-step j - 1 -- while j - 1 is still moving
+            const FlowView fv = flow_view(a.spec, a.nw);
+            const int nj = FLOW ? a.persist : 1;
+            int pend_j = -1;                                  // SMODE 5: the record whose landing is still to be announced
+            for (int j = wh; j < nj; j += FLOW ? 2 : 1) {
+            if (FLOW && pend_j >= 0) {
+                // (to the rows that work ahead from this record's proposal, half-steps from now;
+                // the mover itself takes the record element by element)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (active && (tid & 15) == 0)
+                    __hip_atomic_store(fv.rseq + (size_t)((wh ? a.c_count : 0) + loc) * 2 + cand, (unsigned long long)(pend_j + 1),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the draws: the walker's own for the half-step being prepared, and the one its
+            // partner is moving on meanwhile
+            const int hj = FLOW ? (j & 1) : (a.half ^ 1);
+            const int sb = FLOW ? (hj ? a.c_count : 0) : a.c_begin;      // the half that moves then / the other
+            const int ob = FLOW ? (hj ? 0 : a.c_count) : a.s_begin;
+            const int tn = FLOW ? a.step + (j >> 1) : a.step + a.half;
+            const unsigned long long seed_n =
+                FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j >> 1)
+                     : (a.half ? a.seed + 0x9E3779B97F4A7C15ull : a.seed);
+            const int tp = FLOW ? a.step + ((j - 1) >> 1) : a.step, hp = hj ^ 1;
+            const unsigned long long seed_p =
+                FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((j - 1) >> 1) : a.seed;
+            const bool c1 = cand && (!FLOW || j > 0);
+            const int rown = sb + loc;
+            STAMP(11);
+            double zz = 1.0, u3 = 0.5, zp = 1.0, up;
+            int pj = 0, pjp = 0;
+            if (active) {
+                stretch_draw(rown, tn, hj, seed_n, a.stretch_a, a.c_count, zz, pj, u3);
+                if (c1) stretch_draw(ob + pj, tp, hp, seed_p, a.stretch_a, a.c_count, zp, pjp, up);
+            }
+            double snv[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, cpos[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, cpv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            int m_next = 0;                                   // SMODE 5: the number of the move being prepared
+            if constexpr (FLOW) {
+                // The rows this proposal starts from -- the walker's own and, for candidate 1, its
+                // partner's partner -- made their last move in half-step j - 2.  Such a row is put
+                // together here from what was known before that move was decided (the row as it
+                // was, and the proposal it was tested on: the record of the candidate its own
+                // partner's earlier move selected), so that when the decision arrives nothing is
+                // left to fetch: the constructor starts one hand-off after the decision.
+                const int m_s = flow_cnt(hj, j - 1), m_o = flow_cnt(hj ^ 1, j - 1);   // moves made, as of j - 1
+                m_next = m_s + 1;
+                const int g = j - 2;                                                  // half-step of move m_s
+                const int m_q = flow_cnt(hj ^ 1, g);                                  // the other half's moves before g
+                const int l16 = lane & 15, base = lane & 48;
+                const int pprow = sb + pjp, prow = ob + pj;
+                int qr = 0, qp = 0;                           // partners of the two rows in half-step g
+                if (active && m_s > 0) {
+                    const int tg = a.step + (g >> 1);
+                    const unsigned long long seed_g = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(g >> 1);
+                    double z0, u0;
+                    stretch_draw(rown, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qr, u0);
+                    if (c1) stretch_draw(pprow, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qp, u0);
+                }
+                auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
+                    unsigned long long v = 0;
+                    long long spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        ++spins;
+                        if (spins > (1ll << 22) ||
+                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            atomicMax(a.errflag, 9);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    return v;
+                };
+                // (1) everything that was settled a half-step or more ago, one lane of the row each:
+                //  0, 1: which candidate the two rows' move m_s was tested on (their partners' decisions)
+                //  2   : the partner's row before its pending move has landed
+                //  3, 4: the two rows before move m_s have landed;  5-8: the records of move m_s too
+                const unsigned long long *w1 = fv.seq;
+                unsigned long long n1 = 0;
+                int sh1 = 0;
+                bool watch1 = false;
+                if (active) {
+                    const unsigned long long nq = (unsigned long long)flow_seq(hj ^ 1, m_q);
+                    const unsigned long long nold = (unsigned long long)flow_seq(hj, m_s - 1);
+                    switch (l16) {
+                    case 0: w1 = fv.mseq + (size_t)(ob + qr) * kFlowSlots + (m_q % kFlowSlots); n1 = nq; sh1 = 1; watch1 = m_s > 0 && m_q > 0; break;
+                    case 1: w1 = fv.mseq + (size_t)(ob + qp) * kFlowSlots + (m_q % kFlowSlots); n1 = nq; sh1 = 1; watch1 = c1 && m_s > 0 && m_q > 0; break;
+                    case 2: w1 = fv.seq + prow; n1 = (unsigned long long)flow_seq(hj ^ 1, m_o); watch1 = m_o > 0; break;
+                    case 3: w1 = fv.seq + rown; n1 = nold; watch1 = m_s > 1; break;
+                    case 4: w1 = fv.seq + pprow; n1 = nold; watch1 = c1 && m_s > 1; break;
+                    case 5: case 6: w1 = fv.rseq + (size_t)rown * 2 + (l16 - 5); n1 = (unsigned long long)(g + 1); watch1 = m_s > 0; break;
+                    case 7: case 8: w1 = fv.rseq + (size_t)pprow * 2 + (l16 - 7); n1 = (unsigned long long)(g + 1); watch1 = c1 && m_s > 0; break;
+                    default: break;
+                    }
+                }
+                const unsigned long long v1 = spin(w1, n1, watch1, sh1);
+                const int cr = (m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 0) & 1ull) : 0;
+                const int cp = (m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 1) & 1ull) : 0;
+                // both versions of the two rows and the partner's row -> this row's corner of LDS
+                // (the polynomial table's place), an element or two per lane: [0,5) the walker's row
+                // as it was, [5,10) the proposal it was tested on, [10,20) the same for the
+                // partner's partner, [20,25) the partner
+                double *scr = s_pb + (size_t)(wave * 4 + (lane >> 4)) * 32;
+                if (active) {
+                    const int so = (m_s > 0 ? m_s - 1 : 0) % kFlowSlots;
+                    const double *o_r = fv.st + ((size_t)so * a.nw + rown) * 8, *o_p = fv.st + ((size_t)so * a.nw + pprow) * 8;
+                    const double *n_r = fv.rec + (((size_t)rown * kFlowSlots + (m_s % kFlowSlots)) * 2 + cr) * kFlowRec + 26;
+                    const double *n_p = fv.rec + (((size_t)pprow * kFlowSlots + (m_s % kFlowSlots)) * 2 + cp) * kFlowRec + 26;
+                    const double *sp = fv.st + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * 8;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int e = l16 + 16 * t;
+                        if (e < 25) {
+                            const int grp = e / 5, i = e - 5 * grp;
+                            const double *src = grp == 0 ? o_r : (grp == 1 ? n_r : (grp == 2 ? o_p : (grp == 3 ? n_p : sp)));
+                            const bool want = grp == 0 || grp == 4 || (grp == 1 && m_s > 0) || (grp == 2 && c1) || (grp == 3 && c1 && m_s > 0);
+                            const int stride = (grp == 1 || grp == 3) ? 2 : 1;      // record elements are every other word
+                            scr[e] = want ? ld_dev(src + stride * i) : 0.0;
+                        }
+                    }
+                }
+                // (2) the decisions of half-step j - 2 (lanes 0, 1): the hand-off this chain waits for
+                const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
+                const unsigned long long v2 = spin(w2, (unsigned long long)flow_seq(hj, m_s),
+                                                   active && m_s > 0 && (l16 == 0 || (l16 == 1 && c1)), 1);
+                STAMP(12);
+                const bool ar = m_s > 0 && (__shfl(v2, base + 0) & 1ull), ap = m_s > 0 && (__shfl(v2, base + 1) & 1ull);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { snv[i] = scr[(ar ? 5 : 0) + i]; cpv[i] = scr[(ap ? 15 : 10) + i]; cpos[i] = scr[20 + i]; }
+            } else {
+                __syncthreads();
+                if (active) {
+                    const double *sn = lst + (size_t)rown * 8, *sp = lst + (size_t)(ob + pj) * 8, *cp = lst + (size_t)(sb + pjp) * 8;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { snv[i] = sn[i]; cpos[i] = sp[i]; if (c1) cpv[i] = cp[i]; }
+                }
+            }
+            if (active) {
+                if (c1) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) cpos[i] = stretch_q(cpv[i], cpos[i], zp);
+                }
+                double p[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) p[i] = stretch_q(cpos[i], snv[i], zz);
+                STAMPD(8, p[0] + p[1] + p[2] + p[3] + p[4]);
+                double lo[4];
+                vlog<true>(lo, p[0], p[2], zz, u3);
+                WalkerK k;
+                k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+                k.status = ROW_SKIP;
+                k.pad = 0;
+                double pen_u = 0.0, pen_g = 0.0;
+                const double lT = lo[0], lL = lo[1];
+#include "mbb_walker_consts.inc"
+                if ((tid & 15) == 0) {
+                    double *rec = FLOW ? fv.rec + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFlowRec
+                                       : a.spec + ((size_t)rown * 2 + cand) * kSpecRec;
+                    if constexpr (FLOW) {
+                        // element by element, each with its check word; nothing to wait for
+                        const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(j + 1);
+                        auto put = [&](int c, double v) {
+                            st_dev(rec + 2 * c, v);
+                            __hip_atomic_store(reinterpret_cast<unsigned long long *>(rec) + 2 * c + 1,
+                                               tag ^ (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        };
+                        put(0, k.hokt9); put(1, k.lhokt9); put(2, k.beta); put(3, k.bp3); put(4, k.bp2); put(5, k.alpha);
+                        put(6, k.lx0); put(7, k.xmerge); put(8, k.cbb); put(9, k.cpl); put(10, k.kap); put(11, k.peak);
+                        put(12, __longlong_as_double((long long)(((unsigned long long)(unsigned int)k.pad << 32) | (unsigned int)k.status)));
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) put(13 + i, p[i]);
+                        put(18, 4.0 * lo[2]); put(19, lo[3]); put(20, pen_u); put(21, pen_g);
+                    } else {
+                        *reinterpret_cast<WalkerK *>(rec) = k;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) rec[13 + i] = p[i];
+                        rec[18] = 4.0 * lo[2];                    // (dim - 1) ln z
+                        rec[19] = lo[3];                          // ln u
+                        rec[20] = pen_u;
+                        rec[21] = pen_g;
+                    }
+                }
+                STAMPD(10, pen_u + pen_g);
+            }
+            if constexpr (FLOW) pend_j = j;
+            }   // half-steps of a one-launch run
+            STAMP(6);
+            return;
+        }
+    }
+
     // PERSIST: a.persist half-steps in this launch; otherwise one pass with the launch's values
     unsigned xcc = 0;
     if (PERSIST) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u; }
     const int niter = PERSIST ? a.persist : 1;
+    // SMODE 5, wave 0: the workgroup's two walkers (one of each half) as they are, element l in
+    // lane l < 8 -- nobody else writes them; and the row whose word is still to be published
+    double own_half[2] = {0.0, 0.0};
+    int pend_row = -1, pend_it = 0;
     for (int it = 0; it < niter; ++it) {
     const int L_step = PERSIST ? a.step + (it >> 1) : a.step, L_half = PERSIST ? (it & 1) : a.half;
     const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) : a.s_begin;
@@ -274,8 +657,126 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *const L_chain6 = (PERSIST && a.chain6) ? a.chain6 + (size_t)it * a.n * 6 : a.chain6;
     unsigned int *const L_nacc = PERSIST ? a.nacc + (size_t)L_half * a.n : a.nacc;
 
+    // SMODE 4, a mover: its proposal record was written by the launch before; wave 0 picks the
+    // candidate its partner's accept flag says and lays it out in LDS as phase 1 would have
+    double own_reg = 0.0;          // lane l < 8 of wave 0: element l of the walker's state row
+    if constexpr (SPEC) {
+        if (wave == 0) {
+            const int row = L_s_begin + w0;                   // one ensemble, one walker per workgroup
+            const FlowView fv = flow_view(a.spec, a.nw);
+            const double *rec = FLOW ? fv.rec + ((size_t)row * kFlowSlots + ((flow_cnt(L_half, it) + 1) % kFlowSlots)) * 2 * kFlowRec
+                                     : a.spec + (size_t)row * 2 * kSpecRec;
+            double r0 = 0.0, r1 = 0.0, flag = 0.0;
+            if constexpr (FLOW) {
+                STAMP(11);
+                // SMODE 5: this half-step starts when both candidates of the walker's record are
+                // there and its partner's move of the half-step before is decided (and nobody is
+                // more than four half-steps behind: the state slots and the records are reused)
+                double zz, u3;
+                int pj;
+                stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
+                const int prow = L_c_begin + pj;
+                const int m_par = flow_cnt(L_half ^ 1, it);
+                if (pend_row >= 0) {
+                    // the row this wave wrote a half-step ago has had the time of the draw to land:
+                    // now its word, for the workgroups that work ahead from it
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) {
+                        __hip_atomic_store(fv.seq + pend_row, (unsigned long long)(pend_it + 1), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
+                    unsigned long long v = 0;
+                    long long spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        ++spins;
+                        if (spins > (1ll << 22) ||
+                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            atomicMax(a.errflag, 9);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    return v;
+                };
+                // the record, both candidates: lane c < 22 takes element c when its check word fits
+                {
+                    const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
+                    const int c = lane < kFlowRecN ? lane : 0;
+                    long long spins = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (lane < kFlowRecN) {
+                            r0 = ld_dev(rec + 2 * c);
+                            r1 = ld_dev(rec + kFlowRec + 2 * c);
+                            const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + 2 * c + 1,
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const unsigned long long t1 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + kFlowRec + 2 * c + 1,
+                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (t0 ^ (unsigned long long)__double_as_longlong(r0)) == tag &&
+                                 (t1 ^ (unsigned long long)__double_as_longlong(r1)) == tag;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        ++spins;
+                        if (spins > (1ll << 22) ||
+                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            atomicMax(a.errflag, 9);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (it < 2) {
+                    if (lane < 8) own_reg = ld_dev(fv.st + (size_t)row * 8 + lane);
+                } else {
+                    own_reg = L_half ? own_half[1] : own_half[0];
+                }
+                const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
+                const unsigned long long pv =
+                    spin(lane == 0 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots) : fv.done + ((it - 4) & 7) * 16,
+                         lane == 0 ? need_p : (unsigned long long)a.n * (unsigned long long)(((it - 4) >> 3) + 1),
+                         (lane == 0 && need_p > 0) || (lane == 1 && it >= 4), lane == 0 ? 1 : 0);
+                flag = (need_p > 0 && (__shfl(pv, 0) & 1ull)) ? 1.0 : 0.0;
+                STAMP(12);
+            } else {
+            const double *st8 = a.spec + (size_t)a.nw * 2 * kSpecRec;
+            // everything this wave needs is asked for at once, ahead of the other waves' table
+            // copies in the CU's queue -- all the other half's accept flags too (the partner is
+            // known only after the draw; at most 256 walkers per half: the host checks)
+            const double *flg = st8 + (size_t)2 * a.nw * 8 + (size_t)((a.spec_cfg >> 1) & 1) * a.nw + L_c_begin;
+            double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+            if (lane < kSpecRec) { r0 = rec[lane]; r1 = rec[kSpecRec + lane]; }
+            if (lane < 8) own_reg = st8[((size_t)(a.spec_cfg & 1) * a.nw + row) * 8 + lane];
+            if (lane < a.c_count) f0 = flg[lane];
+            if (lane + 64 < a.c_count) f1 = flg[lane + 64];
+            if (lane + 128 < a.c_count) f2 = flg[lane + 128];
+            if (lane + 192 < a.c_count) f3 = flg[lane + 192];
+            double zz, u3;
+            int pj;
+            stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
+            const int fs = pj >> 6;
+            flag = __shfl(fs == 0 ? f0 : (fs == 1 ? f1 : (fs == 2 ? f2 : f3)), pj & 63);
+            }
+            const double v = flag != 0.0 ? r1 : r0;
+            double *wkd = reinterpret_cast<double *>(wk);
+            if (lane < 13) wkd[lane] = v;
+            else if (lane < 18) prop[lane - 13] = v;          // the proposal
+            else if (lane == 18) prop[5] = v;                 // (dim - 1) ln z
+            else if (lane == 19) prop[7] = v;                 // ln u
+            else if (lane == 20) pen[0] = v;
+            else if (lane == 21) pen[1] = v;
+            if (lane == 5) prop[6] = own_reg;                 // the walker's current lnprob
+            STAMPD(10, v);
+        }
+    }
     // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
     // (the host guarantees blockDim.x >= 16 W)
+    if constexpr (!SPEC)
     if (const int j = tid >> 4; j < W) {
         const bool lead = (tid & 15) == 0;                    // the lane that writes to LDS
         const int w = w0 + j;
@@ -291,16 +792,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // half, proposal q = c - z (c - s)
                 const int src = w / a.m_count, loc = w - src * a.m_count;
                 const int row = src * a.nw_src + L_s_begin + loc;
-                unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * L_step + L_half), 0u, 0u};
-                philox4x32(c4, (unsigned int)L_seed, (unsigned int)(L_seed >> 32));
-                const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) *
-                                  (1.0 / 9007199254740992.0);
-                const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
-                const double u3 = ((double)c4[3] + 0.5) * (1.0 / 4294967296.0);
-                const double sq = (a.stretch_a - 1.0) * u1 + 1.0;
-                const double zz = sq * sq / a.stretch_a;
-                int pj = (int)(u2 * (double)a.c_count);
-                if (pj >= a.c_count) pj = a.c_count - 1;
+                double zz, u3;
+                int pj;
+                stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
                 const double *srow = a.pos6 + (size_t)row * 6;
                 const double *crow = a.pos6 + (size_t)(src * a.nw_src + L_c_begin + pj) * 6;
                 if (PERSIST && it > 0) {
@@ -348,7 +842,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 for (int i = 0; i < 5; ++i) {
                     const double cv = xchg ? ld_sys(crow + i) : (PERSIST ? ld_dev(crow + i) : crow[i]);
                     const double sv = xchg ? ld_sys(srow + i) : (PERSIST ? ld_dev(srow + i) : srow[i]);
-                    p[i] = cv - zz * (cv - sv);
+                    p[i] = stretch_q(cv, sv, zz);
                 }
                 srow5 = xchg ? ld_sys(srow + 5) : (PERSIST ? ld_dev(srow + 5) : srow[5]);
                 double lo[4];
@@ -375,56 +869,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     lT = lo[0]; lL = lo[1];
                 }
             }
-            bool ok = true;                                   // likelihood.py:643-670
-#pragma unroll
-            for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
-            if (!ok) {
-                k.status = ROW_BELOW_LOWLIM;
-            } else if (!finite5(p)) {
-                // NaN passes the reference's `<` gate and its SED arithmetic then
-                // yields NaN; +-inf does the same.  Short-cut both to NaN.
-                k.status = ROW_NONFINITE;
-            } else {
-                SedScalars s;
-                k.status = sed_prologue<OPTHIN, NOALPHA, true>(p[0], p[1], p[3], p[4], lT, lL,
-                                                               a.nunorm, a.lnunorm, s, &k.pad);
-                STAMPD(9, s.normfac);
-                if (k.status == ROW_OK) {
-                    make_walker_k<OPTHIN, NOALPHA>(p[1], p[3], s, k);
-                    if (a.has_uplim | a.has_gprior) {          // one test when there are none
-                    // _uplim_prior, likelihood.py:672-717
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if (((a.has_uplim >> i) & 1u) && p[i] > a.uplim[i]) {
-                            double lw = 0.02 * (a.uplim[i] - a.lowlim[i]);
-                            double d = p[i] - a.uplim[i];
-                            pen_u -= 0.5 * d * d / (lw * lw);
-                        }
-                    double peak = 0.0;
-                    if (((a.has_uplim | a.has_gprior) >> 5) & 1u) {
-                        int pst;
-                        peak = sed_peak_wave<OPTHIN, true>(p[0], p[1], k.lx0, s.hcokt, pst);
-                        if (pst != ROW_OK) k.status = pst;
-                        k.peak = peak;
-                    }
-                    if (((a.has_uplim >> 5) & 1u) && peak > a.uplim[5]) {  // :710-715
-                        double lw = 0.02 * a.uplim[5], d = peak - a.uplim[5];
-                        pen_u -= 0.5 * d * d / (lw * lw);
-                    }
-                    // _gprior, likelihood.py:719-752
-#pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        if ((a.has_gprior >> i) & 1u) {
-                            double d = p[i] - a.gmean[i];
-                            pen_g -= 0.5 * a.givar[i] * d * d;
-                        }
-                    if ((a.has_gprior >> 5) & 1u) {
-                        double d = peak - a.gmean[5];
-                        pen_g -= 0.5 * a.givar[5] * d * d;
-                    }
-                    }
-                }
-            }
+#include "mbb_walker_consts.inc"
         }
         STAMPD(10, pen_u + pen_g);
         if (lead) {
@@ -496,6 +941,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         }
     }
     STAMP(3);
+#ifdef MBB_STAMPS       // every wave's arrival at the second barrier (slots 17..31: waves 1..15)
+    if ((tid & 63) == 0 && tid > 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + 16 + (tid >> 6)] = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- phase 3: one wave per walker, one lane per band (likelihood.py:821-834)
     // Whatever does not depend on the segment sums is fetched before the barrier, for
@@ -598,6 +1046,13 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         } else if (a.model_flux) {
             for (int b = lane; b < nb; b += 64) a.model_flux[(size_t)w * nb + b] = __builtin_nan("");
         }
+        double old5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if constexpr (SPEC) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) old5[i] = __shfl(own_reg, i);
+        }
+        int flow_accept = 0;
+        double flow_r = 0.0;
         if (lane == 0) {
             double r;
             if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
@@ -650,6 +1105,34 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                                 __hip_atomic_store(x.xflag[pr] + x.xrank, xseq, __ATOMIC_RELEASE,
                                                    __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                } else if (FLOW) {
+                    // the decision first -- all the partner's next mover waits for --, then the row
+                    // as it is after this half-step, write-through, to its next slot; the row's
+                    // own word follows at the start of the next half-step, when the stores have
+                    // landed.  (pos6, counts and chain are for the host: plain stores.)
+                    const FlowView fv = flow_view(a.spec, a.nw);
+                    const int m_new = flow_cnt(L_half, it) + 1;
+                    __hip_atomic_store(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
+                                       2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    double *dst = fv.st + ((size_t)(m_new % kFlowSlots) * a.nw + row) * 8;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) st_dev(dst + i, accept ? q[i] : old5[i]);
+                    st_dev(dst + 5, accept ? r : q[6]);
+                    if (accept) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) srow[i] = q[i];
+                        srow[5] = r;
+                        atomicAdd(&L_nacc[w], 1u);
+                    }
+                    if (L_chain6) {
+                        double *crow = L_chain6 + (size_t)w * 6;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : old5[i];
+                        crow[5] = accept ? r : q[6];
+                    }
+                    flow_accept = accept ? 1 : 0;
+                    flow_r = r;
                 } else if (PERSIST) {
                     // the row goes out write-through, the stores are waited for, then this
                     // walker is counted on its XCD's counter: the next half-step starts from that
@@ -667,6 +1150,29 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_fetch_add(a.gbar + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (SPEC) {
+                    // the row always goes to the OTHER slot of the state (the workgroups working
+                    // ahead read this one), with the flag the next launch picks candidates by
+                    double *dst = a.spec + (size_t)a.nw * 2 * kSpecRec +
+                                  ((size_t)((a.spec_cfg & 1) ^ 1) * a.nw + row) * 8;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) dst[i] = accept ? q[i] : old5[i];
+                    dst[5] = accept ? r : q[6];
+                    dst[6] = accept ? 1.0 : 0.0;
+                    a.spec[(size_t)a.nw * 2 * kSpecRec + (size_t)2 * a.nw * 8 + (size_t)((a.spec_cfg & 1) ^ 1) * a.nw + row] =
+                        accept ? 1.0 : 0.0;
+                    if (accept) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) srow[i] = q[i];
+                        srow[5] = r;
+                        atomicAdd(&L_nacc[w], 1u);
+                    }
+                    if (L_chain6) {
+                        double *crow = L_chain6 + (size_t)w * 6;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : old5[i];
+                        crow[5] = accept ? r : q[6];
+                    }
                 } else {
                 if (accept) {
 #pragma unroll
@@ -685,6 +1191,21 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             if (lnl_out) *lnl_out = r;
             if (status_out) *status_out = a.debug ? (st | ((FIRST ? pad_first : wk[j].pad) << 8)) : st;
         }
+        if constexpr (FLOW) {
+            // the walker as it is now stays in this wave's registers for its next half-step
+            const int acc_u = __builtin_amdgcn_readfirstlane(flow_accept);
+            const double r_u = __shfl(flow_r, 0);
+            double nv = own_reg;
+            if (acc_u) {
+                double t = r_u;                                // lane 5: lnprob
+#pragma unroll
+                for (int i = 0; i < 5; ++i) t = (lane == i) ? q_first[i] : t;
+                nv = lane < 6 ? t : nv;
+            }
+            if (L_half) own_half[1] = nv; else own_half[0] = nv;
+            pend_row = row_first;
+            pend_it = it;
+        }
     };
     if (wave < W) epilogue(wave, std::true_type{});
     if (W > nwave)
@@ -693,9 +1214,35 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     STAMP(6);
 }
 
+// SMODE 4: both slots of the double-buffered state from the sampler's rows, accept flags clear.
+static __global__ void k_spec_init(const double *pos6, double *spec, int nw)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw * 8) return;
+    const int row = i >> 3, e = i & 7;
+    const double v = e < 6 ? pos6[(size_t)row * 6 + e] : 0.0;
+    double *st8 = spec + (size_t)nw * 2 * kSpecRec;
+    st8[i] = v;
+    st8[(size_t)nw * 8 + i] = v;
+    if (e == 0) { st8[(size_t)nw * 16 + row] = 0.0; st8[(size_t)nw * 17 + row] = 0.0; }   // the compact accept flags
+}
+
+// SMODE 5: slot 0 of the state from the sampler's rows (accept flags clear), all words zero.
+static __global__ void k_flow_init(const double *pos6, double *spec, int nw)
+{
+    const FlowView fv = flow_view(spec, nw);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nw * 8) {
+        const int row = i >> 3, e = i & 7;
+        fv.st[i] = e < 6 ? pos6[(size_t)row * 6 + e] : 0.0;
+    }
+    const int nwords = nw * (3 + kFlowSlots) + 8 * 16;        // seq, rseq, done, mseq are contiguous
+    for (int k = i; k < nwords; k += gridDim.x * blockDim.x) fv.seq[k] = 0ull;
+}
+
 // Sharded run, one-hop exchange: holds the stream until every peer has posted launch
 // number `seq` (its moved rows are then all in this rank's copy of the ensemble).  One wave.
-__global__ void k_xchg_wait(const unsigned long long *mine, int xn, int xrank, unsigned long long seq,
+static __global__ void k_xchg_wait(const unsigned long long *mine, int xn, int xrank, unsigned long long seq,
                             long long spin_max, int *errflag)
 {
     const int l = threadIdx.x;

@@ -1001,7 +1001,7 @@ def test_cli_config1(mbb, tmp_path):
                              "--seed", "5", "--get_peaklambda"])
     assert rc == 0
     d = np.load(out)
-    assert d["chain"].shape == (50, 200, 5) and d["peaklambda"].shape == (50, 200)
+    assert d["chain"].shape == (50, 200, 5) and d["peaklam"].shape == (50, 200)
     med = np.median(d["chain"].reshape(-1, 5), axis=0)
     # 5 points leave T and beta strongly degenerate: check the fit, not the marginals
     assert 6.0 < med[0] < 20.0 and abs(med[4] - 40.0) < 8.0
@@ -1218,6 +1218,7 @@ def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
             like = mbb.likelihood(response=True, opthin=opthin, noalpha=noalpha)
             like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
             like.context.set_option("persistent_sampler", persistent)
+            like.context.set_option("lookahead_sampler", 0)       # the reference form: one plain launch per half-step
             p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(4).normal(size=(250, 5)))
             s = mbb.DeviceEnsembleSampler(250, 5, like, seed=77)
             a = s.run_mcmc(p0, 40)
@@ -1235,7 +1236,112 @@ def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
     out = []
     for persistent in (1, 0):
         like.context.set_option("persistent_sampler", persistent)
+        like.context.set_option("lookahead_sampler", 0)
         s = mbb.DeviceEnsembleSampler(600, 5, like, seed=5)
         out.append(s.run_mcmc(p0, 6)[:2] + (s.chain.copy(),))
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+def _sampler_forms(ctx):
+    """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
+    return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
+            ("look-ahead launches", {"lookahead_sampler": 1, "flow_sampler": 0}),
+            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1})]
+
+
+def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
+    """The device sampler prepares the next half-step's proposals (draw, SED constructor,
+    penalties) ahead of time, for both outcomes of each partner's pending move -- in extra
+    workgroups of every launch (k_lnlike SMODE 4) or, by default, in ONE launch per run whose
+    half-steps hand over row by row (SMODE 5).  Same draws and same arithmetic, so chain,
+    lnprob, final state and acceptance counts must be bitwise those of the plain train of one
+    launch per half-step: every model variant, stored and unstored runs in sequence, shapes of
+    the working-ahead workgroups other than the host's choice."""
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    for name, opthin, noalpha in VARIANTS:
+        k = "cfg2/" + name
+        res = []
+        for form, opts in _sampler_forms(None):
+            like = mbb.likelihood(response=True, opthin=opthin, noalpha=noalpha)
+            like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+            for o, v in opts.items():
+                like.context.set_option(o, v)
+            p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(4).normal(size=(250, 5)))
+            s = mbb.DeviceEnsembleSampler(250, 5, like, seed=77)
+            a = s.run_mcmc(p0, 40)
+            b = s.run_mcmc(None, 25, storechain=False)
+            s.advance_async(30); like.context.sync()
+            c = s.run_mcmc(None, 7)
+            res.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+        for form, r in zip(_sampler_forms(None)[1:], res[1:]):
+            for x, y in zip(res[0], r):
+                assert np.array_equal(x, y), (name, form[0])
+        assert res[0][6].shape == (250, 47, 5) and 0.1 < res[0][8].mean() / 102 < 0.9
+    # other shapes of the workgroups that work ahead
+    like = mbb.likelihood(response=True)
+    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(5).normal(size=(100, 5)))
+    ref = None
+    for flow, rows, waves in ((0, 0, 0), (0, 1, 16), (0, 4, 4), (0, 2, 3), (1, 0, 0), (1, 2, 4), (1, 4, 16), (1, 1, 7)):
+        ctx = like.context
+        ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", flow)
+        ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
+        s = mbb.DeviceEnsembleSampler(100, 5, like, seed=3)
+        out = s.run_mcmc(p0, 30)[:2] + (s.chain.copy(), s.naccepted.copy())
+        if ref is None:
+            ctx.set_option("lookahead_sampler", 0)
+            s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=3)
+            ref = s0.run_mcmc(p0, 30)[:2] + (s0.chain.copy(), s0.naccepted.copy())
+        for x, y in zip(ref, out):
+            assert np.array_equal(x, y), (flow, rows, waves)
+    like.context.set_option("lookahead_rows", 0); like.context.set_option("lookahead_waves", 0)
+
+
+def test_lookahead_sampler_forms_with_priors_limits_and_long_runs(mbb, g_lnl):
+    """The same equality where the working-ahead path does more than the constructor: upper
+    limits and Gaussian priors on parameters and on the peak wavelength (its root solve runs in
+    the look-ahead rows), walkers driven against a lower limit (rejected proposals, -inf), a
+    covariance matrix, an ensemble of 10, one too large for either look-ahead form (fall-back),
+    and a run longer than the 4096 steps one launch covers."""
+    bands = [str(b) for b in g_lnl["cfg2/bands"]]
+    flux, unc = g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"]
+
+    def run(configure, nw, nsteps, p_center, spread, seed):
+        out = []
+        for form, opts in _sampler_forms(None):
+            like = mbb.likelihood(response=True)
+            like.set_phot(bands, flux, unc)
+            configure(like)
+            for o, v in opts.items():
+                like.context.set_option(o, v)
+            p0 = np.array(p_center) * (1.0 + spread * np.random.RandomState(seed).normal(size=(nw, 5)))
+            s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=seed)
+            pos, lnp, _ = s.run_mcmc(p0, nsteps)
+            out.append((pos, lnp, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+        for form, r in zip(_sampler_forms(None)[1:], out[1:]):
+            for x, y in zip(out[0], r):
+                assert np.array_equal(x, y), form[0]
+        return out[0]
+
+    def priors(like):
+        like.set_uplim("T", 14.0); like.set_uplim("beta", 2.2); like.set_uplim("peaklam", 260.0)
+        like.set_gaussian_prior("beta", 1.9, 0.2); like.set_gaussian_prior("peaklam", 240.0, 15.0)
+        like.set_gaussian_prior("alpha", 3.2, 0.5)
+    r = run(priors, 60, 60, [12.0, 1.8, 600.0, 3.0, 40.0], 0.03, 21)
+    assert np.isfinite(r[1]).all()
+
+    def lowlim(like):
+        like.set_lowlim("T", 11.9); like.set_lowlim("beta", 1.75)
+    r = run(lowlim, 40, 50, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 22)
+    assert 0.0 < r[4].mean() / 50 < 0.6                     # many proposals fall below the limits
+
+    def cov(like):
+        nb = len(bands)
+        c = np.diag(np.asarray(unc) ** 2) + 0.2 * np.outer(unc, unc)
+        like.set_cov(c)
+    run(cov, 30, 40, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 23)
+    run(lambda like: None, 10, 80, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 24)
+    run(lambda like: None, 520, 5, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 25)      # 260 movers: too many, plain train
+    r = run(lambda like: None, 12, 4200, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 26)
+    assert r[2].shape == (12, 4200, 5)
