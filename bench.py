@@ -8,11 +8,15 @@ Workload (BASELINE.json configs[1] / configs[2], SURVEY.md 8d "cfg2/cfg3"):
 2209 quadrature samples), optically thick + alpha model, 250 walkers per GPU.
 
 One *step* is one MCMC step of the whole ensemble (metric M2): the
-device-resident stretch-move sampler advances 250 N walkers, two DEPENDENT launches
-per step (emcee's two half-steps, mbb_fit.py:80-81 / :533), each evaluating the
-fused likelihood of its half; with N > 1 ranks the ensemble is sharded (125 moving
-walkers per GPU per launch) and the moved state rows are exchanged after every
-launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
+device-resident stretch-move sampler advances 250 N walkers, two DEPENDENT half-steps
+per step (emcee's, mbb_fit.py:80-81 / :533), each evaluating the fused likelihood of
+its half.  On one GPU a run is ONE launch per 4096 steps (k_lnlike SMODE 5): 125
+workgroups move the walkers, 125 more prepare the next half-step's proposals (draw, SED
+constructor, penalties) for both outcomes of each partner's pending move, and a row's
+half-step starts when the rows it depends on are done -- the same chain, bit for bit, as
+one launch per half-step (tests/test_gpu_parity.py).  With N > 1 ranks the ensemble is
+sharded (125 moving walkers per GPU per launch, one launch per half-step) and the moved
+state rows are exchanged after every launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
 into every rank's copy through hipIpc mappings), or by an in-place ncclAllGather over
 RCCL (--exchange rccl; also the automatic fall-back).  Positions live in HBM for the whole run: there is no host round
 trip inside the timed region.  `value` = walker-likelihood evaluations per second of
@@ -248,9 +252,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2/cfg3: 8-band PACS+SPIRE+SCUBA2_850+Bolocam passband integration "
                                    "(NQ=2209), thick+alpha, one ensemble of 250 walkers per GPU advanced by "
-                                   "the device-resident stretch move, two dependent launches per step",
+                                   "the device-resident stretch move, two dependent half-steps per step",
                        "walkers_per_gpu": NW_PER_GPU, "walkers": NW_PER_GPU * world, "bands": 8,
-                       "nq": 2209, "launches_per_step": 2}}
+                       "nq": 2209, "half_steps_per_step": 2}}
 
     def fail(code, **kw):
         """A failed run still prints its line (rank 0) and leaves with a non-zero status."""
@@ -417,11 +421,23 @@ def main():
                     # (sharded: the counts of this rank's own walkers)
                     "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps),
                     "ranks_agree": ranks_agree})
-        k_us = stream_ms * 1e3 / (2 * args.steps)       # launch slot of the dominant kernel
-        kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
-        out["kernel_avg_us"] = k_us
+        k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
+        form = ctx.info("last_kernel_form")
+        out["config"] = dict(out["config"])
+        if form == 5:
+            nlaunch = (args.steps + 4095) // 4096
+            kern_label = ("k_lnlike<thick,alpha,one-launch look-ahead run,staged>: %d workgroups move walkers, %d work "
+                          "ahead" % (half, ctx.info("last_workgroups_ahead")))
+            out["config"]["sampler_form"] = ("one launch per 4096 steps (k_lnlike SMODE 5): the timed region is %d launch(es) "
+                                             "of %d half-steps" % (nlaunch, 2 * args.steps))
+            out["kernel_avg_us"] = stream_ms * 1e3 / nlaunch
+        else:
+            kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
+            out["config"]["sampler_form"] = "one launch per half-step (k_lnlike SMODE %d)" % form
+            out["kernel_avg_us"] = k_us
+        out["half_step_us"] = k_us
         if world == 1 and not args.no_extras:
-            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb))
+            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form))
         elif world > 1:
             alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
             out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None,
@@ -444,7 +460,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
+def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     """Everything on the line besides the timed region (rank 0, one GPU)."""
     import mbb_emcee_amd as mbb
     out = {}
@@ -500,6 +516,25 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
     last = props[(2 * (ksteps - 1) + 1) % (2 * NSETS)]
     assert np.array_equal(like(last), got, equal_nan=True)
 
+    # ---- the same chain as a train of launches, one per half-step (what round 1 and the
+    # first half of round 2 timed), and with the look-ahead as extra workgroups of each launch
+    forms = {}
+    for name, opts in (("one_launch_per_half_step", {"lookahead_sampler": 0}),
+                       ("one_launch_per_half_step_with_lookahead", {"lookahead_sampler": 1, "flow_sampler": 0})):
+        for o, v in opts.items():
+            ctx.set_option(o, v)
+        s2 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
+        s2.run_mcmc(pos, 60, storechain=False)
+        s2.advance_async(100); ctx.sync()
+        f0, f1 = ctx.event(), ctx.event()
+        ctx.record(f0); s2.advance_async(ksteps); ctx.record(f1); ctx.sync()
+        forms[name] = {"stream_us_per_step": ctx.elapsed_ms(f0, f1) * 1e3 / ksteps,
+                       "evals_per_s": NW_PER_GPU * ksteps / (ctx.elapsed_ms(f0, f1) * 1e-3)}
+        del s2
+    ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1)
+    forms["note"] = "the other forms of the device sampler, same chain bit for bit (stream time, HIP events)"
+    out["other_sampler_forms"] = forms
+
     # ---- the empirical roof of the sample arithmetic, measured now
     sec, slots, roof_mhz = ctx.roof_probe(TRUTH, reps=40)
     nchunk = ctx.info("nchunk")
@@ -512,28 +547,61 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb):
                       "constants -- the exp + two degree-7 polynomials per sample and nothing else" % nchunk,
              "probe_seconds": sec, "probe_shader_clock_mhz": roof_mhz, "samples_per_launch": half * nq, "lane_slots_per_launch": slots_per_launch}
 
-    # ---- rooflines of the dominant kernel (the sampler's 125-walker launch)
-    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", "k_lnlike<false, false, 1, true>")
+    # ---- rooflines of the dominant kernel.  The one-launch run's launches cover different
+    # numbers of half-steps, so its counters are taken per half-step (all launches of the
+    # profiled run / the half-steps they cover: tools/summarize_valu.py) and priced against
+    # the half-step time measured above; a launch of the timed region is 2 K of those.
+    kname = "k_lnlike<false, false, %d, true>" % form
+    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", kname)
+    per_launch = 1.0
+    if pm and form == 5 and "counters_per_half_step" in pm:
+        pm = dict(pm)
+        pm["counters_per_launch"] = pm["counters_per_half_step"]
+        per_launch = 2.0 * min(args.steps, 4096)
+    elif form == 5:
+        pm = None
     roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
+    if roof and form == 5:
+        roof["unit_of_counts"] = "one half-step (125 walkers moved, 250 proposals prepared ahead)"
+        roof["half_steps_per_launch"] = per_launch
+        roof["fp64_flops_per_launch"] = roof["fp64_flops_per_launch"] * per_launch
+        roof["fp64_flops_per_half_step"] = roof["fp64_flops_per_launch"] / per_launch
+        roof["valu_wave_instructions_per_half_step"] = roof.pop("valu_wave_instructions_per_launch")
+        roof["fp64_wave_instructions_per_half_step"] = roof.pop("fp64_wave_instructions_per_launch")
+        roof["kernel_us"] = k_us * per_launch
+        roof["half_step_us"] = k_us
+        roof["note"] = ("the counts include the proposals prepared for the outcome that did not happen (half of the "
+                        "constructor work) and the instructions spent polling")
     alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-    traffic, traffic_src = measured_traffic("k_lnlike<false, false, 1, true>")
+    traffic, traffic_src = measured_traffic(kname)
+    if form == 5:
+        f = newest_profile("pmc_traffic*.json")
+        traffic = None
+        try:
+            for k, v in json.load(open(f))["kernels"].items():
+                if kname in k:
+                    traffic, traffic_src = v.get("traffic_bytes_per_half_step"), os.path.relpath(f, ROOT)
+        except Exception:
+            pass
     hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
            "traffic_ratio": (traffic / alg_bytes) if traffic else None, "traffic_source": traffic_src,
-           "algorithmic_bytes_per_launch": alg_bytes,
-           "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per launch.  The "
-                   "traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
-                   "kernel code reaching each of the 8 XCD L2s once per launch"}
+           "algorithmic_bytes_per_launch": alg_bytes * per_launch, "algorithmic_bytes_per_half_step": alg_bytes,
+           "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per half-step.  "
+                   + ("Per half-step; the tables are staged once per launch, what crosses the fabric every half-step "
+                      "is the hand-over between workgroups (records, rows, the words they poll)" if form == 5 else
+                      "The traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
+                      "kernel code reaching each of the 8 XCD L2s once per launch")}
     if roof is None:
         roof = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": None, "note": "no committed PMC summary found"}
     roof["traffic"] = traffic
     roof["kernel_avg_us"] = k_us
     roof["sample_arithmetic"] = arith
-    roof["why_far_below"] = ("a 125-walker launch is latency: one workgroup per walker on 125 of 256 CUs; kernel "
-                             "arguments and the parameter rows, then the per-walker prologue (one dependent chain, "
-                             "about a third of the kernel), 9 chunks of samples per SIMD, the epilogue, and 1-2 us "
-                             "of dispatch; see cfg5 for the same kernel when the chip is full")
+    roof["why_far_below"] = ("a half-step of 125 walkers is latency: one workgroup per walker, 9 chunks of samples per "
+                             "SIMD between two workgroup barriers (bound by the LDS reads of the polynomial tables), the "
+                             "band sums and the accept test of one lane, then ~0.6 us until the partner's workgroup on "
+                             "another XCD sees the decision; see cfg5 for the same arithmetic when the chip is full")
     out["roofline"] = roof
     out["roofline_hbm"] = hbm
 

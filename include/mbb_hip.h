@@ -190,7 +190,13 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug", "persistent_sampler" (1: a single-GPU sampler run of up to one
  * walker per CU is ONE launch, its half-steps handing over inside the kernel -- same chains,
- * measured slower than the default 0, one launch per half-step), "xchg_spin_max" (polls before a launch waiting for a peer gives up). */
+ * measured slower than the default 0), "xchg_spin_max" (polls before a launch waiting for a peer
+ * gives up); the look-ahead forms of the single-GPU sampler, same chains bit for bit:
+ * "lookahead_sampler" (default 1; 0: the plain train of one launch per half-step),
+ * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row;
+ * 0: the next half-step's proposals prepared by extra workgroups of every launch),
+ * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
+ * workgroup among those that work ahead).  mbb_get_info "last_kernel_form" says which form ran. */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
 int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 

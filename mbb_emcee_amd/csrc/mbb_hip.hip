@@ -155,7 +155,7 @@ struct mbb_ctx {
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
     size_t lds_granted[48] = {};   // dynamic-LDS ceiling already requested, per kernel variant
-    long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0;
+    long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
     ncclComm_t_ comm = nullptr;
@@ -601,6 +601,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     {
         const int smode = !sl ? 0 : (sl->spec ? (sl->persist ? 5 : 4) : (sl->persist ? 3 : (sl->xseq ? 2 : 1)));
         const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 12 + smode * 2 + (stage ? 1 : 0);
+        c->last_smode = smode;
+        c->last_ahead = smode >= 4 ? a.n_ahead : 0;
         vi_of_kernel = vi;
 #define MBB_VARIANTS(OT, NA)                                                                        \
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
@@ -1420,6 +1422,8 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_wpb")) *value = c->last_wpb;
     else if (!strcmp(name, "last_threads")) *value = c->last_threads;
     else if (!strcmp(name, "last_grid")) *value = c->last_grid;
+    else if (!strcmp(name, "last_kernel_form")) *value = c->last_smode;     // k_lnlike's SMODE of the last launch
+    else if (!strcmp(name, "last_workgroups_ahead")) *value = c->last_ahead;
     else if (!strcmp(name, "last_smem")) *value = c->last_smem;
     else if (!strcmp(name, "last_stage")) *value = c->last_stage;
     else if (!strcmp(name, "device")) *value = c->device;

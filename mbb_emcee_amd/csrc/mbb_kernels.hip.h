@@ -246,6 +246,14 @@ __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsign
 // half-step -- the body of a half-step is 7.6 us either way and a dependent kernel
 // boundary costs this launch train far less than the hand-off -- so the host uses it only
 // on request (option "persistent_sampler" 1); chains are bitwise the same.
+// 4 and 5, the look-ahead forms: the proposals of the NEXT half-step --
+// draw, SED constructor, penalties -- are prepared while this one is being decided, for both
+// outcomes of each partner's pending move, by workgroups of their own (blockIdx < n_ahead); a
+// mover picks the record its partner's accept flag points at and starts at the quadrature.
+// 4: one launch per half-step, the records cross the kernel boundary.  5: one launch per run;
+// a row's half-step starts when the rows it depends on are done (FlowView: per-row words
+// polled with bounded spins, write-through stores, no grid-wide barrier).  Bitwise the chain
+// of SMODE 1; 9.9 us per step against 15.6 (SMODE 1) and 15.3 (SMODE 4).
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
@@ -299,9 +307,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMPD(i, dep) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) { asm volatile("" ::"v"(dep)); a.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
     if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + 7] = t_entry;
+// every wave's own stamp number `page` (1..7): slot 16 + wave of block blockIdx + 256 page
+#define WSTAMP(page) do { if ((tid & 63) == 0 && a.stamps && blockIdx.x < 256) a.stamps[(blockIdx.x + 256 * (page)) * 32 + 16 + (tid >> 6)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WSTAMPD(page, dep) do { asm volatile("" ::"v"(dep)); WSTAMP(page); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMPD(i, dep) do { } while (0)
+#define WSTAMP(page) do { } while (0)
+#define WSTAMPD(page, dep) do { } while (0)
 #endif
     STAMP(0);
 
@@ -411,6 +424,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     const int nunit = W * nun;
     int4 us_first = make_int4(0, 0, 0, 0);
     if (wave < nunit) us_first = a.unit_tab[wave % nun];
+    int tail_first = -1;                  // ... and (a one-launch run) should it be a tail chunk, the slot of this lane's row
+    if (PERSIST && wave < nunit && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
 
     // ---- SMODE 4, the workgroups that work ahead -------------------------------------------
     // Row (16 lanes) `pair` = (walker of the half that moves NEXT, candidate): the walker's
@@ -677,71 +692,62 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
                 const int prow = L_c_begin + pj;
                 const int m_par = flow_cnt(L_half ^ 1, it);
-                if (pend_row >= 0) {
-                    // the row this wave wrote a half-step ago has had the time of the draw to land:
-                    // now its word, for the workgroups that work ahead from it
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) {
-                        __hip_atomic_store(fv.seq + pend_row, (unsigned long long)(pend_it + 1), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-                auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
-                    unsigned long long v = 0;
-                    long long spins = 0;
-                    for (;;) {
-                        bool ok = true;
-                        if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                        ++spins;
-                        if (spins > (1ll << 22) ||
-                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                            atomicMax(a.errflag, 9);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    return v;
-                };
-                // the record, both candidates: lane c < 22 takes element c when its check word fits
-                {
-                    const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
-                    const int c = lane < kFlowRecN ? lane : 0;
-                    long long spins = 0;
-                    for (;;) {
-                        bool ok = true;
-                        if (lane < kFlowRecN) {
-                            r0 = ld_dev(rec + 2 * c);
-                            r1 = ld_dev(rec + kFlowRec + 2 * c);
-                            const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + 2 * c + 1,
-                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const unsigned long long t1 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + kFlowRec + 2 * c + 1,
-                                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok = (t0 ^ (unsigned long long)__double_as_longlong(r0)) == tag &&
+                // One loop, everything asked for in the same round: lane c < 22 the record's element c
+                // of both candidates (taken when its check word fits), lane 22 the partner's decision,
+                // lane 23 the lag guard.  When all of it is there already, that is one round trip.
+                const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
+                const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
+                const unsigned long long need_g = (unsigned long long)a.n * (unsigned long long)(((it - 4) >> 3) + 1);
+                const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
+                                                            : fv.done + ((it - 4) & 7) * 16;
+                const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= 4);
+                const int c = lane < kFlowRecN ? lane : 0;
+                unsigned long long pv = 0;
+                bool rec_ok = false, word_ok = !watch;
+                long long spins = 0;
+                for (;;) {
+                    if (lane < kFlowRecN && !rec_ok) {
+                        r0 = ld_dev(rec + 2 * c);
+                        r1 = ld_dev(rec + kFlowRec + 2 * c);
+                        const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + 2 * c + 1,
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long t1 = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rec) + kFlowRec + 2 * c + 1,
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rec_ok = (t0 ^ (unsigned long long)__double_as_longlong(r0)) == tag &&
                                  (t1 ^ (unsigned long long)__double_as_longlong(r1)) == tag;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                        ++spins;
-                        if (spins > (1ll << 22) ||
-                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                            atomicMax(a.errflag, 9);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
                     }
+                    if (watch && !word_ok) {
+                        pv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        word_ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g);
+                    }
+                    if (pend_row >= 0) {
+                        // The row this wave stored at the end of the half-step before has landed by
+                        // now -- memory operations of a wave complete in the order they were issued,
+                        // and the loads above came after those stores; the explicit wait costs nothing
+                        // then.  Its word, for the workgroups that work ahead from that row.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) {
+                            __hip_atomic_store(fv.seq + pend_row, (unsigned long long)(pend_it + 1), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        pend_row = -1;
+                    }
+                    if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0) break;
+                    ++spins;
+                    if (spins > (1ll << 22) ||
+                        ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicMax(a.errflag, 9);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
                 if (it < 2) {
                     if (lane < 8) own_reg = ld_dev(fv.st + (size_t)row * 8 + lane);
                 } else {
                     own_reg = L_half ? own_half[1] : own_half[0];
                 }
-                const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
-                const unsigned long long pv =
-                    spin(lane == 0 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots) : fv.done + ((it - 4) & 7) * 16,
-                         lane == 0 ? need_p : (unsigned long long)a.n * (unsigned long long)(((it - 4) >> 3) + 1),
-                         (lane == 0 && need_p > 0) || (lane == 1 && it >= 4), lane == 0 ? 1 : 0);
-                flag = (need_p > 0 && (__shfl(pv, 0) & 1ull)) ? 1.0 : 0.0;
+                flag = (need_p > 0 && (__shfl(pv, 22) & 1ull)) ? 1.0 : 0.0;
                 STAMP(12);
             } else {
             const double *st8 = a.spec + (size_t)a.nw * 2 * kSpecRec;
@@ -882,13 +888,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     STAMP(1);
     __syncthreads();
     STAMP(2);
+    WSTAMP(1);
 
     // ---- phase 2: passband quadrature (response.py:572-576) -----------------
     auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     const SampleTabs tabs = {s_tab, s_pb, s_pc};
-    auto do_unit = [&](const WalkerK &k, const int j, const int4 us) {
+    auto do_unit = [&](const WalkerK &k, const int j, const int4 us, const bool first_unit) {
         const int s = us.x, c0 = us.y, c1 = us.z;
         double acc = 0.0;
         int c = c0;
@@ -906,13 +913,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
             acc = fma(f, T_wt(i), acc);
         }
+        WSTAMPD(3, acc);
         if (us.w == 0) {
             acc = wave_sum(acc);
             if (lane == 0) partial[j * npart + s] = acc;
         } else if (us.w == 2) {                               // four band leftovers, one per row
             acc = row_sum(acc);
             if ((lane & 15) == 0) {
-                const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                const int sl = (PERSIST && first_unit) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
                 if (sl >= 0) partial[j * npart + sl] = acc;
             }
         } else {
@@ -926,7 +934,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         for (int j = wave; j < W; j += nwave) {
             if (wk[j].status != ROW_OK) continue;                 // wave-uniform
             const WalkerK k = wk[j];
-            for (int uu = 0; uu < nun; ++uu) do_unit(k, j, a.unit_tab[uu]);
+            for (int uu = 0; uu < nun; ++uu) do_unit(k, j, a.unit_tab[uu], false);
         }
     } else {
         // few walkers (an emcee half-step: one per workgroup): the units of a walker are
@@ -937,7 +945,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nun];
             if (wk[j].status != ROW_OK) continue;                 // wave-uniform
             const WalkerK k = wk[j];
-            do_unit(k, j, us);
+            WSTAMPD(2, k.cbb);
+            do_unit(k, j, us, u == wave);
+            WSTAMP(4);
         }
     }
     STAMP(3);

@@ -31,3 +31,14 @@ d = m[:, 17:32] - m[:, 2:3]
 print("movers: quadrature time of waves 1..15 (after the first barrier; wave 0: %d):" % med(m[:, 3] - m[:, 2]), [int(x) for x in np.median(d, axis=0)])
 ut = ctx.info("nunit")
 print("units per walker:", ut)
+big = np.zeros((256 * 8, 32), dtype=np.uint64)
+lib.mbb_stamps(ctx.h, big.ctypes.data_as(C.c_void_p), 256 * 8)
+bi = big.astype(np.int64)
+mv = slice(nb - nm, nb)
+pg = lambda p: bi[256 * p:256 * p + nb][mv][:, 16:32]
+t1, t2, t3, t4 = pg(1), pg(2), pg(3), pg(4)
+row = lambda x: [int(v) for v in np.median(x, axis=0)]
+print("per wave 0..15, medians over the movers: barrier-1 exit after wave 0's:", row(t1 - t1[:, :1]))
+print("  walker constants read:", row(t2 - t1))
+print("  sample arithmetic:", row(t3 - t2))
+print("  reduction + store:", row(t4 - t3))

@@ -13,6 +13,7 @@ export TMPDIR=/tmp
 cd $R
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SHORT="--steps 300 --warmup 50 --no-extras"
+HS=$((2 * (60 + 50 + 300)))      # half-steps of the sampler in such a run: rehearsal 60 steps, warm-up, timed
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py > $O/stats.log 2>&1 || exit 2
@@ -23,8 +24,8 @@ echo "traffic done"
 timeout -k 10 300 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu_cfg2 -- python3 bench.py $SHORT > $O/valu_cfg2.log 2>&1 || exit 5
 timeout -k 10 400 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu -- python3 tools/bench_cfg5.py --quick > $O/valu.log 2>&1 || exit 6
 echo "valu done"
-python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null
-python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" > /dev/null
+python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $HS > /dev/null
+python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "" $HS > /dev/null
 python3 tools/summarize_valu.py $O/pmc_valu $O/pmc_valu_cfg5.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 tools/bench_cfg5.py --quick" > /dev/null
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
 ls $O

@@ -3,13 +3,17 @@
 medians per launch for every k_lnlike instantiation in the run, largest grid only
 (a run of bench.py or tools/bench_cfg5.py also launches small set-up batches).
 
-    python tools/summarize_valu.py <rocprof output dir> <out.json> "<command that was profiled>" [note]
+    python tools/summarize_valu.py <rocprof output dir> <out.json> "<command that was profiled>" [note] [half_steps]
+
+half_steps: for the one-launch sampler kernel (k_lnlike<.., 5, ..>), whose launches cover different
+numbers of half-steps, the number of half-steps all its launches in the run add up to; the
+summary then also carries the counters summed over the launches and per half-step.
 """
 import csv, glob, json, sys
 import numpy as np
 
 
-def main(run_dir, out, command="", note=""):
+def main(run_dir, out, command="", note="", half_steps="0"):
     path = glob.glob(run_dir + "/*/*_counter_collection.csv")[0]
     per = {}
     for r in csv.DictReader(open(path)):
@@ -25,14 +29,19 @@ def main(run_dir, out, command="", note=""):
         c = {cn: float(np.median(v)) for cn, v in grids[g].items()}
         fma, add, mul = (c.get("SQ_INSTS_VALU_" + x, 0.0) for x in ("FMA_F64", "ADD_F64", "MUL_F64"))
         f64 = fma + add + mul + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+        extra = {}
+        if ", 5, " in k and int(half_steps) > 0:
+            tot = {cn: float(np.sum(v)) for cn, v in grids[g].items()}
+            extra = {"half_steps_in_all_launches": int(half_steps), "counters_all_launches": tot,
+                     "counters_per_half_step": {cn: v / int(half_steps) for cn, v in tot.items()}}
         res["kernels"][k] = {
             "grid_threads": g, "dispatches": len(next(iter(grids[g].values()))),
             "counters_per_launch": c, "fp64_wave_instructions": f64,
             "fp64_share_of_valu": f64 / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None,
-            "fp64_flops_per_launch": 64.0 * (2 * fma + add + mul)}
+            "fp64_flops_per_launch": 64.0 * (2 * fma + add + mul), **extra}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
