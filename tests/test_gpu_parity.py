@@ -1001,7 +1001,7 @@ def test_cli_config1(mbb, tmp_path):
                              "--seed", "5", "--get_peaklambda"])
     assert rc == 0
     d = np.load(out)
-    assert d["chain"].shape == (50, 200, 5) and d["peaklam"].shape == (50, 200)
+    assert d["chain"].shape == (50, 200, 5) and d["peaklambda"].shape == (50, 200)
     med = np.median(d["chain"].reshape(-1, 5), axis=0)
     # 5 points leave T and beta strongly degenerate: check the fit, not the marginals
     assert 6.0 < med[0] < 20.0 and abs(med[4] - 40.0) < 8.0
