@@ -1345,3 +1345,42 @@ def test_lookahead_sampler_forms_with_priors_limits_and_long_runs(mbb, g_lnl):
     run(lambda like: None, 520, 5, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 25)      # 260 movers: too many, plain train
     r = run(lambda like: None, 12, 4200, [12.0, 1.8, 600.0, 3.0, 40.0], 0.02, 26)
     assert r[2].shape == (12, 4200, 5)
+
+
+def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
+    """The look-ahead forms against the plain launch train where the band layout and the launch
+    geometry are not the bench's: delta-function photometry (five bands in one shared chunk,
+    fewer units than waves), the 12-band set with its covariance matrix, passband tables read
+    through L2 instead of LDS, narrower workgroups, units of one and of six chunks."""
+    def compare(make, nw, nsteps, p_center, seed, options=()):
+        out = []
+        for form, opts in _sampler_forms(None):
+            like = make()
+            for o, v in tuple(opts.items()) + tuple(options):
+                like.context.set_option(o, v)
+            if any(o in ("seg_chunks", "pack_tails") for o, _ in options):
+                like._dirty = True                                   # the layout options act at the next set_bands
+            p0 = np.array(p_center) * (1.0 + 0.02 * np.random.RandomState(seed).normal(size=(nw, 5)))
+            s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=seed)
+            pos, lnp, _ = s.run_mcmc(p0, nsteps)
+            pos2, lnp2, _ = s.run_mcmc(None, 3)
+            out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+            assert like.context.info("last_kernel_form") == {"plain": 1, "look-ahead launches": 4,
+                                                             "one launch, row by row": 5}[form]
+        for form, r in zip(_sampler_forms(None)[1:], out[1:]):
+            for x, y in zip(out[0], r):
+                assert np.array_equal(x, y), (form[0], options)
+        assert np.isfinite(out[0][1]).all()
+
+    for name, opthin, noalpha in VARIANTS:
+        compare(lambda: _like_cfg1(mbb, g_lnl, name, opthin, noalpha)[0], 40, 25, [14.0, 1.8, 500.0, 3.0, 30.0], 31)
+
+    def cfg4():
+        like = mbb.likelihood(response=True)
+        k = "cfg4/thick_walpha"
+        like.set_phot([str(b) for b in g_lnl["cfg4/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+        like.set_cov(g_lnl[k + "/cov"])
+        return like
+    compare(cfg4, 60, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 32)
+    for options in ((("stage_tables", 0),), (("block_threads", 512),), (("seg_chunks", 1),), (("seg_chunks", 6), ("pack_tails", 0))):
+        compare(lambda: _cfg2_like(mbb, g_lnl), 50, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 33, options)
