@@ -599,7 +599,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     roof["kernel_avg_us"] = k_us
     roof["sample_arithmetic"] = arith
     roof["why_far_below"] = ("a half-step of 125 walkers is latency: one workgroup per walker, 9 chunks of samples per "
-                             "SIMD between two workgroup barriers (bound by the LDS reads of the polynomial tables), the "
+                             "SIMD between two workgroup barriers (a wave's chunk pairs one after the other: dependent LDS look-ups), the "
                              "band sums and the accept test of one lane, then ~0.6 us until the partner's workgroup on "
                              "another XCD sees the decision; see cfg5 for the same arithmetic when the chip is full")
     out["roofline"] = roof
