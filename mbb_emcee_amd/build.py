@@ -18,6 +18,7 @@ FLOW_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machi
 DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
         os.path.join(HERE, "csrc", "mbb_walker_consts.inc"),
+        os.path.join(HERE, "csrc", "mbb_flow_index.h"),
         os.path.join(HERE, "csrc", "mbb_device.hip.h"),
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),
         os.path.join(HERE, "csrc", "mbb_kernels.hip.h"),

@@ -277,3 +277,15 @@ extern "C" int mbbh_band_layout(const double *freq, const double *weight, const 
     std::copy(L.tail_slot.begin(), L.tail_slot.end(), tail_slot);
     return 0;
 }
+
+// index arithmetic of the one-launch sampler run (mbb_flow_index.h), for the protocol model
+#include "mbb_flow_index.h"
+extern "C" int mbbh_flow_index(int h, int j, int m, int *cnt, int *seq, int *slots, int *lag)
+{
+    *cnt = flow_cnt(h, j);
+    *seq = flow_seq(h, m);
+    *slots = kFlowSlots;
+    *lag = kFlowLag;
+    return 0;
+}
+

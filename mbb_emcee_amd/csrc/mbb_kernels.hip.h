@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "mbb_device.hip.h"
+#include "mbb_flow_index.h"
 
 using namespace mbbd;
 
@@ -143,7 +144,7 @@ constexpr int kSpecRec = 32;  // doubles per record: WalkerK (13), proposal (5),
 //   done  [8][16]   moves completed per half-step mod 8 (the lag guard)
 //   mseq  [nw][kFlowSlots]  2 x (half-step of move m + 1) + (it was accepted): written the moment
 //                   the move is decided, before the row itself
-constexpr int kFlowSlots = 4, kFlowRecN = 22, kFlowRec = 48;
+constexpr int kFlowRecN = 22, kFlowRec = 48;
 struct FlowView {
     double *rec, *st;
     unsigned long long *seq, *rseq, *done, *mseq;
@@ -163,11 +164,7 @@ __device__ __forceinline__ FlowView flow_view(double *spec, int nw)
     v.mseq = v.done + 8 * 16;
     return v;
 }
-// SMODE 5: moves of half h (0: rows [0, n/2), 1: the rest) completed before half-step j; the
-// state after a row's m-th move lives in slot m mod kFlowSlots and is there once the row's word
-// says flow_seq(h, m)
-__host__ __device__ constexpr int flow_cnt(int h, int j) { return (j - h + 1) > 0 ? (j - h + 1) >> 1 : 0; }
-__host__ __device__ constexpr int flow_seq(int h, int m) { return m > 0 ? h + 2 * m - 1 : 0; }
+// (flow_cnt, flow_seq: mbb_flow_index.h)
 
 __device__ __forceinline__ double ld_sys(const double *p)      // system-scope load (bypasses L1)
 {
@@ -697,10 +694,10 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // lane 23 the lag guard.  When all of it is there already, that is one round trip.
                 const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
                 const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
-                const unsigned long long need_g = (unsigned long long)a.n * (unsigned long long)(((it - 4) >> 3) + 1);
+                const unsigned long long need_g = (unsigned long long)a.n * (unsigned long long)(((it - kFlowLag) >> 3) + 1);
                 const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
-                                                            : fv.done + ((it - 4) & 7) * 16;
-                const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= 4);
+                                                            : fv.done + ((it - kFlowLag) & 7) * 16;
+                const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag);
                 const int c = lane < kFlowRecN ? lane : 0;
                 unsigned long long pv = 0;
                 bool rec_ok = false, word_ok = !watch;

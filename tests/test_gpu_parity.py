@@ -1384,3 +1384,24 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
     compare(cfg4, 60, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 32)
     for options in ((("stage_tables", 0),), (("block_threads", 512),), (("seg_chunks", 1),), (("seg_chunks", 6), ("pack_tails", 0))):
         compare(lambda: _cfg2_like(mbb, g_lnl), 50, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 33, options)
+
+
+def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
+    """The one-launch run needs every workgroup on the GPU at once.  A shape of the working-ahead
+    workgroups that does not fit (forced through the options here; too many walkers elsewhere) is
+    not started and left to time out: the run takes the launch-per-half-step form, same chain."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(250, 5)))
+    out = []
+    for rows, waves, form in ((1, 1, 4), (0, 0, 5)):                 # 500 + 125 workgroups do not fit 256 CUs
+        ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
+        s = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
+        pos, lnp, _ = s.run_mcmc(p0, 4)
+        assert ctx.info("last_kernel_form") == form and np.isfinite(lnp).all()
+        out.append((pos, lnp, s.chain.copy()))
+    ctx.set_option("lookahead_sampler", 0)
+    s2 = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
+    pos2, lnp2, _ = s2.run_mcmc(p0, 4)
+    for pos, lnp, ch in out:
+        assert np.array_equal(pos, pos2) and np.array_equal(lnp, lnp2) and np.array_equal(ch, s2.chain)

@@ -454,3 +454,37 @@ def test_dustmass_identities():
     np.testing.assert_allclose(pp.dustmass(thin, chain, z, dl, kappa=2 * kappa), m_thin / 2, rtol=1e-14)
     with pytest.raises(ValueError):
         pp.dustmass(thin, chain, z, dl, kappa=0.0)
+
+
+def test_flow_protocol_model():
+    """The hand-over protocol of the one-launch look-ahead sampler run (k_lnlike SMODE 5), restated
+    on the host with the kernel's own index arithmetic (mbb_flow_index.h) and run in random and in
+    adversarial order: with the lag guard no slot is ever reused under a reader and every run
+    completes; a stalled worker stops what depends on it and nothing else goes wrong; without the
+    guard the same adversary does get a slot overwritten -- the model can see what the guard is for."""
+    import random
+    import _flow_model as FM
+    LC, lib = _hosttables_lib()
+    ix = FM.Index(lib)
+    assert ix.slots == 4 and ix.lag == 4
+    # index arithmetic: moves completed before half-step j, and the word after move m
+    for h in (0, 1):
+        for j in range(-1, 40):
+            assert ix.cnt(h, j) == len([g for g in range(h, j, 2)]) if j > h else ix.cnt(h, j) == 0
+        for m in range(1, 20):
+            assert ix.seq(h, m) == (h + 2 * (m - 1)) + 1
+    # random schedules, random partners
+    for seed in range(12):
+        rng = random.Random(seed)
+        lead, events, finished = FM.run(ix, n2=rng.choice((3, 5, 8)), nsteps=14, rng=rng)
+        assert finished and lead <= ix.lag + 2, (seed, lead)
+    # adversary: nobody ever needs row 0 as a partner, and row 0's worker sleeps through half-step 4
+    # for a long time: the others run ahead of row 0 until the guard stops them; when the sleeper
+    # wakes up everything it reads is still there, and the run completes
+    n2 = 4
+    avoid0 = lambda r, j: 1 + (r + j) % (n2 - 1)
+    lead, events, finished = FM.run(ix, n2, 14, random.Random(1), partner=avoid0, stall=(0, 4, 5000))
+    assert finished and lead <= ix.lag + 2
+    # the same without the guard: they run on, and the sleeper wakes up to slots that were reused
+    with pytest.raises(FM.Violation):
+        FM.run(ix, n2, 14, random.Random(1), guard=False, partner=avoid0, stall=(0, 4, 5000))
