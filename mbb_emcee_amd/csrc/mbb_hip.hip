@@ -151,7 +151,6 @@ struct mbb_ctx {
     long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals one launch ahead (SMODE 4)
     unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
-    long opt_la_debug = 0;
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
     size_t lds_granted[48] = {};   // dynamic-LDS ceiling already requested, per kernel variant
@@ -589,8 +588,6 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             if (sl->persist && a.n_ahead + grid > c->cu_count)
                 return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
             grid = a.n_ahead + (sl->spec_first ? 0 : grid);
-            if ((c->opt_la_debug & 1) && !sl->spec_first) { grid -= a.n_ahead; a.n_ahead = 0; }     // timing only: movers alone
-            if (c->opt_la_debug & 2) a.spec_cfg |= 8;                          // timing only: movers exit at once
             c->last_grid = grid;
         }
     } else {
@@ -1397,7 +1394,6 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
     else if (!strcmp(name, "lookahead_waves")) c->opt_la_waves = value;
-    else if (!strcmp(name, "lookahead_debug")) c->opt_la_debug = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
     else if (!strcmp(name, "roof_threads")) c->opt_roof_threads = value;
     else return fail(MBB_ERR_ARG, "unknown option");

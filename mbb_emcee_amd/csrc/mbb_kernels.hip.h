@@ -320,7 +320,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // stage what the later phases need in LDS and pull their first segment's samples
     // and the index table into this CU's L1, so that nothing after the barrier waits
     // on L2; without spare waves every wave stages first.
-    if (SPEC && (a.spec_cfg & 8) && (int)blockIdx.x >= a.n_ahead) return;
     const int pwaves = min(nwave, (16 * W + 63) >> 6);
     if ((!SPEC || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
         const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;

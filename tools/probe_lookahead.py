@@ -23,20 +23,18 @@ def run(look, rows=1, nsteps=40, runs=2, flow=0):
     return smp.chain.copy(), smp.lnprobability.copy(), smp.naccepted.copy(), pos, lnp
 
 
-def rate(look, rows=1, nsteps=2000, dbg=0, flow=0):
+def rate(look, rows=1, nsteps=2000, flow=0):
     ctx.set_option("flow_sampler", flow)
     ctx.set_option("lookahead_sampler", look)
     ctx.set_option("lookahead_rows", rows)
     smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
     smp.run_mcmc(p0, 20, storechain=False)
-    ctx.set_option("lookahead_debug", dbg)
     smp.advance_async(200); ctx.sync()
     best = 1e9
     for _ in range(5):
         e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0); smp.advance_async(nsteps); ctx.record(e1); ctx.sync()
         best = min(best, ctx.elapsed_ms(e0, e1) * 1e3 / nsteps)
-    ctx.set_option("lookahead_debug", 0)
     return best
 
 
@@ -59,8 +57,6 @@ if "flow" in sys.argv:
         print("one launch per run, %d waves x %d rows ahead per workgroup: %.3f us per step" % (waves, rows, rate(1, rows, flow=1)))
     ctx.set_option("lookahead_waves", 0)
 print("plain      : %.3f us per step" % rate(0))
-for dbg in (1, 2):
-    print("look-ahead, timing only, %s: %.3f us per step" % ("movers alone" if dbg == 1 else "workers-ahead alone", rate(1, 1, dbg=dbg)))
 for rows, waves in ((0, 0), (1, 2), (1, 4), (1, 8), (2, 4), (4, 4), (4, 16)):
     ctx.set_option("lookahead_waves", waves)
     print("look-ahead (%d rows/wave, %d waves; 0 = the host's plan): %.3f us per step" % (rows, waves, rate(1, rows)))

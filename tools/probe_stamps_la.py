@@ -17,10 +17,6 @@ for look in (0, 1):
     ctx.set_option("lookahead_sampler", look & 1)
     smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
     smp.run_mcmc(walkers(1)[:NW_PER_GPU], 30, storechain=False)
-    if look > 1:
-        ctx.set_option("lookahead_debug", look & 12)
-        smp.advance_async(30); ctx.sync()
-        ctx.set_option("lookahead_debug", 0)
     nb = int(ctx.info("last_grid"))
     st = np.zeros((nb, 32), dtype=np.uint64)
     lib.mbb_stamps(ctx.h, st.ctypes.data_as(C.c_void_p), nb)
