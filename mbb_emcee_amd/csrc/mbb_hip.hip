@@ -150,6 +150,8 @@ struct mbb_ctx {
     long last_stage = 0;
     long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals one launch ahead (SMODE 4)
     unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
+    long opt_flow_spin_log2 = 0;   // one-launch run: log2 of the polls before a wait gives up (0: the kernel's 22)
+    long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
@@ -491,6 +493,8 @@ static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, 
     n_ahead = (pairs + rows * aw - 1) / (rows * aw);
 }
 
+static unsigned long long g_flow_serial = 0;    // one-launch sampler runs started in this process (their check words)
+
 struct SamplerLaunch {
     double *pos6, *chain6;
     unsigned int *nacc;
@@ -575,7 +579,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.persist = sl->persist; a.gbar = sl->gbar;
         if (sl->spec) {
             a.xargs = nullptr;
-            if (sl->persist) a.flow_serial = ++c->flow_serial;
+            if (sl->persist) a.flow_serial = c->flow_serial = ++g_flow_serial;
             // first the workgroups that prepare the next half-step -- one row of 16 lanes per
             // (walker, candidate), `rows` of them per wave, `aw` such waves per workgroup -- then
             // the movers.  A constructor is one dependent chain: a wave alone on its SIMD runs it
@@ -583,7 +587,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             int rows, aw, n_ahead;
             lookahead_plan(c, grid, threads, sl->c_count, sl->persist > 0, rows, aw, n_ahead);
             a.spec = sl->spec;
-            a.spec_cfg = sl->spec_cfg | (rows << 8) | (aw << 16);
+            a.spec_cfg = sl->spec_cfg | (rows << 8) | (aw << 16) |
+                         (sl->persist ? (int)((c->opt_flow_spin_log2 & 0x3f) << 24) : 0);
             a.n_ahead = n_ahead;
             if (sl->persist && a.n_ahead + grid > c->cu_count)
                 return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
@@ -737,6 +742,8 @@ struct mbb_sampler_state {
     unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
     unsigned int *d_gbar = nullptr;      // arrival counters of the one-launch run (8 x 128 bytes)
+    double *d_bak = nullptr;             // one-launch run: the rows and counts it started from (R x 6 doubles, R counts)
+    bool flow_used = false;              // the last enqueue took the one-launch form
     double *d_spec = nullptr;            // look-ahead run: records [rows][2][kSpecRec] + state [2][rows][8]
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
     size_t chain_cap = 0;
@@ -782,6 +789,7 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     if (s->pos6_owned) free_dev(s->d_pos6);
     else if (c->x.users > 0) --c->x.users;
     free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar); free_dev(s->d_spec);
+    free_dev(s->d_bak);
     delete s;
     return MBB_OK;
 }
@@ -867,6 +875,7 @@ static int allgather_bytes(mbb_ctx *c, void *base, size_t bytes_per_rank)
 
 static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store)
 {
+    s->flow_used = false;
     ShardPlan p;
     int rc = shard_plan(c, s, p);
     if (rc) return rc;
@@ -916,7 +925,12 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     if (c->opt_lookahead && p.shards == 1 && !p.collective && s->nsrc == 1 && nsteps > 0 && wpb_1 == 1 &&
         (int)nl + (2 * (int)nl + 63) / 64 <= c->cu_count && s->rows() <= kPolyBDoubles / 8) {
         const size_t R = (size_t)s->rows();
-        if (!s->d_spec) HIPCHK(hipMalloc((void **)&s->d_spec, spec_words(R) * sizeof(double)));
+        if (!s->d_spec) {
+            // zeroed: the records of a one-launch run are taken by their check words, and freshly
+            // allocated memory may hold those of another sampler's run
+            HIPCHK(hipMalloc((void **)&s->d_spec, spec_words(R) * sizeof(double)));
+            HIPCHK(hipMemsetAsync(s->d_spec, 0, spec_words(R) * sizeof(double), c->stream));
+        }
         int la_rows, la_aw, la_ahead;
         lookahead_plan(c, (int)nl, thr_1, half, true, la_rows, la_aw, la_ahead);
         if (c->opt_flow && la_ahead + (int)nl <= c->cu_count) {
@@ -924,6 +938,12 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
             sl.spec = s->d_spec;
+            // what the run starts from, kept so that a run that times out (a workgroup that is not
+            // resident: another process on the GPU) can be redone as a launch train (mbb_sampler_run)
+            if (!s->d_bak) HIPCHK(hipMalloc((void **)&s->d_bak, R * 6 * sizeof(double) + R * sizeof(unsigned int)));
+            HIPCHK(hipMemcpyAsync(s->d_bak, s->d_pos6, R * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(s->d_bak + R * 6, s->d_nacc, R * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
+            s->flow_used = true;
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
                 hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
@@ -1040,6 +1060,18 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     if (err) {
         HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
         if (err == 8) return fail(MBB_ERR_RCCL, "the exchange timed out: a peer did not post its launch");
+        if (err == 9 && s->flow_used && s->d_bak) {
+            // The one-launch run gave up waiting (not every workgroup was resident): back to the state it
+            // started from and the same steps as a train of launches -- the same chain.  The context keeps
+            // to the launch train from here on (option "flow_sampler" 1 turns the one-launch form back on).
+            HIPCHK(hipMemcpyAsync(s->d_pos6, s->d_bak, (size_t)R * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(s->d_nacc, s->d_bak + (size_t)R * 6, (size_t)R * sizeof(unsigned int), hipMemcpyDeviceToDevice,
+                                  c->stream));
+            s->steps_done -= (unsigned long long)nsteps;
+            c->opt_flow = 0;
+            ++c->flow_fallbacks;
+            return mbb_sampler_run(c, sp, nsteps, stretch_a, chain, lnprob, pos_out, lnprob_out, naccepted);
+        }
         if (err == 9) return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step");
         g_err = "lnprob returned NaN or the SED constructor rejected a proposal (row status " +
                 std::to_string(err) + ")";
@@ -1392,6 +1424,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "persistent_sampler")) c->opt_persist = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
+    else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
     else if (!strcmp(name, "lookahead_waves")) c->opt_la_waves = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
@@ -1418,6 +1451,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_wpb")) *value = c->last_wpb;
     else if (!strcmp(name, "last_threads")) *value = c->last_threads;
     else if (!strcmp(name, "last_grid")) *value = c->last_grid;
+    else if (!strcmp(name, "flow_fallbacks")) *value = c->flow_fallbacks;
     else if (!strcmp(name, "last_kernel_form")) *value = c->last_smode;     // k_lnlike's SMODE of the last launch
     else if (!strcmp(name, "last_workgroups_ahead")) *value = c->last_ahead;
     else if (!strcmp(name, "last_smem")) *value = c->last_smem;

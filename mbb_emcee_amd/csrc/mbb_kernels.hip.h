@@ -118,7 +118,8 @@ struct LikeArgs {
                               // bit 2: a run's first launch (works ahead for itself, moves nothing)
                               // (bits 0-2: SMODE 4 only);
                               // bits 8-15: candidates per wave (1, 2 or 4 rows of 16 lanes),
-                              // bits 16-23: waves of a workgroup working ahead that take candidates
+                              // bits 16-23: waves of a workgroup working ahead that take candidates,
+                              // bits 24-31: SMODE 5, log2 of the polls before a wait gives up (0: 22)
             int n_ahead;      // workgroups 0 .. n_ahead-1 work ahead (dispatched first: theirs is the
                               // longer path), the rest move walkers
         };
@@ -283,6 +284,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const int w0 = (SMODE >= 4 ? (int)blockIdx.x - a.n_ahead : (int)blockIdx.x) * W;
+    // SMODE 5: polls before a wait gives up and ends the run with error 9 (~1.5 us each)
+    const long long flow_spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
+    bool flow_dead = false;         // ... after which this wave waits for nothing any more: the run drains
     // The compiler fetches kernel arguments where they are first used, one exposed
     // scalar-cache round trip (~200 cycles) each; on the latency path that is a
     // dozen of them.  Ask for the hot ones here so that they arrive in one batch.
@@ -520,11 +524,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     for (;;) {
                         bool ok = true;
                         if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0 || flow_dead) break;
                         ++spins;
-                        if (spins > (1ll << 22) ||
+                        if (spins > flow_spin_limit ||
                             ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                             atomicMax(a.errflag, 9);
+                            flow_dead = true;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -729,11 +734,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         }
                         pend_row = -1;
                     }
-                    if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0) break;
+                    if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0 || flow_dead) break;
                     ++spins;
-                    if (spins > (1ll << 22) ||
+                    if (spins > flow_spin_limit ||
                         ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         atomicMax(a.errflag, 9);
+                        flow_dead = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);

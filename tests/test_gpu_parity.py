@@ -1405,3 +1405,45 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     pos2, lnp2, _ = s2.run_mcmc(p0, 4)
     for pos, lnp, ch in out:
         assert np.array_equal(pos, pos2) and np.array_equal(lnp, lnp2) and np.array_equal(ch, s2.chain)
+
+
+def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, g_lnl):
+    """A one-launch run whose waits give up (here: a poll budget of two; in the field: a workgroup
+    that is not resident because another process holds CUs) ends with an error flag, not a hang;
+    mbb_sampler_run then restores the state the run started from and does the same steps as a train
+    of launches -- the caller gets the chain it would have got, and the context stays on the train."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(100, 5)))
+    ctx.set_option("lookahead_sampler", 0)
+    s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
+    a = s0.run_mcmc(p0, 6)[:2] + (s0.run_mcmc(None, 5)[:2]) + (s0.chain.copy(), s0.naccepted.copy())
+    ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1)
+    s1 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
+    first = s1.run_mcmc(p0, 6)[:2]
+    assert ctx.info("last_kernel_form") == 5 and ctx.info("flow_fallbacks") == 0
+    ctx.set_option("flow_spin_log2", 1)                       # the second run gives up at once ...
+    second = s1.run_mcmc(None, 5)[:2]
+    assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 4      # ... and was redone
+    b = first + second + (s1.chain.copy(), s1.naccepted.copy())
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ctx.set_option("flow_spin_log2", 0)
+
+
+def test_one_launch_sampler_ignores_records_left_in_reused_memory(mbb, g_lnl):
+    """A one-launch run takes its proposal records by their check words.  Samplers of short runs on
+    context after context get the same device memory back from the allocator, with another run's
+    records still in it: they must not be mistaken for this run's (the check words carry a
+    process-wide launch number, and a sampler's record memory starts zeroed)."""
+    for k in range(8):
+        res = []
+        for look in (1, 0):
+            like = _cfg2_like(mbb, g_lnl)                         # a context of its own each time
+            like.context.set_option("lookahead_sampler", look)
+            p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(100 + k).normal(size=(64, 5)))
+            s = mbb.DeviceEnsembleSampler(64, 5, like, seed=4)     # the same seed: the same check-word arithmetic
+            res.append(s.run_mcmc(p0, 3)[:2] + (s.chain.copy(),))
+            del s, like
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y), k
