@@ -141,18 +141,17 @@ constexpr int kSpecRec = 32;  // doubles per record: WalkerK (13), proposal (5),
 //                   the writer neither waits for its stores nor raises a flag after them
 //   st    [kFlowSlots][nw][8]            the row after move m (slot 0: as the run found it)
 //   seq   [nw]      the half-step after the last one whose row has LANDED in st (0: none)
-//   rseq  [nw][2]   the same for the records, per candidate
 //   done  [8][16]   moves completed per half-step mod 8 (the lag guard)
 //   mseq  [nw][kFlowSlots]  2 x (half-step of move m + 1) + (it was accepted): written the moment
 //                   the move is decided, before the row itself
 constexpr int kFlowRecN = 22, kFlowRec = 48;
 struct FlowView {
     double *rec, *st;
-    unsigned long long *seq, *rseq, *done, *mseq;
+    unsigned long long *seq, *done, *mseq;
 };
 __host__ __device__ constexpr size_t spec_words(size_t nw)
 {
-    return nw * ((size_t)kFlowSlots * 2 * kFlowRec + kFlowSlots * 8 + 3 + kFlowSlots) + 8 * 16;
+    return nw * ((size_t)kFlowSlots * 2 * kFlowRec + kFlowSlots * 8 + 1 + kFlowSlots) + 8 * 16;
 }
 __device__ __forceinline__ FlowView flow_view(double *spec, int nw)
 {
@@ -160,8 +159,7 @@ __device__ __forceinline__ FlowView flow_view(double *spec, int nw)
     v.rec = spec;
     v.st = spec + (size_t)nw * kFlowSlots * 2 * kFlowRec;
     v.seq = reinterpret_cast<unsigned long long *>(v.st + (size_t)nw * kFlowSlots * 8);
-    v.rseq = v.seq + nw;
-    v.done = v.rseq + (size_t)2 * nw;
+    v.done = v.seq + nw;
     v.mseq = v.done + 8 * 16;
     return v;
 }
@@ -464,16 +462,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             // there -- the state as of the start of half-step j - 1 -- while j - 1 is still moving
             const FlowView fv = flow_view(a.spec, a.nw);
             const int nj = FLOW ? a.persist : 1;
-            int pend_j = -1;                                  // SMODE 5: the record whose landing is still to be announced
             for (int j = wh; j < nj; j += FLOW ? 2 : 1) {
-            if (FLOW && pend_j >= 0) {
-                // (to the rows that work ahead from this record's proposal, half-steps from now;
-                // the mover itself takes the record element by element)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (active && (tid & 15) == 0)
-                    __hip_atomic_store(fv.rseq + (size_t)((wh ? a.c_count : 0) + loc) * 2 + cand, (unsigned long long)(pend_j + 1),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             // the draws: the walker's own for the half-step being prepared, and the one its
             // partner is moving on meanwhile
             const int hj = FLOW ? (j & 1) : (a.half ^ 1);
@@ -500,23 +489,26 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             if constexpr (FLOW) {
                 // The rows this proposal starts from -- the walker's own and, for candidate 1, its
                 // partner's partner -- made their last move in half-step j - 2.  Such a row is put
-                // together here from what was known before that move was decided (the row as it
-                // was, and the proposal it was tested on: the record of the candidate its own
-                // partner's earlier move selected), so that when the decision arrives nothing is
-                // left to fetch: the constructor starts one hand-off after the decision.
+                // together here from what was known before that move was decided: the row as it
+                // was, and the proposal it was tested on -- formed again from that row, its partner's
+                // row of the time and the same draw, so the same bits as the record its mover used --
+                // so that when the decision arrives nothing is left to fetch: the constructor starts
+                // one hand-off after the decision.  (Only rows and decision words are read: what a
+                // sharded run would have to replicate.)
                 const int m_s = flow_cnt(hj, j - 1), m_o = flow_cnt(hj ^ 1, j - 1);   // moves made, as of j - 1
                 m_next = m_s + 1;
                 const int g = j - 2;                                                  // half-step of move m_s
                 const int m_q = flow_cnt(hj ^ 1, g);                                  // the other half's moves before g
                 const int l16 = lane & 15, base = lane & 48;
                 const int pprow = sb + pjp, prow = ob + pj;
-                int qr = 0, qp = 0;                           // partners of the two rows in half-step g
+                int qr = 0, qp = 0;                           // partners of the two rows in half-step g,
+                double zr = 1.0, zq = 1.0;                    // and their stretch factors
                 if (active && m_s > 0) {
                     const int tg = a.step + (g >> 1);
                     const unsigned long long seed_g = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(g >> 1);
-                    double z0, u0;
-                    stretch_draw(rown, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qr, u0);
-                    if (c1) stretch_draw(pprow, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qp, u0);
+                    double u0;
+                    stretch_draw(rown, tg, hj, seed_g, a.stretch_a, a.c_count, zr, qr, u0);
+                    if (c1) stretch_draw(pprow, tg, hj, seed_g, a.stretch_a, a.c_count, zq, qp, u0);
                 }
                 auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
                     unsigned long long v = 0;
@@ -536,41 +528,33 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     }
                     return v;
                 };
-                // (1) everything that was settled a half-step or more ago, one lane of the row each:
-                //  0, 1: which candidate the two rows' move m_s was tested on (their partners' decisions)
-                //  2   : the partner's row before its pending move has landed
-                //  3, 4: the two rows before move m_s have landed;  5-8: the records of move m_s too
+                // (1) rows that were settled a half-step or more ago have landed, one lane of the row each:
+                //  0, 1: the rows the two rows' move m_s was proposed from (their partners of then)
+                //  2   : the partner's row before its pending move;  3, 4: the two rows before move m_s
                 const unsigned long long *w1 = fv.seq;
                 unsigned long long n1 = 0;
-                int sh1 = 0;
                 bool watch1 = false;
                 if (active) {
                     const unsigned long long nq = (unsigned long long)flow_seq(hj ^ 1, m_q);
                     const unsigned long long nold = (unsigned long long)flow_seq(hj, m_s - 1);
                     switch (l16) {
-                    case 0: w1 = fv.mseq + (size_t)(ob + qr) * kFlowSlots + (m_q % kFlowSlots); n1 = nq; sh1 = 1; watch1 = m_s > 0 && m_q > 0; break;
-                    case 1: w1 = fv.mseq + (size_t)(ob + qp) * kFlowSlots + (m_q % kFlowSlots); n1 = nq; sh1 = 1; watch1 = c1 && m_s > 0 && m_q > 0; break;
+                    case 0: w1 = fv.seq + (ob + qr); n1 = nq; watch1 = m_s > 0 && m_q > 0; break;
+                    case 1: w1 = fv.seq + (ob + qp); n1 = nq; watch1 = c1 && m_s > 0 && m_q > 0; break;
                     case 2: w1 = fv.seq + prow; n1 = (unsigned long long)flow_seq(hj ^ 1, m_o); watch1 = m_o > 0; break;
                     case 3: w1 = fv.seq + rown; n1 = nold; watch1 = m_s > 1; break;
                     case 4: w1 = fv.seq + pprow; n1 = nold; watch1 = c1 && m_s > 1; break;
-                    case 5: case 6: w1 = fv.rseq + (size_t)rown * 2 + (l16 - 5); n1 = (unsigned long long)(g + 1); watch1 = m_s > 0; break;
-                    case 7: case 8: w1 = fv.rseq + (size_t)pprow * 2 + (l16 - 7); n1 = (unsigned long long)(g + 1); watch1 = c1 && m_s > 0; break;
                     default: break;
                     }
                 }
-                const unsigned long long v1 = spin(w1, n1, watch1, sh1);
-                const int cr = (m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 0) & 1ull) : 0;
-                const int cp = (m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 1) & 1ull) : 0;
-                // both versions of the two rows and the partner's row -> this row's corner of LDS
-                // (the polynomial table's place), an element or two per lane: [0,5) the walker's row
-                // as it was, [5,10) the proposal it was tested on, [10,20) the same for the
-                // partner's partner, [20,25) the partner
+                spin(w1, n1, watch1, 0);
+                // the rows -> this row's corner of LDS (the polynomial table's place), an element or
+                // two per lane: [0,5) the walker's row as it was, [5,10) the row its last move was
+                // proposed from, [10,20) the same two for the partner's partner, [20,25) the partner
                 double *scr = s_pb + (size_t)(wave * 4 + (lane >> 4)) * 32;
                 if (active) {
-                    const int so = (m_s > 0 ? m_s - 1 : 0) % kFlowSlots;
+                    const int so = (m_s > 0 ? m_s - 1 : 0) % kFlowSlots, sq = m_q % kFlowSlots;
                     const double *o_r = fv.st + ((size_t)so * a.nw + rown) * 8, *o_p = fv.st + ((size_t)so * a.nw + pprow) * 8;
-                    const double *n_r = fv.rec + (((size_t)rown * kFlowSlots + (m_s % kFlowSlots)) * 2 + cr) * kFlowRec + 26;
-                    const double *n_p = fv.rec + (((size_t)pprow * kFlowSlots + (m_s % kFlowSlots)) * 2 + cp) * kFlowRec + 26;
+                    const double *n_r = fv.st + ((size_t)sq * a.nw + ob + qr) * 8, *n_p = fv.st + ((size_t)sq * a.nw + ob + qp) * 8;
                     const double *sp = fv.st + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * 8;
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -579,8 +563,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                             const int grp = e / 5, i = e - 5 * grp;
                             const double *src = grp == 0 ? o_r : (grp == 1 ? n_r : (grp == 2 ? o_p : (grp == 3 ? n_p : sp)));
                             const bool want = grp == 0 || grp == 4 || (grp == 1 && m_s > 0) || (grp == 2 && c1) || (grp == 3 && c1 && m_s > 0);
-                            const int stride = (grp == 1 || grp == 3) ? 2 : 1;      // record elements are every other word
-                            scr[e] = want ? ld_dev(src + stride * i) : 0.0;
+                            scr[e] = want ? ld_dev(src + i) : 0.0;
                         }
                     }
                 }
@@ -593,7 +576,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) { snv[i] = scr[(ar ? 5 : 0) + i]; cpv[i] = scr[(ap ? 15 : 10) + i]; cpos[i] = scr[20 + i]; }
+                for (int i = 0; i < 5; ++i) {
+                    snv[i] = ar ? stretch_q(scr[5 + i], scr[i], zr) : scr[i];
+                    cpv[i] = ap ? stretch_q(scr[15 + i], scr[10 + i], zq) : scr[10 + i];
+                    cpos[i] = scr[20 + i];
+                }
             } else {
                 __syncthreads();
                 if (active) {
@@ -650,7 +637,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 }
                 STAMPD(10, pen_u + pen_g);
             }
-            if constexpr (FLOW) pend_j = j;
             }   // half-steps of a one-launch run
             STAMP(6);
             return;
@@ -1248,7 +1234,7 @@ static __global__ void k_flow_init(const double *pos6, double *spec, int nw)
         const int row = i >> 3, e = i & 7;
         fv.st[i] = e < 6 ? pos6[(size_t)row * 6 + e] : 0.0;
     }
-    const int nwords = nw * (3 + kFlowSlots) + 8 * 16;        // seq, rseq, done, mseq are contiguous
+    const int nwords = nw * (1 + kFlowSlots) + 8 * 16;        // seq, done, mseq are contiguous
     for (int k = i; k < nwords; k += gridDim.x * blockDim.x) fv.seq[k] = 0ull;
 }
 

@@ -55,7 +55,6 @@ def run(ix, n2, nsteps, rng, guard=True, partner=None, stall=None, max_events=20
     rec = {(r, s, c): None for r in rows for s in range(S) for c in (0, 1)}
     mseq = {(r, s): None for r in rows for s in range(S)}         # move number decided
     seq = {r: 0 for r in rows}
-    rseq = {(r, c): 0 for r in rows for c in (0, 1)}
     done = {}                                                     # half-step -> completions published
     next_move = {r: half_of(r) for r in rows}                     # the half-step the row's mover does next
     next_work = {(r, c): half_of(r) for r in rows for c in (0, 1)}
@@ -107,12 +106,9 @@ def run(ix, n2, nsteps, rng, guard=True, partner=None, stall=None, max_events=20
             if m_s > 1 and seq[x] < ix.seq(h, m_s - 1):
                 return False
             if m_s > 0:
-                if rseq[(x, 0)] < g + 1 or rseq[(x, 1)] < g + 1:
-                    return False
                 m_q = ix.cnt(1 - h, g)
-                if m_q > 0 and mseq[(prow(x, g), m_q % S)] != m_q:
-                    return False if mseq[(prow(x, g), m_q % S)] is None or mseq[(prow(x, g), m_q % S)] < m_q else _raise(
-                        "decision word of row %d (move %d) overwritten under a worker" % (prow(x, g), m_q))
+                if m_q > 0 and seq[prow(x, g)] < ix.seq(1 - h, m_q):   # the row x's last move was proposed from
+                    return False
                 if mseq[(x, m_s % S)] != m_s:                     # the decision of half-step j - 2
                     return False if mseq[(x, m_s % S)] is None or mseq[(x, m_s % S)] < m_s else _raise(
                         "decision word of row %d overwritten under its worker" % x)
@@ -131,10 +127,9 @@ def run(ix, n2, nsteps, rng, guard=True, partner=None, stall=None, max_events=20
         for x in [r] + ([pp] if pp is not None else []):
             expect(st, (x, (m_s - 1 if m_s > 0 else 0) % S), m_s - 1 if m_s > 0 else 0, "row as it was")
             if m_s > 0:
-                expect(rec, (x, m_s % S, 0), m_s, "record of the last move")
-                expect(rec, (x, m_s % S, 1), m_s, "record of the last move")
+                m_q = ix.cnt(1 - h, j - 2)
+                expect(st, (prow(x, j - 2), m_q % S), m_q, "row the last move was proposed from")
         rec[(r, (m_s + 1) % S, c)] = m_s + 1                      # element by element, no flag
-        pending.append(("rseq", r, c, j))
         next_work[(r, c)] = j + 2
 
     events = [0]
@@ -143,7 +138,7 @@ def run(ix, n2, nsteps, rng, guard=True, partner=None, stall=None, max_events=20
                  [("w", r, c) for r in rows for c in (0, 1) if worker_ready(r, c)])
         # a wave's publications stay in the order it made them (a mover workgroup owns a row of
         # each half; a worker row owns one row and candidate)
-        owner = lambda e: ("row", e[1] % n2) if e[0] == "row" else ("rseq", e[1], e[2])
+        owner = lambda e: ("row", e[1] % n2)
         seen, pubs = set(), []
         for i, e in enumerate(pending):
             if owner(e) not in seen:
@@ -163,12 +158,9 @@ def run(ix, n2, nsteps, rng, guard=True, partner=None, stall=None, max_events=20
             worker_step(ev[1], ev[2])
         else:
             kind, a, b, j = pending.pop(ev[1])
-            if kind == "row":
-                st[(a, b % S)] = b
-                seq[a] = max(seq[a], j + 1)
-                done[j] = done.get(j, 0) + 1
-            else:
-                rseq[(a, b)] = max(rseq[(a, b)], j + 1)
+            st[(a, b % S)] = b
+            seq[a] = max(seq[a], j + 1)
+            done[j] = done.get(j, 0) + 1
         fastest = max(next_move.values()) - 2
         slowest = min(next_move[r] - 2 for r in rows)
         lead = max(lead, fastest - slowest)
