@@ -284,9 +284,12 @@ def main():
     import mbb_emcee_amd as mbb
     allw = walkers(world)
     nwt = NW_PER_GPU * world
-    modes = [args.exchange] if args.exchange != "auto" else ["ipc", "rccl"]
-    if world > ndev:
-        modes = ["ipc"]
+    # "ipc": the one-hop exchange, first as ONE launch per run on every rank (k_lnlike SMODE 6:
+    # decisions, rows and words stored into every rank's copy as they are made), then, should that
+    # not come up or not agree, as one launch per half-step with the rows exchanged after it
+    modes = {"auto": ["ipc", "ipc-launches", "rccl"], "ipc": ["ipc", "ipc-launches"], "rccl": ["rccl"]}[args.exchange]
+    if world > ndev and not os.environ.get("MBB_BENCH_TRY_ONE_LAUNCH"):
+        modes = ["ipc-launches"]        # (ranks sharing a device: their kernels cannot all be resident)
     if world == 1:
         modes = ["none"]
     collective, tried, smp = "none", [], None
@@ -302,10 +305,16 @@ def main():
     for mode in modes:
         ok, why = True, ""
         try:
-            if mode == "ipc":
+            if mode in ("ipc", "ipc-launches"):
                 from mbb_emcee_amd import parallel
                 parallel.ipc_exchange_setup(ctx, rank, world, dist, max_rows=max(4096, nwt))
-                collective = ("one-hop peer writes: the lane that accepts a move stores the state row (6 f64) "
+                ctx.set_option("sharded_flow_sampler", 1 if mode == "ipc" else 0)
+                ctx.set_option("flow_spin_log2", 20)      # (a run that cannot proceed gives up within seconds)
+                collective = ("one-hop peer writes, one launch per run: every decision, moved row and progress word is "
+                              "stored into every rank's copy of the run's state as it is made (hipIpc mappings, system "
+                              "scope) and a row's half-step starts when the rows it depends on are done, on whatever "
+                              "GPU; no collective library" if mode == "ipc" else
+                              "one-hop peer writes: the lane that accepts a move stores the state row (6 f64) "
                               "into every rank's copy of the ensemble (hipIpc mappings, system scope) and the "
                               "launch's last walker raises a flag in every peer; no collective library")
             elif mode == "rccl":
@@ -318,7 +327,7 @@ def main():
         if not all_ok(ok):
             tried.append("%s %s" % (mode, why or "set-up failed on another rank"))
             try:
-                ctx.xchg_close() if mode == "ipc" else ctx.comm_destroy()
+                ctx.xchg_close() if mode.startswith("ipc") else ctx.comm_destroy()
             except Exception:
                 pass
             continue
@@ -356,7 +365,7 @@ def main():
             gc.collect()
             try:
                 ctx.sync()
-                ctx.xchg_close() if mode == "ipc" else (ctx.comm_destroy() if mode == "rccl" else None)
+                ctx.xchg_close() if mode.startswith("ipc") else (ctx.comm_destroy() if mode == "rccl" else None)
             except Exception:
                 pass
 
@@ -424,12 +433,12 @@ def main():
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = ctx.info("last_kernel_form")
         out["config"] = dict(out["config"])
-        if form == 5:
+        if form in (5, 6):
             nlaunch = (args.steps + 4095) // 4096
             kern_label = ("k_lnlike<thick,alpha,one-launch look-ahead run,staged>: %d workgroups move walkers, %d work "
                           "ahead" % (half, ctx.info("last_workgroups_ahead")))
-            out["config"]["sampler_form"] = ("one launch per 4096 steps (k_lnlike SMODE 5): the timed region is %d launch(es) "
-                                             "of %d half-steps" % (nlaunch, 2 * args.steps))
+            out["config"]["sampler_form"] = ("one launch per 4096 steps%s (k_lnlike SMODE %d): the timed region is %d launch(es) "
+                                             "of %d half-steps" % (" on every rank" if form == 6 else "", form, nlaunch, 2 * args.steps))
             out["kernel_avg_us"] = stream_ms * 1e3 / nlaunch
         else:
             kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
@@ -455,7 +464,7 @@ def main():
         gc.collect()
         if mode_used == "rccl":
             ctx.comm_destroy()
-        elif mode_used == "ipc":
+        elif mode_used.startswith("ipc"):
             ctx.xchg_close()
         dist.destroy_process_group()
 

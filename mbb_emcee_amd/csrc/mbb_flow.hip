@@ -1,4 +1,4 @@
-// mbb_flow.hip -- the one-launch look-ahead sampler run (k_lnlike, SMODE 5) in a translation unit
+// mbb_flow.hip -- the one-launch look-ahead sampler run (k_lnlike, SMODE 5; SMODE 6 sharded) in a translation unit
 // of its own, because it wants other code generation than the rest of the library: the kernel
 // is a loop over half-steps around two long dependent chains, and with the default pipeline the
 // compiler hoists every loop-invariant value out of that loop, runs out of registers and
@@ -10,7 +10,9 @@
 
 #define MBB_FLOW_INST(OT, NA)                                            \
     template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
-    template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);
+    template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);  \
+    template __global__ void k_lnlike<OT, NA, 6, false>(const LikeArgs); \
+    template __global__ void k_lnlike<OT, NA, 6, true>(const LikeArgs);
 MBB_FLOW_INST(false, false)
 MBB_FLOW_INST(false, true)
 MBB_FLOW_INST(true, false)

@@ -26,10 +26,12 @@
 #include "mbb_device.hip.h"
 #include "mbb_kernels.hip.h"
 
-// SMODE 5 is instantiated in mbb_flow.hip (its own compiler flags)
+// SMODE 5 and 6 are instantiated in mbb_flow.hip (its own compiler flags)
 #define MBB_FLOW_EXT(OT, NA)                                                    \
     extern template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
-    extern template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);
+    extern template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);  \
+    extern template __global__ void k_lnlike<OT, NA, 6, false>(const LikeArgs); \
+    extern template __global__ void k_lnlike<OT, NA, 6, true>(const LikeArgs);
 MBB_FLOW_EXT(false, false)
 MBB_FLOW_EXT(false, true)
 MBB_FLOW_EXT(true, false)
@@ -152,10 +154,11 @@ struct mbb_ctx {
     unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
     long opt_flow_spin_log2 = 0;   // one-launch run: log2 of the polls before a wait gives up (0: the kernel's 22)
     long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
+    long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[48] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[56] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -170,10 +173,14 @@ struct mbb_ctx {
         unsigned char *base = nullptr;            // own allocation
         unsigned char *peer[16] = {};             // every rank's allocation as mapped here (own = base)
         XchgArgs *d_args = nullptr;               // the kernel's view (device memory)
+        FlowX *d_flowx = nullptr;                 // the one-launch sharded run's view of every rank's copy (device memory)
+        unsigned long long flow_run = 0;          // one-launch sharded runs so far (the same on every rank)
         unsigned long long seq = 0;               // launches posted so far
         long long spin_max = 4000000;
         static constexpr size_t kHeader = 256;
         double *pos6(int r) const { return reinterpret_cast<double *>(peer[r] + kHeader); }
+        // behind the rows: the state of a one-launch run (FlowView, mbb_kernels.hip.h), sized for cap_rows
+        double *flow(int r) const { return reinterpret_cast<double *>(peer[r] + kHeader + cap_rows * 6 * sizeof(double)); }
         unsigned long long *flags(int r) const { return reinterpret_cast<unsigned long long *>(peer[r]); }
         unsigned int *count() const { return reinterpret_cast<unsigned int *>(base + 128); }
     } x;
@@ -508,6 +515,7 @@ struct SamplerLaunch {
     double *spec;                 // != nullptr: look-ahead run (k_lnlike SMODE 4), records + state
     int spec_cfg;                 // LikeArgs::spec_cfg
     bool spec_first;              // the run's first launch: nobody moves
+    bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -585,7 +593,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             // the movers.  A constructor is one dependent chain: a wave alone on its SIMD runs it
             // fastest, so the candidates are spread as thinly as the CUs the movers leave free allow.
             int rows, aw, n_ahead;
-            lookahead_plan(c, grid, threads, sl->c_count, sl->persist > 0, rows, aw, n_ahead);
+            lookahead_plan(c, grid, threads, sl->persist > 0 ? sl->m_count : sl->c_count, sl->persist > 0, rows, aw, n_ahead);
             a.spec = sl->spec;
             a.spec_cfg = sl->spec_cfg | (rows << 8) | (aw << 16) |
                          (sl->persist ? (int)((c->opt_flow_spin_log2 & 0x3f) << 24) : 0);
@@ -601,8 +609,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
-        const int smode = !sl ? 0 : (sl->spec ? (sl->persist ? 5 : 4) : (sl->persist ? 3 : (sl->xseq ? 2 : 1)));
-        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 12 + smode * 2 + (stage ? 1 : 0);
+        const int smode = !sl ? 0 : (sl->spec ? (sl->persist ? (sl->xflow ? 6 : 5) : 4) : (sl->persist ? 3 : (sl->xseq ? 2 : 1)));
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 14 + smode * 2 + (stage ? 1 : 0);
         c->last_smode = smode;
         c->last_ahead = smode >= 4 ? a.n_ahead : 0;
         vi_of_kernel = vi;
@@ -610,8 +618,9 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
         k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>,           \
         k_lnlike<OT, NA, 3, false>, k_lnlike<OT, NA, 3, true>, k_lnlike<OT, NA, 4, false>,          \
-        k_lnlike<OT, NA, 4, true>, k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>
-        static void (*const table[48])(const LikeArgs) = {
+        k_lnlike<OT, NA, 4, true>, k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>,           \
+        k_lnlike<OT, NA, 6, false>, k_lnlike<OT, NA, 6, true>
+        static void (*const table[56])(const LikeArgs) = {
             MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
             MBB_VARIANTS(true, true)};
 #undef MBB_VARIANTS
@@ -896,6 +905,55 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
     sl.xseq = 0; sl.persist = 0; sl.gbar = nullptr;
     sl.spec = nullptr; sl.spec_cfg = 0; sl.spec_first = false;
+    // A sharded ensemble with the one-hop exchange, one launch per run (k_lnlike SMODE 6): every rank
+    // moves its share of each half and prepares their proposals ahead, decisions / rows / words go
+    // into every rank's copy of the run's state (behind the rows in the exchange buffer) at system
+    // scope, and a row's half-step starts when the rows it depends on are done, on whatever GPU.
+    // Around the launch: set up this rank's copy, tell the peers (a mover's first store into a
+    // peer's copy waits for that peer's word), launch, tell the peers the launch has ended, wait
+    // for theirs (no store of theirs is in flight any more), bring the rows up to date.
+    {
+        int wpb_x = 0, thr_x = 0, la_rows, la_aw, la_ahead;
+        pick_geometry(c, (int)nl, wpb_x, thr_x);
+        lookahead_plan(c, (int)nl, thr_x, p.per, true, la_rows, la_aw, la_ahead);
+        if (p.xchg && c->opt_lookahead && c->opt_flow && c->opt_xflow && s->nsrc == 1 && nsteps > 0 && wpb_x == 1 &&
+            la_ahead + (int)nl <= c->cu_count && (size_t)s->rows() <= c->x.cap_rows) {
+            const size_t R = (size_t)s->rows();
+            double *mine = c->x.flow(c->x.rank);
+            const FlowView fvl = flow_view(mine, (int)R);
+            sl.spec = reinterpret_cast<double *>(c->x.d_flowx);
+            sl.xflow = true;
+            for (int t0 = 0; t0 < nsteps; t0 += 4096) {
+                const int nt = std::min(4096, nsteps - t0);
+                FlowX fxh;
+                memset(&fxh, 0, sizeof fxh);
+                for (int r = 0; r < c->x.n; ++r) fxh.base[r] = c->x.flow(r);
+                fxh.n = c->x.n; fxh.rank = c->x.rank; fxh.run = ++c->x.flow_run;
+                HIPCHK(hipMemcpyAsync(c->x.d_flowx, &fxh, sizeof fxh, hipMemcpyHostToDevice, c->stream));
+                hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
+                                   s->d_pos6, mine, (int)R);
+                hipLaunchKernelGGL(k_flow_post, dim3(1), dim3(64), 0, c->stream, c->x.d_flowx, (int)R, 0, fxh.run,
+                                   (const int *)nullptr);
+                HIPCHK(hipGetLastError());
+                sl.s_begin = c->x.rank * p.per; sl.c_begin = half; sl.step = t0; sl.half = 0;
+                sl.persist = 2 * nt;
+                sl.chain6 = store ? s->d_chain6 + ((((size_t)c->x.rank * nsteps + t0) * 2) * nl) * 6 : nullptr;
+                sl.nacc = s->d_nacc + (size_t)c->x.rank * 2 * nl;
+                sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
+                sl.spec_cfg = 0; sl.spec_first = false;
+                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+                hipLaunchKernelGGL(k_flow_post, dim3(1), dim3(64), 0, c->stream, c->x.d_flowx, (int)R, 1, fxh.run,
+                                   (const int *)s->d_err);
+                hipLaunchKernelGGL(k_flow_wait_end, dim3(1), dim3(64), 0, c->stream, fvl.endf, c->x.n, c->x.rank, fxh.run,
+                                   c->x.spin_max, s->d_err);
+                hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream,
+                                   s->d_pos6, mine, (int)R, 2 * nt);
+                HIPCHK(hipGetLastError());
+            }
+            s->steps_done += (unsigned long long)nsteps;
+            return MBB_OK;
+        }
+    }
     // Option "persistent_sampler" 1 -- one GPU, one ensemble, at most one walker per CU: the
     // whole run in ONE launch per 4096 steps (k_lnlike SMODE 3: every workgroup is resident,
     // the half-steps hand over inside the kernel).  Off by default: measured slower.
@@ -956,6 +1014,10 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
                 sl.spec_cfg = 0; sl.spec_first = false;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+                // the sampler's rows from the slots the launch's last moves went to
+                hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream,
+                                   s->d_pos6, s->d_spec, (int)R, 2 * nt);
+                HIPCHK(hipGetLastError());
             }
             s->steps_done += (unsigned long long)nsteps;
             return MBB_OK;
@@ -1425,6 +1487,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
+    else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;
     else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
     else if (!strcmp(name, "lookahead_waves")) c->opt_la_waves = value;
     else if (!strcmp(name, "roof_wgs_per_cu")) c->opt_roof_wgs = value;
@@ -1473,6 +1536,7 @@ static int xchg_free(mbb_ctx *c)
         if (r != c->x.rank && c->x.peer[r]) (void)hipIpcCloseMemHandle(c->x.peer[r]);
     free_dev(c->x.base);
     free_dev(c->x.d_args);
+    free_dev(c->x.d_flowx);
     c->x = mbb_ctx::Xchg();
     return MBB_OK;
 }
@@ -1485,7 +1549,8 @@ extern "C" int mbb_xchg_open(mbb_ctx *c, int nranks, int rank, int max_rows, uns
         return fail(MBB_ERR_ARG, "bad exchange layout (at most 16 ranks)");
     if (c->x.base) return fail(MBB_ERR_STATE, "this context already has an exchange (mbb_xchg_close first)");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-    const size_t bytes = mbb_ctx::Xchg::kHeader + (size_t)max_rows * 6 * sizeof(double);
+    const size_t bytes = mbb_ctx::Xchg::kHeader + (size_t)max_rows * 6 * sizeof(double) +
+                         spec_words((size_t)max_rows) * sizeof(double);
     // fine-grained: peers' system-scope stores must be visible to this device's loads while
     // kernels run on both sides
     HIPCHK(hipExtMallocWithFlags((void **)&c->x.base, bytes, hipDeviceMallocFinegrained));
@@ -1518,6 +1583,7 @@ extern "C" int mbb_xchg_connect(mbb_ctx *c, const unsigned char *handles)
         c->x.peer[r] = (unsigned char *)p;
     }
     HIPCHK(hipMalloc((void **)&c->x.d_args, sizeof(XchgArgs)));
+    HIPCHK(hipMalloc((void **)&c->x.d_flowx, sizeof(FlowX)));
     c->x.connected = 1;
     return MBB_OK;
 }

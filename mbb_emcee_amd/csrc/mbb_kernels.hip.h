@@ -141,19 +141,25 @@ constexpr int kSpecRec = 32;  // doubles per record: WalkerK (13), proposal (5),
 //                   the writer neither waits for its stores nor raises a flag after them
 //   st    [kFlowSlots][nw][8]            the row after move m (slot 0: as the run found it)
 //   seq   [nw]      the half-step after the last one whose row has LANDED in st (0: none)
-//   done  [8][16]   moves completed per half-step mod 8 (the lag guard)
+//   done  [8][16]   this GPU's moves completed per half-step mod 8; the last one of a half-step says
+//                   so in pub (the lag guard)
 //   mseq  [nw][kFlowSlots]  2 x (half-step of move m + 1) + (it was accepted): written the moment
 //                   the move is decided, before the row itself
+//   pub   [16][8]   per rank of a sharded run (SMODE 6; one rank otherwise) and half-step mod 8: that
+//                   half-step + 1 once all of the rank's moves of it are complete
+//   startf, endf [16]  per rank: the number of the run whose state is set up / whose launch has ended
+// In a sharded run every rank holds all of it (its own records only) in memory its peers have
+// mapped, and whoever publishes a decision, a row or a word stores it into every rank's copy.
 constexpr int kFlowRecN = 22, kFlowRec = 48;
 struct FlowView {
     double *rec, *st;
-    unsigned long long *seq, *done, *mseq;
+    unsigned long long *seq, *done, *mseq, *pub, *startf, *endf;
 };
 __host__ __device__ constexpr size_t spec_words(size_t nw)
 {
-    return nw * ((size_t)kFlowSlots * 2 * kFlowRec + kFlowSlots * 8 + 1 + kFlowSlots) + 8 * 16;
+    return nw * ((size_t)kFlowSlots * 2 * kFlowRec + kFlowSlots * 8 + 1 + kFlowSlots) + 8 * 16 + 16 * 8 + 32;
 }
-__device__ __forceinline__ FlowView flow_view(double *spec, int nw)
+__host__ __device__ __forceinline__ FlowView flow_view(double *spec, int nw)
 {
     FlowView v;
     v.rec = spec;
@@ -161,8 +167,18 @@ __device__ __forceinline__ FlowView flow_view(double *spec, int nw)
     v.seq = reinterpret_cast<unsigned long long *>(v.st + (size_t)nw * kFlowSlots * 8);
     v.done = v.seq + nw;
     v.mseq = v.done + 8 * 16;
+    v.pub = v.mseq + (size_t)nw * kFlowSlots;
+    v.startf = v.pub + 16 * 8;
+    v.endf = v.startf + 16;
     return v;
 }
+// A sharded one-launch run (SMODE 6): where every rank's copy is mapped here.  In device memory;
+// a.spec points at it (and base[rank] is this rank's own copy).
+struct FlowX {
+    double *base[16];
+    int n, rank;
+    unsigned long long run;      // number of this run (the same on every rank)
+};
 // (flow_cnt, flow_seq: mbb_flow_index.h)
 
 __device__ __forceinline__ double ld_sys(const double *p)      // system-scope load (bypasses L1)
@@ -253,8 +269,23 @@ __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsign
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
-    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, FLOW = SMODE == 5, PERSIST = SMODE == 3 || FLOW,
-                   SPEC = SMODE == 4 || FLOW;
+    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, XF = SMODE == 6, FLOW = SMODE == 5 || XF,
+                   PERSIST = SMODE == 3 || FLOW, SPEC = SMODE == 4 || FLOW;
+    // SMODE 6, the one-launch run of a sharded ensemble: this rank's copy of the run's state and
+    // its peers'; words and rows that cross GPUs are read and written at system scope
+    const FlowX *const fx = XF ? reinterpret_cast<const FlowX *>(a.spec) : nullptr;
+    const int npeer = XF ? fx->n : 1, xrank = XF ? fx->rank : 0;
+    auto peer_view = [&](int pr) { return flow_view(XF ? fx->base[pr] : a.spec, a.nw); };
+    auto fl_ld = [&](const double *q) { if constexpr (XF) return ld_sys(q); else return ld_dev(q); };
+    auto fl_st = [&](double *q, double v) { if constexpr (XF) st_sys(q, v); else st_dev(q, v); };
+    auto fl_ldw = [&](const unsigned long long *q) {
+        if constexpr (XF) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto fl_stw = [&](unsigned long long *q, unsigned long long v) {
+        if constexpr (XF) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
     __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
@@ -441,7 +472,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             // (a proposal takes about a half-step to prepare; what can be fetched before the
             // decision it waits for is fetched during the half-step in between)
             const int wh = FLOW ? (pair >> 1) & 1 : 0;
-            const bool active = wave < aw && (lane >> 4) < rpw && pair < (FLOW ? 4 : 2) * a.c_count && !(first && (pair & 1));
+            const bool active = wave < aw && (lane >> 4) < rpw && pair < (FLOW ? 4 * a.m_count : 2 * a.c_count) &&
+                                !(first && (pair & 1));
             const int loc = FLOW ? pair >> 2 : pair >> 1, cand = pair & 1;
             double *lst = s_pb;
             if constexpr (!FLOW) {
@@ -460,7 +492,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             }
             // SMODE 5: half-step j of the run is prepared as soon as the rows it starts from are
             // there -- the state as of the start of half-step j - 1 -- while j - 1 is still moving
-            const FlowView fv = flow_view(a.spec, a.nw);
+            const FlowView fv = peer_view(xrank);
             const int nj = FLOW ? a.persist : 1;
             for (int j = wh; j < nj; j += FLOW ? 2 : 1) {
             // the draws: the walker's own for the half-step being prepared, and the one its
@@ -476,7 +508,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             const unsigned long long seed_p =
                 FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((j - 1) >> 1) : a.seed;
             const bool c1 = cand && (!FLOW || j > 0);
-            const int rown = sb + loc;
+            const int rown = sb + (FLOW ? a.s_begin : 0) + loc;      // (SMODE 5/6: s_begin = this rank's offset in a half)
             STAMP(11);
             double zz = 1.0, u3 = 0.5, zp = 1.0, up;
             int pj = 0, pjp = 0;
@@ -515,7 +547,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     long long spins = 0;
                     for (;;) {
                         bool ok = true;
-                        if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
+                        if (watch) { v = fl_ldw(word); ok = (v >> shift) >= need; }
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0 || flow_dead) break;
                         ++spins;
                         if (spins > flow_spin_limit ||
@@ -563,7 +595,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                             const int grp = e / 5, i = e - 5 * grp;
                             const double *src = grp == 0 ? o_r : (grp == 1 ? n_r : (grp == 2 ? o_p : (grp == 3 ? n_p : sp)));
                             const bool want = grp == 0 || grp == 4 || (grp == 1 && m_s > 0) || (grp == 2 && c1) || (grp == 3 && c1 && m_s > 0);
-                            scr[e] = want ? ld_dev(src + i) : 0.0;
+                            scr[e] = want ? fl_ld(src + i) : 0.0;
                         }
                     }
                 }
@@ -653,7 +685,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     int pend_row = -1, pend_it = 0;
     for (int it = 0; it < niter; ++it) {
     const int L_step = PERSIST ? a.step + (it >> 1) : a.step, L_half = PERSIST ? (it & 1) : a.half;
-    const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) : a.s_begin;
+    const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) + (FLOW ? a.s_begin : 0) : a.s_begin;
     const int L_c_begin = PERSIST ? (L_half ? 0 : a.c_count) : a.c_begin;
     const unsigned long long L_seed = PERSIST ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1) : a.seed;
     double *const L_chain6 = (PERSIST && a.chain6) ? a.chain6 + (size_t)it * a.n * 6 : a.chain6;
@@ -665,7 +697,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if constexpr (SPEC) {
         if (wave == 0) {
             const int row = L_s_begin + w0;                   // one ensemble, one walker per workgroup
-            const FlowView fv = flow_view(a.spec, a.nw);
+            const FlowView fv = peer_view(xrank);
             const double *rec = FLOW ? fv.rec + ((size_t)row * kFlowSlots + ((flow_cnt(L_half, it) + 1) % kFlowSlots)) * 2 * kFlowRec
                                      : a.spec + (size_t)row * 2 * kSpecRec;
             double r0 = 0.0, r1 = 0.0, flag = 0.0;
@@ -684,10 +716,22 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 // lane 23 the lag guard.  When all of it is there already, that is one round trip.
                 const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
                 const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
-                const unsigned long long need_g = (unsigned long long)a.n * (unsigned long long)(((it - kFlowLag) >> 3) + 1);
-                const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
-                                                            : fv.done + ((it - kFlowLag) & 7) * 16;
-                const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag);
+                // lane 23: this GPU's count of half-step it - kFlowLag (the lag guard); a sharded run
+                // besides: lanes 24 ..: the other ranks' words for that half-step (its first mover
+                // workgroup tells them this rank's, the moment the count is full), lanes 40 .. (first
+                // half-step): every peer has set up its copy of this run
+                const int gl = lane - 24, sl = lane - 40;
+                const bool guard = XF && gl >= 0 && gl < npeer && gl != xrank && it >= kFlowLag;
+                const bool started = XF && it == 0 && sl >= 0 && sl < npeer;
+                const unsigned long long need_g =
+                    started ? fx->run : (guard ? (unsigned long long)(it - kFlowLag + 1)
+                                               : (unsigned long long)a.n * (unsigned long long)(((it - kFlowLag) >> 3) + 1));
+                const unsigned long long *word =
+                    lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
+                               : (started ? fv.startf + sl
+                                          : (guard ? fv.pub + gl * 8 + ((it - kFlowLag) & 7) : fv.done + ((it - kFlowLag) & 7) * 16));
+                const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag) || guard || started;
+                bool told = !(XF && w0 == 0 && it >= kFlowLag);           // (this workgroup has nothing to tell, or has)
                 const int c = lane < kFlowRecN ? lane : 0;
                 unsigned long long pv = 0;
                 bool rec_ok = false, word_ok = !watch;
@@ -704,7 +748,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                                  (t1 ^ (unsigned long long)__double_as_longlong(r1)) == tag;
                     }
                     if (watch && !word_ok) {
-                        pv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv = fl_ldw(word);
                         word_ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g);
                     }
                     if (pend_row >= 0) {
@@ -713,12 +757,18 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         // and the loads above came after those stores; the explicit wait costs nothing
                         // then.  Its word, for the workgroups that work ahead from that row.
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (XF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // across GPUs: a full release
                         if (lane == 0) {
-                            __hip_atomic_store(fv.seq + pend_row, (unsigned long long)(pend_it + 1), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+                            for (int pr = 0; pr < npeer; ++pr) fl_stw(peer_view(pr).seq + pend_row, (unsigned long long)(pend_it + 1));
                             __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         pend_row = -1;
+                    }
+                    if (!told && __builtin_amdgcn_ballot_w64(lane == 23 && word_ok) != 0) {
+                        // this rank has completed half-step it - kFlowLag: every peer's guard may know
+                        if (lane < npeer && lane != xrank)
+                            fl_stw(peer_view(lane).pub + xrank * 8 + ((it - kFlowLag) & 7), (unsigned long long)(it - kFlowLag + 1));
+                        told = true;
                     }
                     if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0 || flow_dead) break;
                     ++spins;
@@ -731,7 +781,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (it < 2) {
-                    if (lane < 8) own_reg = ld_dev(fv.st + (size_t)row * 8 + lane);
+                    if (lane < 8) own_reg = fl_ld(fv.st + (size_t)row * 8 + lane);
                 } else {
                     own_reg = L_half ? own_half[1] : own_half[0];
                 }
@@ -1105,24 +1155,21 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     }
                 } else if (FLOW) {
                     // the decision first -- all the partner's next mover waits for --, then the row
-                    // as it is after this half-step, write-through, to its next slot; the row's
-                    // own word follows at the start of the next half-step, when the stores have
-                    // landed.  (pos6, counts and chain are for the host: plain stores.)
-                    const FlowView fv = flow_view(a.spec, a.nw);
+                    // as it is after this half-step, write-through, to its next slot (every rank's
+                    // copy in a sharded run); the row's own word follows at the start of the next
+                    // half-step, when the stores have landed.  pos6 is brought up to date once, when
+                    // the launch has ended (k_flow_finish); counts and chain are for the host: plain stores.
                     const int m_new = flow_cnt(L_half, it) + 1;
-                    __hip_atomic_store(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
-                                       2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    double *dst = fv.st + ((size_t)(m_new % kFlowSlots) * a.nw + row) * 8;
+                    for (int pr = 0; pr < npeer; ++pr)
+                        fl_stw(peer_view(pr).mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
+                               2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull));
+                    for (int pr = 0; pr < npeer; ++pr) {
+                        double *dst = peer_view(pr).st + ((size_t)(m_new % kFlowSlots) * a.nw + row) * 8;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) st_dev(dst + i, accept ? q[i] : old5[i]);
-                    st_dev(dst + 5, accept ? r : q[6]);
-                    if (accept) {
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) srow[i] = q[i];
-                        srow[5] = r;
-                        atomicAdd(&L_nacc[w], 1u);
+                        for (int i = 0; i < 5; ++i) fl_st(dst + i, accept ? q[i] : old5[i]);
+                        fl_st(dst + 5, accept ? r : q[6]);
                     }
+                    if (accept) atomicAdd(&L_nacc[w], 1u);
                     if (L_chain6) {
                         double *crow = L_chain6 + (size_t)w * 6;
 #pragma unroll
@@ -1234,8 +1281,54 @@ static __global__ void k_flow_init(const double *pos6, double *spec, int nw)
         const int row = i >> 3, e = i & 7;
         fv.st[i] = e < 6 ? pos6[(size_t)row * 6 + e] : 0.0;
     }
-    const int nwords = nw * (1 + kFlowSlots) + 8 * 16;        // seq, done, mseq are contiguous
+    const int nwords = nw * (1 + kFlowSlots) + 8 * 16 + 16 * 8;   // seq, done, mseq, pub are contiguous
     for (int k = i; k < nwords; k += gridDim.x * blockDim.x) fv.seq[k] = 0ull;
+}
+
+// SMODE 5, 6, when a launch of `nhalf` half-steps has ended: the sampler's rows from the slots
+// the last moves went to (every row is in this GPU's copy, whoever moved it).
+static __global__ void k_flow_finish(double *pos6, double *spec, int nw, int nhalf)
+{
+    const FlowView fv = flow_view(spec, nw);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw * 6) return;
+    const int row = i / 6, e = i - 6 * row;
+    const int slot = flow_cnt(row < nw / 2 ? 0 : 1, nhalf) % kFlowSlots;
+    pos6[i] = __hip_atomic_load(fv.st + ((size_t)slot * nw + row) * 8 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// SMODE 6: tells every rank that this rank's copy is set up for run `run` (which = 0) or that
+// its launch of that run has ended (which = 1; with the top bit set if the launch gave up: what it
+// stored into the peers' copies after that is not to be trusted, so they must fail too).  One wave.
+static __global__ void k_flow_post(const FlowX *fx, int nw, int which, unsigned long long run, const int *errflag)
+{
+    const int pr = threadIdx.x;
+    if (pr >= fx->n) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    const FlowView v = flow_view(fx->base[pr], nw);
+    const unsigned long long bad = (which && errflag && *errflag != 0) ? (1ull << 63) : 0ull;
+    __hip_atomic_store((which ? v.endf : v.startf) + fx->rank, run | bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// SMODE 6: holds the stream until every peer's launch of run `run` has ended (none of its stores
+// into this rank's copy is in flight any more); a peer that gave up, or does not answer, fails
+// this rank's run too.  One wave.
+static __global__ void k_flow_wait_end(const unsigned long long *endf, int xn, int xrank, unsigned long long run,
+                                       long long spin_max, int *errflag)
+{
+    const int l = threadIdx.x;
+    long long spins = 0;
+    for (;;) {
+        unsigned long long v = run;
+        if (l < xn && l != xrank) v = __hip_atomic_load(endf + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (__builtin_amdgcn_ballot_w64((v & ~(1ull << 63)) < run) == 0) {
+            if (__builtin_amdgcn_ballot_w64((v >> 63) != 0) != 0) atomicMax(errflag, 9);
+            break;
+        }
+        if (++spins > spin_max) { atomicMax(errflag, 8); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 // Sharded run, one-hop exchange: holds the stream until every peer has posted launch

@@ -28,46 +28,59 @@ def main():
     nw, nsteps = 48, 12
     rng = np.random.RandomState(3)                     # the same on every rank
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(nw, 5)))
-    # the unsharded run, on a context of its own
-    ref_like = make()
-    ref = mbb.DeviceEnsembleSampler(nw, 5, ref_like, seed=21)
-    rpos, rlnp, _ = ref.run_mcmc(p0, nsteps)
-    rchain, rlnpc, racc = ref.chain.copy(), ref.lnprobability.copy(), ref.naccepted.copy()
-    rpos2, rlnp2, _ = ref.run_mcmc(None, 5)
-    # the sharded run
     like = make()
     ctx = like._sync_device()
     parallel.ipc_exchange_setup(ctx, rank, world, dist, max_rows=256)
     assert ctx.info("nranks") == world and ctx.info("rank") == rank
-    smp = mbb.DeviceEnsembleSampler(nw, 5, like, seed=21)
-    pos, lnp, _ = smp.run_mcmc(p0, nsteps)
-    half, per = nw // 2, nw // 2 // world
-    mine = np.r_[rank * per:(rank + 1) * per, half + rank * per:half + (rank + 1) * per]
-    assert np.array_equal(pos, rpos) and np.array_equal(lnp, rlnp), "final state differs on rank %d" % rank
-    assert np.array_equal(smp.chain[mine], rchain[mine]), "chain differs on rank %d" % rank
-    assert np.array_equal(smp.lnprobability[mine], rlnpc[mine])
-    assert np.array_equal(smp.naccepted[mine], racc[mine])
-    others = np.setdiff1d(np.arange(nw), mine)
-    assert not smp.chain[others].any()                 # left untouched for the caller to gather
-    assert ctx.info("xchg_launches") == 2 * nsteps
-    # continuing the chain, and the asynchronous form the benchmark uses
-    pos2, lnp2, _ = smp.run_mcmc(None, 5)
-    assert np.array_equal(pos2, rpos2) and np.array_equal(lnp2, rlnp2)
-    dist.barrier()
-    smp.advance_async(40)
-    ctx.sync()
-    ref.advance_async(40)
-    ref_like.context.sync()
-    a, la, _ = smp.run_mcmc(None, 0)
-    b, lb, _ = ref.run_mcmc(None, 0)
-    assert np.array_equal(a, b) and np.array_equal(la, lb)
-    # the whole chain, gathered by the caller over the side channel
-    full = smp.chain.copy()
-    import torch
-    t = torch.from_numpy(full)
-    dist.all_reduce(t)                                 # disjoint rows, zeros elsewhere: the sum is the gather
-    assert np.array_equal(t.numpy()[:, :nsteps], rchain)
-    dist.barrier()
+    # the sharded run in both its forms -- one launch per run, decisions / rows / words stored into
+    # every rank's copy as they are made (k_lnlike SMODE 6), and one launch per half-step with the
+    # moved rows exchanged after it (SMODE 2) -- against the unsharded run on a context of its own
+    launches_before = 0
+    for one_launch in (1, 0):
+        ctx.set_option("sharded_flow_sampler", one_launch)
+        ref_like = make()
+        ref = mbb.DeviceEnsembleSampler(nw, 5, ref_like, seed=21)
+        rpos, rlnp, _ = ref.run_mcmc(p0, nsteps)
+        rchain, rlnpc, racc = ref.chain.copy(), ref.lnprobability.copy(), ref.naccepted.copy()
+        rpos2, rlnp2, _ = ref.run_mcmc(None, 5)
+        smp = mbb.DeviceEnsembleSampler(nw, 5, like, seed=21)
+        pos, lnp, _ = smp.run_mcmc(p0, nsteps)
+        assert ctx.info("last_kernel_form") == (6 if one_launch else 2), ctx.info("last_kernel_form")
+        half, per = nw // 2, nw // 2 // world
+        mine = np.r_[rank * per:(rank + 1) * per, half + rank * per:half + (rank + 1) * per]
+        assert np.array_equal(pos, rpos) and np.array_equal(lnp, rlnp), "final state differs on rank %d (form %d)" % (rank, one_launch)
+        assert np.array_equal(smp.chain[mine], rchain[mine]), "chain differs on rank %d" % rank
+        assert np.array_equal(smp.lnprobability[mine], rlnpc[mine])
+        assert np.array_equal(smp.naccepted[mine], racc[mine])
+        others = np.setdiff1d(np.arange(nw), mine)
+        assert not smp.chain[others].any()                 # left untouched for the caller to gather
+        if not one_launch:
+            assert ctx.info("xchg_launches") - launches_before == 2 * nsteps
+        # continuing the chain, and the asynchronous form the benchmark uses
+        pos2, lnp2, _ = smp.run_mcmc(None, 5)
+        assert np.array_equal(pos2, rpos2) and np.array_equal(lnp2, rlnp2)
+        dist.barrier()
+        smp.advance_async(40)
+        ctx.sync()
+        ref.advance_async(40)
+        ref_like.context.sync()
+        a, la, _ = smp.run_mcmc(None, 0)
+        b, lb, _ = ref.run_mcmc(None, 0)
+        assert np.array_equal(a, b) and np.array_equal(la, lb)
+        # the whole chain, gathered by the caller over the side channel
+        full = smp.chain.copy()
+        import torch
+        t = torch.from_numpy(full)
+        dist.all_reduce(t)                                 # disjoint rows, zeros elsewhere: the sum is the gather
+        assert np.array_equal(t.numpy()[:, :nsteps], rchain)
+        dist.barrier()
+        launches_before = ctx.info("xchg_launches")
+        if one_launch:
+            del smp
+            import gc
+            gc.collect()
+    ctx.set_option("sharded_flow_sampler", 1)
+    ctx.set_option("flow_spin_log2", 13)
     # a peer that stops taking part must surface as an error on the others, not as a hang:
     # rank 1 sits this run out, rank 0's second launch waits for rank 1's flag, gives up
     # after xchg_spin_max polls and the run reports it
