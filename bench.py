@@ -15,8 +15,10 @@ workgroups move the walkers, 125 more prepare the next half-step's proposals (dr
 constructor, penalties) for both outcomes of each partner's pending move, and a row's
 half-step starts when the rows it depends on are done -- the same chain, bit for bit, as
 one launch per half-step (tests/test_gpu_parity.py).  With N > 1 ranks the ensemble is
-sharded (125 moving walkers per GPU per launch, one launch per half-step) and the moved
-state rows are exchanged after every launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
+sharded (125 moving walkers per GPU per half-step); the same one-launch run goes across the
+ranks (SMODE 6: decisions, rows and progress words stored into every rank's copy as they are
+made) or, if that does not come up, one launch per half-step with the moved state rows
+exchanged after every launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
 into every rank's copy through hipIpc mappings), or by an in-place ncclAllGather over
 RCCL (--exchange rccl; also the automatic fall-back).  Positions live in HBM for the whole run: there is no host round
 trip inside the timed region.  `value` = walker-likelihood evaluations per second of

@@ -196,7 +196,9 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row;
  * 0: the next half-step's proposals prepared by extra workgroups of every launch),
  * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
- * workgroup among those that work ahead), "flow_spin_log2" (0 = 22: log2 of the polls before a wait
+ * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
+ * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),
+ * "flow_spin_log2" (0 = 22: log2 of the polls before a wait
  * inside the one-launch run gives up; mbb_sampler_run then redoes the run as a launch train and
  * counts it in mbb_get_info "flow_fallbacks").  mbb_get_info "last_kernel_form" says which form ran. */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);

@@ -683,6 +683,10 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // lane l < 8 -- nobody else writes them; and the row whose word is still to be published
     double own_half[2] = {0.0, 0.0};
     int pend_row = -1, pend_it = 0;
+    // (a sharded run) this wave's place in the count of the half-step before that one, looked at a
+    // half-step after it was asked for: whoever came last tells every rank that this rank is through
+    unsigned long long cnt_seen = 0;
+    int cnt_it = -1;
     for (int it = 0; it < niter; ++it) {
     const int L_step = PERSIST ? a.step + (it >> 1) : a.step, L_half = PERSIST ? (it & 1) : a.half;
     const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) + (FLOW ? a.s_begin : 0) : a.s_begin;
@@ -717,9 +721,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(it + 1);
                 const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
                 // lane 23: this GPU's count of half-step it - kFlowLag (the lag guard); a sharded run
-                // besides: lanes 24 ..: the other ranks' words for that half-step (its first mover
-                // workgroup tells them this rank's, the moment the count is full), lanes 40 .. (first
-                // half-step): every peer has set up its copy of this run
+                // besides: lanes 24 ..: the other ranks' words for that half-step (whichever of a
+                // rank's movers completes a half-step last tells them), lanes 40 .. (first half-step):
+                // every peer has set up its copy of this run
                 const int gl = lane - 24, sl = lane - 40;
                 const bool guard = XF && gl >= 0 && gl < npeer && gl != xrank && it >= kFlowLag;
                 const bool started = XF && it == 0 && sl >= 0 && sl < npeer;
@@ -731,7 +735,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                                : (started ? fv.startf + sl
                                           : (guard ? fv.pub + gl * 8 + ((it - kFlowLag) & 7) : fv.done + ((it - kFlowLag) & 7) * 16));
                 const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag) || guard || started;
-                bool told = !(XF && w0 == 0 && it >= kFlowLag);           // (this workgroup has nothing to tell, or has)
                 const int c = lane < kFlowRecN ? lane : 0;
                 unsigned long long pv = 0;
                 bool rec_ok = false, word_ok = !watch;
@@ -760,15 +763,19 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         if (XF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // across GPUs: a full release
                         if (lane == 0) {
                             for (int pr = 0; pr < npeer; ++pr) fl_stw(peer_view(pr).seq + pend_row, (unsigned long long)(pend_it + 1));
-                            __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if constexpr (XF) {
+                                if (cnt_it >= 0 && cnt_seen + 1 == (unsigned long long)a.n * (unsigned long long)((cnt_it >> 3) + 1))
+                                    for (int pr = 0; pr < npeer; ++pr)
+                                        if (pr != xrank)
+                                            fl_stw(peer_view(pr).pub + xrank * 8 + (cnt_it & 7), (unsigned long long)(cnt_it + 1));
+                                cnt_seen = __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT);
+                                cnt_it = pend_it;
+                            } else {
+                                __hip_atomic_fetch_add(fv.done + (pend_it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                         }
                         pend_row = -1;
-                    }
-                    if (!told && __builtin_amdgcn_ballot_w64(lane == 23 && word_ok) != 0) {
-                        // this rank has completed half-step it - kFlowLag: every peer's guard may know
-                        if (lane < npeer && lane != xrank)
-                            fl_stw(peer_view(lane).pub + xrank * 8 + ((it - kFlowLag) & 7), (unsigned long long)(it - kFlowLag + 1));
-                        told = true;
                     }
                     if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0 || flow_dead) break;
                     ++spins;

@@ -1182,23 +1182,43 @@ def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
     ctx.comm_destroy()
 
 
-def test_one_hop_exchange_two_processes_one_gpu():
-    """The sharded device sampler with the one-hop peer-write exchange (mbb_xchg_*): two
-    processes on this one GPU map each other's copy of the ensemble through hipIpc, each
-    moves its block of every half-ensemble and stores the moved rows into both copies;
-    chains, final state and counts are bitwise those of the unsharded run
-    (tests/_xchg_worker.py).  On a multi-GPU node the same protocol crosses xGMI instead of
-    staying inside one device; that part cannot be exercised on a one-GPU box."""
+def _run_xchg_worker(nproc, extra_env=None):
     import os, subprocess, sys, socket
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tests", "_xchg_worker.py")]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    env.update(extra_env or {})
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode(errors="replace")
+    if out.returncode != 0 or "XCHG_OK" not in text:
+        try:                                           # the whole transcript: the first failing rank's lines are early in it
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "xchg_worker_%d_ranks.txt" % nproc), "w").write(text)
+        except OSError:
+            pass
     assert out.returncode == 0 and "XCHG_OK" in text, text[-4000:]
+
+
+def test_one_hop_exchange_two_processes_one_gpu():
+    """The sharded device sampler with the one-hop peer-write exchange (mbb_xchg_*): two
+    processes on this one GPU map each other's copy of the ensemble through hipIpc, each
+    moves its block of every half-ensemble and stores what it decides into both copies -- as
+    one launch per run handing over row by row across the ranks (k_lnlike SMODE 6) and as one
+    launch per half-step with the moved rows exchanged after it (SMODE 2); chains, final state
+    and counts are bitwise those of the unsharded run (tests/_xchg_worker.py).  On a multi-GPU
+    node the same protocol crosses xGMI instead of staying inside one device; that part cannot
+    be exercised on a one-GPU box."""
+    _run_xchg_worker(2)
+
+
+def test_one_hop_exchange_four_processes_one_gpu():
+    """The same with four ranks (96 walkers, 12 movers per rank and half-step): every rank's
+    movers wait for decisions made on three other ranks, every rank's lag guard for three others'
+    progress words."""
+    _run_xchg_worker(4, {"MBB_XCHG_TEST_WALKERS": "96", "MBB_XCHG_TEST_SKIP_LOST_PEER": "1"})
 
 
 def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
