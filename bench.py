@@ -381,6 +381,26 @@ def main():
             smp = None
             teardown()
             continue
+        if world > 1:
+            # ... and it is the chain of the UNSHARDED sampler: rank 0 runs the same 60 steps of the whole
+            # ensemble by itself (a walker's result does not depend on the launch that evaluates it, so the
+            # two must agree bit for bit); an exchange that is consistently wrong on every rank ends here
+            ok_ref = True
+            if rank == 0:
+                try:
+                    like_ref, _ = make_likelihood(local_rank % ndev)
+                    sref = mbb.DeviceEnsembleSampler(nwt, 5, like_ref, seed=11)
+                    pr, lr, _ = sref.run_mcmc(allw[:nwt], 60, storechain=False)
+                    ok_ref = ensemble_crc(pr, lr) == state["crc"]
+                    del sref, like_ref
+                except Exception as e:       # noqa
+                    ok_ref, state["err"] = False, repr(e)
+            if not all_ok(ok_ref):
+                tried.append("%s rehearsal: differs from the unsharded sampler's chain after 60 steps" % mode)
+                smp = None
+                teardown()
+                continue
+            base["config"]["rehearsal"] = "60 steps: every rank's copy and the unsharded sampler's state have the same CRC"
 
         # ---- the timed region: K dependent MCMC steps ----------------------------
         smp.advance_async(args.warmup)
