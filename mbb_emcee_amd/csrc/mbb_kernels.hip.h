@@ -314,8 +314,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const int w0 = (SMODE >= 4 ? (int)blockIdx.x - a.n_ahead : (int)blockIdx.x) * W;
     // SMODE 5: polls before a wait gives up and ends the run with error 9 (~1.5 us each)
-    const long long flow_spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
-    bool flow_dead = false;         // ... after which this wave waits for nothing any more: the run drains
+    // (taken from the argument block where it is needed, not kept in registers across the chains; once
+    // the error flag is up, every wait notices within a few polls and the run drains)
+#define MBB_FLOW_SPIN_LIMIT (1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22))
     // The compiler fetches kernel arguments where they are first used, one exposed
     // scalar-cache round trip (~200 cycles) each; on the latency path that is a
     // dozen of them.  Ask for the hot ones here so that they arrive in one batch.
@@ -548,12 +549,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     for (;;) {
                         bool ok = true;
                         if (watch) { v = fl_ldw(word); ok = (v >> shift) >= need; }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0 || flow_dead) break;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                         ++spins;
-                        if (spins > flow_spin_limit ||
-                            ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        if (spins > MBB_FLOW_SPIN_LIMIT ||
+                            ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                             atomicMax(a.errflag, 9);
-                            flow_dead = true;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -599,6 +599,14 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         }
                     }
                 }
+                // the proposals those two rows were tested on, formed now, in place of the rows they
+                // were proposed from: after the decisions only a selection is left
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (active && m_s > 0 && l16 < 10) {
+                    const int i = l16 < 5 ? l16 : l16 - 5, o = l16 < 5 ? 0 : 10;
+                    if (l16 < 5 || c1) scr[o + 5 + i] = stretch_q(scr[o + 5 + i], scr[o + i], l16 < 5 ? zr : zq);
+                }
                 // (2) the decisions of half-step j - 2 (lanes 0, 1): the hand-off this chain waits for
                 const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
                 const unsigned long long v2 = spin(w2, (unsigned long long)flow_seq(hj, m_s),
@@ -608,11 +616,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    snv[i] = ar ? stretch_q(scr[5 + i], scr[i], zr) : scr[i];
-                    cpv[i] = ap ? stretch_q(scr[15 + i], scr[10 + i], zq) : scr[10 + i];
-                    cpos[i] = scr[20 + i];
-                }
+                for (int i = 0; i < 5; ++i) { snv[i] = scr[(ar ? 5 : 0) + i]; cpv[i] = scr[(ap ? 15 : 10) + i]; cpos[i] = scr[20 + i]; }
             } else {
                 __syncthreads();
                 if (active) {
@@ -777,12 +781,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         }
                         pend_row = -1;
                     }
-                    if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0 || flow_dead) break;
+                    if (__builtin_amdgcn_ballot_w64((lane < kFlowRecN && !rec_ok) || !word_ok) == 0) break;
                     ++spins;
-                    if (spins > flow_spin_limit ||
-                        ((spins & 255) == 0 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (spins > MBB_FLOW_SPIN_LIMIT ||
+                        ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         atomicMax(a.errflag, 9);
-                        flow_dead = true;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
