@@ -765,8 +765,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                         // then.  Its word, for the workgroups that work ahead from that row.
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         if (XF) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");     // across GPUs: a full release
+                        if (XF && lane < npeer) fl_stw(peer_view(lane).seq + pend_row, (unsigned long long)(pend_it + 1));
                         if (lane == 0) {
-                            for (int pr = 0; pr < npeer; ++pr) fl_stw(peer_view(pr).seq + pend_row, (unsigned long long)(pend_it + 1));
+                            if (!XF) fl_stw(fv.seq + pend_row, (unsigned long long)(pend_it + 1));
                             if constexpr (XF) {
                                 if (cnt_it >= 0 && cnt_seen + 1 == (unsigned long long)a.n * (unsigned long long)((cnt_it >> 3) + 1))
                                     for (int pr = 0; pr < npeer; ++pr)
@@ -1169,16 +1170,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     // copy in a sharded run); the row's own word follows at the start of the next
                     // half-step, when the stores have landed.  pos6 is brought up to date once, when
                     // the launch has ended (k_flow_finish); counts and chain are for the host: plain stores.
+                    const FlowView fv = peer_view(xrank);
                     const int m_new = flow_cnt(L_half, it) + 1;
-                    for (int pr = 0; pr < npeer; ++pr)
-                        fl_stw(peer_view(pr).mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
+                    if constexpr (!XF)
+                        fl_stw(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
                                2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull));
-                    for (int pr = 0; pr < npeer; ++pr) {
-                        double *dst = peer_view(pr).st + ((size_t)(m_new % kFlowSlots) * a.nw + row) * 8;
+                    if constexpr (!XF) {
+                        double *dst = fv.st + ((size_t)(m_new % kFlowSlots) * a.nw + row) * 8;
 #pragma unroll
                         for (int i = 0; i < 5; ++i) fl_st(dst + i, accept ? q[i] : old5[i]);
                         fl_st(dst + 5, accept ? r : q[6]);
-                    }
+                    }                                          // (a sharded run: below, a lane per rank)
                     if (accept) atomicAdd(&L_nacc[w], 1u);
                     if (L_chain6) {
                         double *crow = L_chain6 + (size_t)w * 6;
@@ -1249,6 +1251,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         if constexpr (FLOW) {
             // the walker as it is now stays in this wave's registers for its next half-step
             const int acc_u = __builtin_amdgcn_readfirstlane(flow_accept);
+            if constexpr (XF) {
+                // the decision, into every rank's copy at once (lane pr stores to rank pr)
+                if (lane < npeer)
+                    fl_stw(peer_view(lane).mseq + (size_t)row_first * kFlowSlots + ((flow_cnt(L_half, it) + 1) % kFlowSlots),
+                           2ull * (unsigned long long)(it + 1) + (acc_u ? 1ull : 0ull));
+            }
             const double r_u = __shfl(flow_r, 0);
             double nv = own_reg;
             if (acc_u) {
@@ -1258,6 +1266,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 nv = lane < 6 ? t : nv;
             }
             if (L_half) own_half[1] = nv; else own_half[0] = nv;
+            if constexpr (XF) {
+                // the row as it is now into every rank's copy: lane pr stores to rank pr, an
+                // instruction per element instead of one per element and rank
+                const int m_new = flow_cnt(L_half, it) + 1;
+                double *dst = peer_view(lane < npeer ? lane : 0).st + ((size_t)(m_new % kFlowSlots) * a.nw + row_first) * 8;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const double ve = __shfl(nv, e);
+                    if (lane < npeer) fl_st(dst + e, ve);
+                }
+            }
             pend_row = row_first;
             pend_it = it;
         }
