@@ -20,6 +20,7 @@
 #include <functional>
 #include <string>
 #include <type_traits>
+#include <atomic>
 #include <vector>
 
 #include "../../include/mbb_hip.h"
@@ -500,7 +501,7 @@ static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, 
     n_ahead = (pairs + rows * aw - 1) / (rows * aw);
 }
 
-static unsigned long long g_flow_serial = 0;    // one-launch sampler runs started in this process (their check words)
+static std::atomic<unsigned long long> g_flow_serial{0};   // one-launch sampler runs started in this process (their check words)
 
 struct SamplerLaunch {
     double *pos6, *chain6;

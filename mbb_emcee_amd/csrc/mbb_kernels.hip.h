@@ -1286,6 +1286,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
     }   // half-steps of a persistent run
     STAMP(6);
+#undef MBB_FLOW_SPIN_LIMIT
 }
 
 // SMODE 4: both slots of the double-buffered state from the sampler's rows, accept flags clear.
