@@ -560,52 +560,91 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     }
                     return v;
                 };
-                // (1) rows that were settled a half-step or more ago have landed, one lane of the row each:
-                //  0, 1: the rows the two rows' move m_s was proposed from (their partners of then)
+                // A row's last proposal comes from its record where that is on this GPU (always the
+                // walker's own; its partner's partner's unless the run is sharded): the candidate its
+                // mover took is the one the earlier decision of ITS partner says.  A row of another
+                // rank's has no record here: its proposal is formed again from the row it was
+                // proposed from, which has to have landed.
+                constexpr bool rec_r = true, rec_p = !XF;
+                // (1) what was settled a half-step or more ago, one lane of the row each:
+                //  0, 1: for the two rows, that earlier decision (record) or the landing of the row the
+                //        move m_s was proposed from
                 //  2   : the partner's row before its pending move;  3, 4: the two rows before move m_s
                 const unsigned long long *w1 = fv.seq;
                 unsigned long long n1 = 0;
+                int sh1 = 0;
                 bool watch1 = false;
                 if (active) {
                     const unsigned long long nq = (unsigned long long)flow_seq(hj ^ 1, m_q);
                     const unsigned long long nold = (unsigned long long)flow_seq(hj, m_s - 1);
                     switch (l16) {
-                    case 0: w1 = fv.seq + (ob + qr); n1 = nq; watch1 = m_s > 0 && m_q > 0; break;
-                    case 1: w1 = fv.seq + (ob + qp); n1 = nq; watch1 = c1 && m_s > 0 && m_q > 0; break;
+                    case 0:
+                        w1 = rec_r ? fv.mseq + (size_t)(ob + qr) * kFlowSlots + (m_q % kFlowSlots) : fv.seq + (ob + qr);
+                        n1 = nq; sh1 = rec_r ? 1 : 0; watch1 = m_s > 0 && m_q > 0; break;
+                    case 1:
+                        w1 = rec_p ? fv.mseq + (size_t)(ob + qp) * kFlowSlots + (m_q % kFlowSlots) : fv.seq + (ob + qp);
+                        n1 = nq; sh1 = rec_p ? 1 : 0; watch1 = c1 && m_s > 0 && m_q > 0; break;
                     case 2: w1 = fv.seq + prow; n1 = (unsigned long long)flow_seq(hj ^ 1, m_o); watch1 = m_o > 0; break;
                     case 3: w1 = fv.seq + rown; n1 = nold; watch1 = m_s > 1; break;
                     case 4: w1 = fv.seq + pprow; n1 = nold; watch1 = c1 && m_s > 1; break;
                     default: break;
                     }
                 }
-                spin(w1, n1, watch1, 0);
+                const unsigned long long v1 = spin(w1, n1, watch1, sh1);
+                const int cr = (rec_r && m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 0) & 1ull) : 0;
+                const int cp = (rec_p && m_s > 0 && m_q > 0) ? (int)(__shfl(v1, base + 1) & 1ull) : 0;
                 // the rows -> this row's corner of LDS (the polynomial table's place), an element or
                 // two per lane: [0,5) the walker's row as it was, [5,10) the row its last move was
                 // proposed from, [10,20) the same two for the partner's partner, [20,25) the partner
                 double *scr = s_pb + (size_t)(wave * 4 + (lane >> 4)) * 32;
-                if (active) {
-                    const int so = (m_s > 0 ? m_s - 1 : 0) % kFlowSlots, sq = m_q % kFlowSlots;
-                    const double *o_r = fv.st + ((size_t)so * a.nw + rown) * 8, *o_p = fv.st + ((size_t)so * a.nw + pprow) * 8;
-                    const double *n_r = fv.st + ((size_t)sq * a.nw + ob + qr) * 8, *n_p = fv.st + ((size_t)sq * a.nw + ob + qp) * 8;
-                    const double *sp = fv.st + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * 8;
+                for (long long tries = 0;; ++tries) {
+                    bool bad = false;
+                    if (active) {
+                        const int so = (m_s > 0 ? m_s - 1 : 0) % kFlowSlots, sq = m_q % kFlowSlots;
+                        const double *o_r = fv.st + ((size_t)so * a.nw + rown) * 8, *o_p = fv.st + ((size_t)so * a.nw + pprow) * 8;
+                        // the proposal of move m_s: elements 13..17 of the record (each with its check
+                        // word), or the row it was proposed from
+                        const double *n_r = rec_r ? fv.rec + (((size_t)rown * kFlowSlots + (m_s % kFlowSlots)) * 2 + cr) * kFlowRec + 26
+                                                  : fv.st + ((size_t)sq * a.nw + ob + qr) * 8;
+                        const double *n_p = rec_p ? fv.rec + (((size_t)pprow * kFlowSlots + (m_s % kFlowSlots)) * 2 + cp) * kFlowRec + 26
+                                                  : fv.st + ((size_t)sq * a.nw + ob + qp) * 8;
+                        const double *sp = fv.st + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * 8;
+                        const unsigned long long tag_g = (a.flow_serial << 32) | (unsigned long long)(g + 1);
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int e = l16 + 16 * t;
-                        if (e < 25) {
-                            const int grp = e / 5, i = e - 5 * grp;
-                            const double *src = grp == 0 ? o_r : (grp == 1 ? n_r : (grp == 2 ? o_p : (grp == 3 ? n_p : sp)));
-                            const bool want = grp == 0 || grp == 4 || (grp == 1 && m_s > 0) || (grp == 2 && c1) || (grp == 3 && c1 && m_s > 0);
-                            scr[e] = want ? fl_ld(src + i) : 0.0;
+                        for (int t = 0; t < 2; ++t) {
+                            const int e = l16 + 16 * t;
+                            if (e < 25) {
+                                const int grp = e / 5, i = e - 5 * grp;
+                                const bool from_rec = (grp == 1 && rec_r) || (grp == 3 && rec_p);
+                                const double *src = grp == 0 ? o_r : (grp == 1 ? n_r : (grp == 2 ? o_p : (grp == 3 ? n_p : sp)));
+                                const bool want = grp == 0 || grp == 4 || (grp == 1 && m_s > 0) || (grp == 2 && c1) || (grp == 3 && c1 && m_s > 0);
+                                double v = 0.0;
+                                if (want && from_rec) {
+                                    v = ld_dev(src + 2 * i);
+                                    const unsigned long long chk = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src) + 2 * i + 1,
+                                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    bad = bad || (chk ^ (unsigned long long)__double_as_longlong(v)) != tag_g;
+                                } else if (want) {
+                                    v = fl_ld(src + i);
+                                }
+                                scr[e] = v;
+                            }
                         }
                     }
+                    // (a record element that is not there yet: again -- its mover used it a half-step
+                    // ago, so this does not happen; bounded all the same)
+                    if (__builtin_amdgcn_ballot_w64(bad) == 0) break;
+                    if (tries > MBB_FLOW_SPIN_LIMIT) { atomicMax(a.errflag, 9); break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                // the proposals those two rows were tested on, formed now, in place of the rows they
-                // were proposed from: after the decisions only a selection is left
+                // a proposal that did not come from a record is formed now, in place of the row it
+                // was proposed from: after the decisions only a selection is left
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (active && m_s > 0 && l16 < 10) {
                     const int i = l16 < 5 ? l16 : l16 - 5, o = l16 < 5 ? 0 : 10;
-                    if (l16 < 5 || c1) scr[o + 5 + i] = stretch_q(scr[o + 5 + i], scr[o + i], l16 < 5 ? zr : zq);
+                    if ((l16 < 5 && !rec_r) || (l16 >= 5 && c1 && !rec_p))
+                        scr[o + 5 + i] = stretch_q(scr[o + 5 + i], scr[o + i], l16 < 5 ? zr : zq);
                 }
                 // (2) the decisions of half-step j - 2 (lanes 0, 1): the hand-off this chain waits for
                 const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
