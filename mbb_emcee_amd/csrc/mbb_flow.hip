@@ -18,3 +18,13 @@ MBB_FLOW_INST(false, true)
 MBB_FLOW_INST(true, false)
 MBB_FLOW_INST(true, true)
 #undef MBB_FLOW_INST
+
+#include "mbb_flowm.hip.h"
+#define MBB_FLOWM_INST(OT, NA)                                         \
+    template __global__ void k_flowm<OT, NA, false>(const LikeArgs); \
+    template __global__ void k_flowm<OT, NA, true>(const LikeArgs);
+MBB_FLOWM_INST(false, false)
+MBB_FLOWM_INST(false, true)
+MBB_FLOWM_INST(true, false)
+MBB_FLOWM_INST(true, true)
+#undef MBB_FLOWM_INST

@@ -1,0 +1,528 @@
+// mbb_flowm.hip.h -- k_flowm, the one-launch sampler run with every stage of a half-step working
+// ahead (sampler form 7; single GPU, single ensemble).  Included by mbb_flow.hip only.
+//
+// k_lnlike's one-launch form (SMODE 5) prepares a walker's proposal ahead -- the draw, the SED
+// constructor and the penalties, for both outcomes of its partner's pending move -- but its mover
+// waits for that partner's decision BEFORE the passband quadrature: hand-over + quadrature + band
+// sums + accept test are one chain per half-step.  Here the quadrature runs ahead as well.  One
+// workgroup per (pair of walkers, candidate): workgroup 2 w + c takes, in half-step j, walker w
+// of the half that moves then, under the assumption c that its partner's pending move (half-step
+// j - 1) is rejected (c = 0) or accepted (c = 1).  Inside the workgroup three kinds of waves form a
+// pipeline, handing over through words in LDS (no workgroup barrier after the set-up):
+//   C  two waves, one per half of the ensemble (a proposal takes longer than a half-step).  A
+//      wave's four rows of 16 lanes run the constructor for the four outcomes of the two moves of
+//      half-step j - 2 the proposal depends on (the walker's own, and its partner's partner's for
+//      c = 1) -- the values either way are known once half-step j - 3 is decided -- and when those
+//      two decisions arrive only a selection is left: that row's constants go to LDS for Q, its
+//      proposal to the run's state (what other workgroups form their rows from).
+//   Q  the quadrature waves (the units of k_lnlike's phase 2, dealt the same way).
+//   E  one wave: band sums and lnL for this candidate (phase 3 of k_lnlike).  Then the partner's
+//      decision of half-step j - 1 says which of the two sibling workgroups holds the proposal the
+//      chain actually makes: that one does the accept test and publishes decision, row, chain entry.
+// A decision therefore depends on the one a half-step earlier only through a selection, on the one
+// two half-steps earlier through quadrature and band sums, and on the one three half-steps earlier
+// through the constructor: the chain per half-step is the largest of (hand-over + accept test),
+// (hand-over + quadrature + band sums) / 2 and (hand-over + constructor + quadrature + band sums) / 3
+// instead of their sum.  The price is twice the quadrature and up to four times the constructor
+// work, on CUs that were waiting.
+// Same draws, same arithmetic per candidate, same order of every sum: the chain is bitwise that of
+// the launch train (SMODE 1).
+//
+// State of a run (FlowMView, in the allocation forms 5/6 use for theirs), everything filed under the
+// number m of the move it belongs to, mod kFlowSlots (mbb_flow_index.h; the lag guard keeps a
+// slot from being overwritten under a reader):
+//   prop [nw][kFlowSlots][2][16]  the proposal of move m, per candidate: word 2i is coordinate i,
+//                                 word 2i + 1 its check word
+//   row  [kFlowSlots][nw][16]     the row after move m (T, beta, lambda0, alpha, fnorm, lnprob), same pairs;
+//                                 slot 0 also holds what the launch found (m = 0)
+//   mseq [nw][kFlowSlots]         2 x (half-step of move m + 1) + (it was accepted): the decision
+//   done [8][16]                  workgroups through with half-step j, running total per j mod 8
+// A check word is (serial of the launch << 32 | half-step of the move + 1) XOR the bits of the value:
+// a reader takes an element when the pair fits, whenever and in whatever order the two stores arrive,
+// so nobody waits for stores to land or raises a flag after them, and nothing left in memory by an
+// earlier run ever fits.
+#pragma once
+#include "mbb_kernels.hip.h"
+
+// LDS control words (ints) of a k_flowm workgroup
+constexpr int kFmReady = 0;    // [2] C wave b: half-step + 1 of the record last handed to Q (buffer b)
+constexpr int kFmQDone = 2;    // [2] Q waves that have finished a unit pass over buffer b, running total
+constexpr int kFmEDone = 4;    //     E wave: half-step + 1 of the last record it is through with
+constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: proposal 0..4, (dim-1) ln z,
+                               // ln u, the two penalties, the walker's row as it is (9..13)
+// dynamic LDS of a k_flowm launch besides the staged passband tables (bytes)
+__host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds)
+{
+    return 2 * sizeof(WalkerK) + 8 * (2 * npart + nb + 2 * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (2 * 4 * 32) + 64 + 32;
+}
+
+// an element and its check word
+__device__ __forceinline__ void fm_put(double *pair, double v, unsigned long long tag)
+{
+    st_dev(pair, v);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(pair) + 1, tag ^ (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool fm_get(const double *pair, unsigned long long tag, double &v)
+{
+    v = ld_dev(pair);
+    const unsigned long long chk = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(pair) + 1, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+    return (chk ^ (unsigned long long)__double_as_longlong(v)) == tag;
+}
+
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_pb[kPolyBDoubles];
+    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6, nq = nwave - 3;        // Q waves 0 .. nq-1, E wave nq, C waves nq+1, nq+2
+    const int nun = a.nunit, npart = a.npart, nb = a.nb;
+    const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1;
+    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);                    // [2]
+    double *partial = reinterpret_cast<double *>(wk + 2);                   // [2][npart]
+    double *mflux = partial + 2 * (size_t)npart;                            // [nb]
+    double *prop = mflux + nb;                                              // [2][kFmProp]
+    double *s_flux = prop + 2 * kFmProp;                                    // [nb]
+    double *s_ivar = s_flux + nb;                                           // [nb]
+    double *s_invcov = s_ivar + nb;                                         // [nb*nb] when in LDS
+    int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));   // [nb]
+    double *cscr = reinterpret_cast<double *>(s_band + nb + 1);             // [2][64] (room for [2][4][32])
+    int *ctl = reinterpret_cast<int *>(cscr + 2 * 4 * 32);                  // [16]
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15;
+    double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
+    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
+    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
+    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
+    const FlowMView fv = flowm_view(a.spec, a.nw);
+    const unsigned long long serial32 = a.flow_serial << 32;
+    const int niter = a.persist;
+
+    // ---- set-up, once per launch: tables -> LDS, control words clear --------------------------
+    {
+        const int nt = (int)blockDim.x;
+        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+        double2 *lb = reinterpret_cast<double2 *>(s_pb);
+        double2 *lc = reinterpret_cast<double2 *>(s_pc);
+        for (int i = tid; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+        for (int i = tid; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
+        if (!OPTHIN)
+            for (int i = tid; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
+        for (int b = tid; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
+        if (a.cov_in_lds)
+            for (int i = tid; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
+        if (STAGE) {
+            const int n2 = a.nchunk * 32;
+            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu), *g1 = reinterpret_cast<const double2 *>(a.lnnu),
+                          *g2 = reinterpret_cast<const double2 *>(a.wt);
+            double2 *l0 = reinterpret_cast<double2 *>(s_nu), *l1 = reinterpret_cast<double2 *>(s_lnnu),
+                    *l2 = reinterpret_cast<double2 *>(s_wt);
+            for (int i = tid; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        }
+        if (tid < 16) ctl[tid] = 0;
+    }
+    __syncthreads();
+    // diagnostic build: cycles a wave spends in each part of its loop, summed over the launch
+    // -> stamps[(workgroup * 16 + wave) * 8 + part] (tools/probe_stamps_flowm.py)
+#ifdef MBB_STAMPS
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#define FM_T(kk) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[kk] += t_now - t_last; t_last = t_now; } while (0)
+#define FM_TD(kk, dep) do { asm volatile("" ::"v"(dep)); FM_T(kk); } while (0)
+#define FM_TOUT() do { if (lane == 0 && a.stamps) for (int kk = 0; kk < 8; ++kk) a.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + kk] = t_acc[kk]; } while (0)
+#else
+#define FM_T(kk) do { } while (0)
+#define FM_TD(kk, dep) do { } while (0)
+#define FM_TOUT() do { } while (0)
+#endif
+
+    // hand-over words in LDS.  A wave's LDS operations execute in the order it issued them, so data
+    // then word (writer) and word then data (reader) need no wait in between, only the compiler's
+    // order; every wait is bounded and gives up once the run's error flag is up.
+#define MBB_FM_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    auto lds_wait = [&](int *word, int need) {
+        long long spins = 0;
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+            ++spins;
+            if (spins > spin_limit * 16 ||
+                ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                atomicMax(a.errflag, 9);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        MBB_FM_ORDER();
+    };
+    auto lds_post = [&](int *word, int v) {
+        MBB_FM_ORDER();
+        __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    // =========================== Q: the passband quadrature ====================================
+    if (wave < nq) {
+        auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
+        auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
+        auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
+        const SampleTabs tabs = {s_tab, s_pb, s_pc};
+        int4 us_first = make_int4(0, 0, 0, 0);
+        if (wave < nun) us_first = a.unit_tab[wave];
+        int tail_first = -1;
+        if (wave < nun && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
+        for (int it = 0; it < niter; ++it) {
+            const int b = it & 1;
+            lds_wait(ctl + kFmReady + b, it + 1);
+            FM_T(0);
+            const WalkerK *wkb = wk + b;
+            double *part = partial + (size_t)b * npart;
+            if (wkb->status == ROW_OK) {                          // wave-uniform
+                const WalkerK k = *wkb;
+                for (int u = wave; u < nun; u += nq) {
+                    const int4 us = (u == wave) ? us_first : a.unit_tab[u];
+                    const int s = us.x, c0 = us.y, c1 = us.z;
+                    double acc = 0.0;
+                    int c = c0;
+                    for (; c + 2 <= c1; c += 2) {                 // two chunks per step (k_lnlike, do_unit)
+                        const int i0 = c * 64 + lane, i1 = i0 + 64;
+                        const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+                        const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
+                        const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                        const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                        acc = fma(f0, q0, acc);
+                        acc = fma(f1, q1, acc);
+                    }
+                    if (c < c1) {
+                        const int i = c * 64 + lane;
+                        const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
+                        acc = fma(f, T_wt(i), acc);
+                    }
+                    if (us.w == 0) {
+                        acc = wave_sum(acc);
+                        if (lane == 0) part[s] = acc;
+                    } else if (us.w == 2) {
+                        acc = row_sum(acc);
+                        if ((lane & 15) == 0) {
+                            const int sl = (u == wave) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
+                            if (sl >= 0) part[sl] = acc;
+                        }
+                    } else {
+                        part[s + lane] = acc;
+                    }
+                }
+            }
+            MBB_FM_ORDER();
+            if (lane == 0) __hip_atomic_fetch_add(ctl + kFmQDone + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            FM_T(1);
+        }
+        FM_TOUT();
+        return;
+    }
+
+    // =========================== E: band sums, lnL, and the move if it is this candidate's =====
+    if (wave == nq) {
+        for (int it = 0; it < niter; ++it) {
+            const int b = it & 1;
+            const int L_step = a.step + (it >> 1), L_half = it & 1;
+            const unsigned long long L_seed = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1);
+            const int row = (L_half ? a.c_count : 0) + w, c_begin = L_half ? 0 : a.c_count;
+            double zz, u3;
+            int pj;
+            stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
+            const int prow = c_begin + pj;
+            const int m_par = flow_cnt(L_half ^ 1, it), m_s = flow_cnt(L_half, it);
+            const unsigned long long need_p = (unsigned long long)flow_seq(L_half ^ 1, m_par);
+            // one loop, one round trip when everything is there: lane 21 the walker's lnprob as it is
+            // (element 5 of its row after move m_s), lane 22 the partner's decision of half-step it - 1,
+            // lane 23 the lag guard
+            const double *lnp_p = fv.row + ((size_t)(m_s % kFlowSlots) * a.nw + row) * kFmWords + 10;
+            const unsigned long long tag_s = serial32 | (unsigned long long)flow_seq(L_half, m_s);
+            const unsigned long long need_g = 2ull * (unsigned long long)a.n * (unsigned long long)(((it - kFlowLag) >> 3) + 1);
+            const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
+                                                        : fv.done + ((it - kFlowLag) & 7) * 16;
+            const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag);
+            unsigned long long pv = 0;
+            double lnp = 0.0;
+            bool ok = !(watch || lane == 21);
+            long long spins = 0;
+            for (;;) {
+                if (lane == 21 && !ok) ok = fm_get(lnp_p, tag_s, lnp);
+                if (watch && !ok) {
+                    pv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g);
+                }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                ++spins;
+                if (spins > spin_limit ||
+                    ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    atomicMax(a.errflag, 9);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const int flag = (need_p > 0 && (__shfl(pv, 22) & 1ull)) ? 1 : 0;
+            const bool mine = flag == cand;                       // this workgroup's candidate is the chain's proposal
+            const double lnp_cur = __shfl(lnp, 21);
+            FM_TD(0, lnp_cur);
+
+            lds_wait(ctl + kFmQDone + b, nq * ((it >> 1) + 1));
+            FM_T(1);
+            const WalkerK *wkb = wk + b;
+            const double *pr = prop + b * kFmProp;
+            const int st = wkb->status;
+            const double cbb = wkb->cbb, pen_u = pr[7], pen_g = pr[8];
+            double q[5], old5[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { q[i] = pr[i]; old5[i] = pr[9 + i]; }
+            const double lnz4 = pr[5], lnu = pr[6];
+            double acc = 0.0;
+            if (st == ROW_OK) {
+                const double *pj2 = partial + (size_t)b * npart;
+                auto band = [&](const int bb) {                    // band flux, fixed order (k_lnlike, phase 3)
+                    // (no contraction: there the product and the difference are separate roundings --
+                    // the model flux is also an output of that kernel -- and the chain must be the same bits)
+#pragma clang fp contract(off)
+                    double sum = 0.0;
+                    const int2 rng = s_band[bb];
+                    for (int sg = rng.x; sg < rng.y; sg += 4) {
+                        const int l = rng.y - 1;
+                        const double q0 = pj2[sg], q1 = pj2[min(sg + 1, l)], q2 = pj2[min(sg + 2, l)], q3 = pj2[min(sg + 3, l)];
+                        sum += q0;
+                        if (sg + 1 < rng.y) sum += q1;
+                        if (sg + 2 < rng.y) sum += q2;
+                        if (sg + 3 < rng.y) sum += q3;
+                    }
+                    sum *= cbb;
+                    const double d = s_flux[bb] - sum;             // likelihood.py:821
+                    if (a.invcov) mflux[bb] = d;
+                    else acc = fma(d * d, s_ivar[bb], acc);        // :825
+                };
+                for (int bb = lane; bb < nb; bb += 64) band(bb);
+                if (a.invcov) {                                    // :823
+                    MBB_FM_ORDER();
+                    for (int i = lane; i < nb; i += 64) {
+                        double t = 0.0;
+                        const double *crow = (a.cov_in_lds ? s_invcov : a.invcov) + (size_t)i * nb;
+                        for (int jj = 0; jj < nb; ++jj) t = fma(crow[jj], mflux[jj], t);
+                        acc = fma(mflux[i], t, acc);
+                    }
+                }
+                acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
+            }
+            FM_TD(2, acc);
+            if (lane == 0) lds_post(ctl + kFmEDone, it + 1);       // buffer b may be written again
+            {
+                // (every lane: the band total is in all of them)
+                double r;
+                if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
+                else if (st != ROW_OK) r = __builtin_nan("");
+                else {
+                    r = fma(-0.5, acc, pen_u);                     // :828 (one rounding there too)
+                    if (a.has_gprior) r += pen_g;                  // :830-831
+                }
+                if (mine) {
+                    if (lane == 0 && (st >= 2 || r != r)) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
+                    const bool accept = (lnz4 + r - lnp_cur) > lnu;
+                    const int m_new = m_s + 1;
+                    // the decision first, then the row as it is after this half-step, an element and its
+                    // check word per lane; counts and chain are for the host: plain stores
+                    if (lane == 0)
+                        __hip_atomic_store(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
+                                           2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    const double lnp_new = accept ? r : lnp_cur;
+                    double ve = lnp_new;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) ve = ((lane & 7) == i) ? (accept ? q[i] : old5[i]) : ve;
+                    if (lane < 6)
+                        fm_put(fv.row + ((size_t)(m_new % kFlowSlots) * a.nw + row) * kFmWords + 2 * lane, ve,
+                               serial32 | (unsigned long long)(it + 1));
+                    else if (lane >= 8 && lane < 14 && a.chain6)
+                        a.chain6[((size_t)it * a.n + w) * 6 + (lane - 8)] = ve;
+                    if (lane == 0 && accept) atomicAdd(a.nacc + (size_t)L_half * a.n + w, 1u);
+                }
+                if (lane == 0) __hip_atomic_fetch_add(fv.done + (it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            FM_T(3);
+        }
+        FM_TOUT();
+        return;
+    }
+
+    // =========================== C: the proposals, worked out ahead of their decisions =========
+    {
+        const int cb = wave - nq - 1;                             // this wave's half of the ensemble
+        const int vrow = lane >> 4, l16 = lane & 15, base = lane & 48;
+        double *scr = cscr + (size_t)cb * 64;
+        auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
+            unsigned long long v = 0;
+            long long spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                ++spins;
+                if (spins > spin_limit ||
+                    ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    atomicMax(a.errflag, 9);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            return v;
+        };
+        for (int j = cb; j < niter; j += 2) {
+            const int hj = j & 1;
+            const int sb = hj ? a.c_count : 0, ob = hj ? 0 : a.c_count;    // the half that moves in j / the other
+            const int tn = a.step + (j >> 1);
+            const unsigned long long seed_n = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j >> 1);
+            const int tp = a.step + ((j - 1) >> 1), hp = hj ^ 1;
+            const unsigned long long seed_p = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((j - 1) >> 1);
+            const bool c1 = cand && j > 0;
+            const int rown = sb + w;
+            double zz = 1.0, u3 = 0.5, zp = 1.0, up;
+            int pj = 0, pjp = 0;
+            stretch_draw(rown, tn, hj, seed_n, a.stretch_a, a.c_count, zz, pj, u3);
+            if (c1) stretch_draw(ob + pj, tp, hp, seed_p, a.stretch_a, a.c_count, zp, pjp, up);
+            // The rows this proposal starts from -- the walker's own and, for candidate 1, its
+            // partner's partner -- made their last move (number m_s) in half-step j - 2.  Either is put
+            // together from what was known before that move was decided: the row as it was, and the
+            // proposal it was tested on, whose candidate is the one the decision of ITS partner in
+            // half-step j - 3 says (k_lnlike, SMODE 5, the workgroups that work ahead).
+            const int m_s = flow_cnt(hj, j - 1), m_o = flow_cnt(hj ^ 1, j - 1);
+            const int m_next = m_s + 1;
+            const int g = j - 2;
+            const int m_q = flow_cnt(hj ^ 1, g);
+            const int pprow = sb + pjp, prow = ob + pj;
+            int qr = 0, qp = 0;
+            if (m_s > 0) {
+                const int tg = a.step + (g >> 1);
+                const unsigned long long seed_g = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(g >> 1);
+                double u0, z0;
+                stretch_draw(rown, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qr, u0);
+                if (c1) stretch_draw(pprow, tg, hj, seed_g, a.stretch_a, a.c_count, z0, qp, u0);
+            }
+            int snv_off = 0, cpv_off = 15;
+            // (1) everything that is settled once half-step j - 3 is decided, one item per lane, all asked
+            // for in the same round (one round trip when it is all there) -> LDS:
+            //   lane 0, 1    the two decisions of j - 3 that say which candidate the rows' last proposals were
+            //   lane 2..6    the walker's row before its last move              -> scr[0..5)
+            //   lane 7..11   its partner's partner's                            -> scr[15..20)
+            //   lane 12..16  its partner's row as it is (before the pending move) -> scr[30..35)
+            //   lane 17..26  the proposals of the walker's last move, both candidates -> scr[5..15)
+            //   lane 27..36  the same for the partner's partner                 -> scr[20..30)
+            {
+                const bool has = m_s > 0;
+                const int so = (has ? m_s - 1 : 0) % kFlowSlots;
+                const unsigned long long tag_old = serial32 | (unsigned long long)flow_seq(hj, has ? m_s - 1 : 0);
+                const unsigned long long tag_g = serial32 | (unsigned long long)(g + 1);
+                const unsigned long long tag_o = serial32 | (unsigned long long)flow_seq(hj ^ 1, m_o);
+                const double *src = fv.row;
+                unsigned long long tag = 0, need = 0;
+                const unsigned long long *wsrc = fv.mseq;
+                int slot = -1, kind = 0;                              // kind 1: a decision word, 2: an element
+                if (lane < 2) {
+                    const int r = lane == 0 ? qr : qp;
+                    wsrc = fv.mseq + (size_t)(ob + r) * kFlowSlots + (m_q % kFlowSlots);
+                    need = (unsigned long long)flow_seq(hj ^ 1, m_q);
+                    kind = (has && m_q > 0 && (lane == 0 || c1)) ? 1 : 0;
+                } else if (lane < 7) {
+                    src = fv.row + ((size_t)so * a.nw + rown) * kFmWords + 2 * (lane - 2); tag = tag_old; slot = lane - 2; kind = 2;
+                } else if (lane < 12) {
+                    src = fv.row + ((size_t)so * a.nw + pprow) * kFmWords + 2 * (lane - 7); tag = tag_old; slot = 15 + lane - 7; kind = c1 ? 2 : 0;
+                } else if (lane < 17) {
+                    src = fv.row + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * kFmWords + 2 * (lane - 12); tag = tag_o; slot = 30 + lane - 12; kind = 2;
+                } else if (lane < 27) {
+                    const int c = (lane - 17) / 5, i = (lane - 17) - 5 * c;
+                    src = fv.prop + (((size_t)rown * kFlowSlots + (m_s % kFlowSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 5 + lane - 17;
+                    kind = has ? 2 : 0;
+                } else if (lane < 37) {
+                    const int c = (lane - 27) / 5, i = (lane - 27) - 5 * c;
+                    src = fv.prop + (((size_t)pprow * kFlowSlots + (m_s % kFlowSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 20 + lane - 27;
+                    kind = (has && c1) ? 2 : 0;
+                }
+                bool ok = kind == 0;
+                double v = 0.0;
+                unsigned long long dv = 0;
+                long long spins = 0;
+                for (;;) {
+                    if (kind == 2 && !ok) ok = fm_get(src, tag, v);
+                    if (kind == 1 && !ok) { dv = __hip_atomic_load(wsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (dv >> 1) >= need; }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                    ++spins;
+                    if (spins > spin_limit ||
+                        ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        atomicMax(a.errflag, 9);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (slot >= 0) scr[slot] = v;
+                FM_TD(0, v);
+                MBB_FM_ORDER();
+                // (a decision word that was not waited for reads as candidate 0)
+                const int cr = (int)(__shfl(dv, 0) & 1ull), cp = (int)(__shfl(dv, 1) & 1ull);
+                // this row of lanes' assumption about the two moves of half-step j - 2
+                const bool ar_v = has && (vrow & 1), ap_v = has && c1 && (vrow & 2);
+                snv_off = ar_v ? 5 + 5 * cr : 0;
+                cpv_off = ap_v ? 20 + 5 * cp : 15;
+            }
+            double snv[5], cpos[5], cpv[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { snv[i] = scr[snv_off + i]; cpv[i] = scr[cpv_off + i]; cpos[i] = scr[30 + i]; }
+            FM_T(1);
+            if (c1) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) cpos[i] = stretch_q(cpv[i], cpos[i], zp);
+            }
+            double p[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) p[i] = stretch_q(cpos[i], snv[i], zz);
+            double lo[4];
+            vlog<true>(lo, p[0], p[2], zz, u3);
+            WalkerK k;
+            k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+            k.status = ROW_SKIP;
+            k.pad = 0;
+            double pen_u = 0.0, pen_g = 0.0;
+            const double lT = lo[0], lL = lo[1];
+#include "mbb_walker_consts.inc"
+            FM_TD(2, pen_u + pen_g + k.cbb);
+            // (2) the two decisions of half-step j - 2: which row of lanes was right
+            const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
+            const unsigned long long v2 = spin(w2, (unsigned long long)flow_seq(hj, m_s), m_s > 0 && (l16 == 0 || (l16 == 1 && c1)), 1);
+            const bool ar = m_s > 0 && (__shfl(v2, base + 0) & 1ull), ap = m_s > 0 && c1 && (__shfl(v2, base + 1) & 1ull);
+            const int vsel = (ar ? 1 : 0) | (ap ? 2 : 0);
+            FM_TD(3, v2);
+            // the record buffer must be free: E is through with half-step j - 2
+            if (j >= 2) lds_wait(ctl + kFmEDone, j - 1);
+            FM_T(4);
+            if (vrow == vsel && l16 == 0) {
+                wk[hj] = k;
+                double *pr = prop + hj * kFmProp;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { pr[i] = p[i]; pr[9 + i] = snv[i]; }
+                pr[5] = 4.0 * lo[2];                              // (dim - 1) ln z, dim = 5
+                pr[6] = lo[3];                                    // ln u
+                pr[7] = pen_u;
+                pr[8] = pen_g;
+                lds_post(ctl + kFmReady + hj, j + 1);
+                // the proposal, for the workgroups that form rows from it: element by element, each
+                // with its check word
+                double *rec = fv.prop + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFmWords;
+                const unsigned long long tag = serial32 | (unsigned long long)(j + 1);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) fm_put(rec + 2 * i, p[i], tag);
+            }
+            FM_T(5);
+        }
+        FM_TOUT();
+    }
+#undef FM_T
+#undef FM_TD
+#undef FM_TOUT
+#undef MBB_FM_ORDER
+}

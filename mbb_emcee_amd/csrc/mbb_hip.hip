@@ -38,6 +38,23 @@ MBB_FLOW_EXT(false, true)
 MBB_FLOW_EXT(true, false)
 MBB_FLOW_EXT(true, true)
 #undef MBB_FLOW_EXT
+// ... and so is k_flowm, sampler form 7 (mbb_flowm.hip.h; only its LDS plan is needed here)
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void k_flowm(const LikeArgs a);
+#define MBB_FLOWM_EXT(OT, NA)                                         \
+    extern template __global__ void k_flowm<OT, NA, false>(const LikeArgs); \
+    extern template __global__ void k_flowm<OT, NA, true>(const LikeArgs);
+MBB_FLOWM_EXT(false, false)
+MBB_FLOWM_EXT(false, true)
+MBB_FLOWM_EXT(true, false)
+MBB_FLOWM_EXT(true, true)
+#undef MBB_FLOWM_EXT
+constexpr int kFmPropHost = 16;
+static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)   // = flowm_lds() of mbb_flowm.hip.h
+{
+    return 2 * sizeof(WalkerK) + 8 * (2 * npart + nb + 2 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (2 * 4 * 32) + 64 + 32;
+}
 #include "mbb_host_tables.h"
 
 static_assert(kPolyBDoubles == mbbh::kPolyBCount * (mbbh::kPolyDeg + 1), "poly table size");
@@ -157,9 +174,10 @@ struct mbb_ctx {
     long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
     long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
+    long opt_flowm = 0;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[56] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[64] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -517,6 +535,8 @@ struct SamplerLaunch {
     int spec_cfg;                 // LikeArgs::spec_cfg
     bool spec_first;              // the run's first launch: nobody moves
     bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
+    bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
+    unsigned long long serial = 0;   // ... the number of its launch (set up with it: k_flowm_init)
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -578,6 +598,48 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     c->last_stage = stage ? 1 : 0;
     void (*kern)(const LikeArgs);
     int vi_of_kernel = 0;
+    if (sl && sl->merged) {
+        // sampler form 7: 2 n workgroups of (quadrature waves + 3), every one resident; its own LDS plan
+        a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
+        a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
+        a.m_count = sl->m_count;
+        a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
+        a.nw_src = sl->nw_src;
+        a.persist = sl->persist;
+        a.flow_serial = c->flow_serial = sl->serial;
+        a.spec = sl->spec;
+        a.spec_cfg = (int)((c->opt_flow_spin_log2 & 0x3f) << 24);
+        a.n_ahead = 0;
+        const int nq = std::min(threads / 64, 13);
+        const int thr = (nq + 3) * 64;
+        a.cov_in_lds = (c->has_cov && flowm_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
+        const size_t sm = flowm_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
+        const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
+        const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
+        if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
+        if (2 * n > c->cu_count)
+            return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
+        static void (*const mtable[8])(const LikeArgs) = {
+            k_flowm<false, false, false>, k_flowm<false, false, true>, k_flowm<false, true, false>,
+            k_flowm<false, true, true>,   k_flowm<true, false, false>, k_flowm<true, false, true>,
+            k_flowm<true, true, false>,   k_flowm<true, true, true>};
+        const int mi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+        kern = mtable[mi];
+        c->last_wpb = 1; c->last_threads = thr; c->last_grid = 2 * n; c->last_smem = (long)sm_total;
+        c->last_stage = stg ? 1 : 0; c->last_smode = 7; c->last_ahead = 0;
+        if (static_lds(c) + sm_total > 60 * 1024) {
+            size_t &g = c->lds_granted[56 + mi];
+            if (sm_total > g) {
+                size_t want = (sm_total + 16383) & ~(size_t)16383;
+                if (want > dyn_limit) want = dyn_limit;
+                HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+                g = want;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3(2 * n), dim3(thr), sm_total, c->stream, a);
+        HIPCHK(hipGetLastError());
+        return MBB_OK;
+    }
     if (sl) {
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
@@ -992,7 +1054,9 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
         }
         int la_rows, la_aw, la_ahead;
         lookahead_plan(c, (int)nl, thr_1, half, true, la_rows, la_aw, la_ahead);
-        if (c->opt_flow && la_ahead + (int)nl <= c->cu_count) {
+        // form 7 where every (pair, candidate) gets a CU of its own; else form 5
+        const bool merged = c->opt_flowm && 2 * (int)nl <= c->cu_count;
+        if (c->opt_flow && (merged || la_ahead + (int)nl <= c->cu_count)) {
             // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
@@ -1005,8 +1069,14 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             s->flow_used = true;
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
-                hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
-                                   s->d_pos6, s->d_spec, (int)R);
+                if (merged) {
+                    sl.serial = ++g_flow_serial;
+                    hipLaunchKernelGGL(k_flowm_init, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream,
+                                       s->d_pos6, s->d_spec, (int)R, sl.serial);
+                } else {
+                    hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
+                                       s->d_pos6, s->d_spec, (int)R);
+                }
                 HIPCHK(hipGetLastError());
                 sl.s_begin = 0; sl.c_begin = half; sl.step = t0; sl.half = 0;
                 sl.persist = 2 * nt;
@@ -1014,10 +1084,11 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.nacc = s->d_nacc;
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
                 sl.spec_cfg = 0; sl.spec_first = false;
+                sl.merged = merged;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 // the sampler's rows from the slots the launch's last moves went to
-                hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream,
-                                   s->d_pos6, s->d_spec, (int)R, 2 * nt);
+                hipLaunchKernelGGL(merged ? k_flowm_finish : k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0,
+                                   c->stream, s->d_pos6, s->d_spec, (int)R, 2 * nt);
                 HIPCHK(hipGetLastError());
             }
             s->steps_done += (unsigned long long)nsteps;
@@ -1487,6 +1558,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "persistent_sampler")) c->opt_persist = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
+    else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;
     else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
