@@ -80,7 +80,15 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwave = blockDim.x >> 6, nq = nwave - 3;        // Q waves 0 .. nq-1, E wave nq, C waves nq+1, nq+2
+    const int nwave = blockDim.x >> 6, nq = nwave - 3;
+    // Which wave does what.  The constructor is one long dependent chain and runs fastest on a SIMD it
+    // does not share with the quadrature's bursts: waves 3, 7 and 11 (one SIMD: a workgroup's waves go
+    // round the four in turn) are C0, C1 and E, every other wave is a Q wave, numbered in order.
+    // (Fewer than 12 waves: the last three.)
+    const bool spread = nwave >= 12;
+    const int role = spread ? ((wave == 3) ? 1 : (wave == 7) ? 2 : (wave == 11) ? 3 : 0)
+                            : (wave < nq ? 0 : (wave == nq ? 3 : wave - nq));      // 0 Q, 1 C0, 2 C1, 3 E
+    const int qi = spread ? wave - (wave > 3) - (wave > 7) - (wave > 11) : wave;   // Q wave number
     const int nun = a.nunit, npart = a.npart, nb = a.nb;
     const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1;
     WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);                    // [2]
@@ -135,7 +143,21 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #define FM_T(kk) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[kk] += t_now - t_last; t_last = t_now; } while (0)
 #define FM_TD(kk, dep) do { asm volatile("" ::"v"(dep)); FM_T(kk); } while (0)
 #define FM_TOUT() do { if (lane == 0 && a.stamps) for (int kk = 0; kk < 8; ++kk) a.stamps[((size_t)blockIdx.x * 16 + wave) * 8 + kk] = t_acc[kk]; } while (0)
+    if (lane == 0 && a.stamps) {                                  // where the wave runs: HW_ID (SIMD in bits 4-5, CU 8-11, SE 13-15)
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.stamps[(1u << 20) + blockIdx.x * 16 + wave] = ((unsigned long long)xcc << 32) | hwid;
+    }
+// ... and when things happened in the launch's last 64 half-steps, on the clock all CUs share (100 MHz):
+// log[(workgroup * 64 + half-step mod 64) * 8 + event], tools/probe_chain_flowm.py
+#define FM_EV(jj, ev) do { if (lane == 0 && a.stamps && (jj) >= niter - 64) \
+        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 8 + (ev))] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FM_EVV(jj, ev, val) do { if (lane == 0 && a.stamps && (jj) >= niter - 64) \
+        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 8 + (ev))] = (unsigned long long)(val); } while (0)
 #else
+#define FM_EV(jj, ev) do { } while (0)
+#define FM_EVV(jj, ev, val) do { } while (0)
 #define FM_T(kk) do { } while (0)
 #define FM_TD(kk, dep) do { } while (0)
 #define FM_TOUT() do { } while (0)
@@ -164,15 +186,15 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     };
 
     // =========================== Q: the passband quadrature ====================================
-    if (wave < nq) {
+    if (role == 0) {
         auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
         auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
         auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
         const SampleTabs tabs = {s_tab, s_pb, s_pc};
         int4 us_first = make_int4(0, 0, 0, 0);
-        if (wave < nun) us_first = a.unit_tab[wave];
+        if (qi < nun) us_first = a.unit_tab[qi];
         int tail_first = -1;
-        if (wave < nun && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
+        if (qi < nun && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
         for (int it = 0; it < niter; ++it) {
             const int b = it & 1;
             lds_wait(ctl + kFmReady + b, it + 1);
@@ -181,8 +203,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             double *part = partial + (size_t)b * npart;
             if (wkb->status == ROW_OK) {                          // wave-uniform
                 const WalkerK k = *wkb;
-                for (int u = wave; u < nun; u += nq) {
-                    const int4 us = (u == wave) ? us_first : a.unit_tab[u];
+                for (int u = qi; u < nun; u += nq) {
+                    const int4 us = (u == qi) ? us_first : a.unit_tab[u];
                     const int s = us.x, c0 = us.y, c1 = us.z;
                     double acc = 0.0;
                     int c = c0;
@@ -206,7 +228,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     } else if (us.w == 2) {
                         acc = row_sum(acc);
                         if ((lane & 15) == 0) {
-                            const int sl = (u == wave) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
+                            const int sl = (u == qi) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
                             if (sl >= 0) part[sl] = acc;
                         }
                     } else {
@@ -223,7 +245,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     }
 
     // =========================== E: band sums, lnL, and the move if it is this candidate's =====
-    if (wave == nq) {
+    if (role == 3) {
         for (int it = 0; it < niter; ++it) {
             const int b = it & 1;
             const int L_step = a.step + (it >> 1), L_half = it & 1;
@@ -244,16 +266,81 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
                                                         : fv.done + ((it - kFlowLag) & 7) * 16;
             const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag);
+            // The band sums do not wait for the partner: as soon as Q is through they are formed, between
+            // asking for the words and looking at the answers; whichever comes last -- the partner's
+            // decision or the sums -- is followed by the accept test alone.
+            const WalkerK *wkb = wk + b;
+            const double *pr = prop + b * kFmProp;
+            int st = ROW_SKIP;
+            double cbb = 0.0, pen_u = 0.0, pen_g = 0.0, lnz4 = 0.0, lnu = 0.0, acc = 0.0;
+            double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            auto sums = [&]() {
+                st = wkb->status;
+                cbb = wkb->cbb; pen_u = pr[7]; pen_g = pr[8];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) { q[i] = pr[i]; old5[i] = pr[9 + i]; }
+                lnz4 = pr[5]; lnu = pr[6];
+                if (st == ROW_OK) {
+                    const double *pj2 = partial + (size_t)b * npart;
+                    auto band = [&](const int bb) {                    // band flux, fixed order (k_lnlike, phase 3)
+                        // (no contraction: there the product and the difference are separate roundings --
+                        // the model flux is also an output of that kernel -- and the chain must be the same bits)
+#pragma clang fp contract(off)
+                        double sum = 0.0;
+                        const int2 rng = s_band[bb];
+                        for (int sg = rng.x; sg < rng.y; sg += 4) {
+                            const int l = rng.y - 1;
+                            const double q0 = pj2[sg], q1 = pj2[min(sg + 1, l)], q2 = pj2[min(sg + 2, l)], q3 = pj2[min(sg + 3, l)];
+                            sum += q0;
+                            if (sg + 1 < rng.y) sum += q1;
+                            if (sg + 2 < rng.y) sum += q2;
+                            if (sg + 3 < rng.y) sum += q3;
+                        }
+                        sum *= cbb;
+                        const double d = s_flux[bb] - sum;             // likelihood.py:821
+                        if (a.invcov) mflux[bb] = d;
+                        else acc = fma(d * d, s_ivar[bb], acc);        // :825
+                    };
+                    for (int bb = lane; bb < nb; bb += 64) band(bb);
+                    if (a.invcov) {                                    // :823
+                        MBB_FM_ORDER();
+                        for (int i = lane; i < nb; i += 64) {
+                            double t = 0.0;
+                            const double *crow = (a.cov_in_lds ? s_invcov : a.invcov) + (size_t)i * nb;
+                            for (int jj = 0; jj < nb; ++jj) t = fma(crow[jj], mflux[jj], t);
+                            acc = fma(mflux[i], t, acc);
+                        }
+                    }
+                    acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
+                }
+                MBB_FM_ORDER();
+                if (lane == 0) lds_post(ctl + kFmEDone, it + 1);       // buffer b may be written again
+            };
+            const int q_need = nq * ((it >> 1) + 1);
             unsigned long long pv = 0;
             double lnp = 0.0;
-            bool ok = !(watch || lane == 21);
+            bool ok = !(watch || lane == 21), have_sums = false;
             long long spins = 0;
             for (;;) {
-                if (lane == 21 && !ok) ok = fm_get(lnp_p, tag_s, lnp);
-                if (watch && !ok) {
-                    pv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g);
+                // (asked for ...)
+                double lv = 0.0;
+                unsigned long long lchk = 0, wv = 0;
+                const bool ask_l = lane == 21 && !ok, ask_w = watch && !ok;
+                if (ask_l) {
+                    lv = ld_dev(lnp_p);
+                    lchk = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(lnp_p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (ask_w) wv = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (... the sums meanwhile, if Q is through ...)
+                if (!have_sums && __hip_atomic_load(ctl + kFmQDone + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= q_need) {
+                    MBB_FM_ORDER();
+                    FM_EV(it, 4);
+                    sums();
+                    have_sums = true;
+                }
+                // (... and looked at)
+                if (ask_l) { lnp = lv; ok = (lchk ^ (unsigned long long)__double_as_longlong(lv)) == tag_s; }
+                if (ask_w) { pv = wv; ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g); }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 ++spins;
                 if (spins > spin_limit ||
@@ -267,53 +354,15 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             const bool mine = flag == cand;                       // this workgroup's candidate is the chain's proposal
             const double lnp_cur = __shfl(lnp, 21);
             FM_TD(0, lnp_cur);
-
-            lds_wait(ctl + kFmQDone + b, nq * ((it >> 1) + 1));
-            FM_T(1);
-            const WalkerK *wkb = wk + b;
-            const double *pr = prop + b * kFmProp;
-            const int st = wkb->status;
-            const double cbb = wkb->cbb, pen_u = pr[7], pen_g = pr[8];
-            double q[5], old5[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { q[i] = pr[i]; old5[i] = pr[9 + i]; }
-            const double lnz4 = pr[5], lnu = pr[6];
-            double acc = 0.0;
-            if (st == ROW_OK) {
-                const double *pj2 = partial + (size_t)b * npart;
-                auto band = [&](const int bb) {                    // band flux, fixed order (k_lnlike, phase 3)
-                    // (no contraction: there the product and the difference are separate roundings --
-                    // the model flux is also an output of that kernel -- and the chain must be the same bits)
-#pragma clang fp contract(off)
-                    double sum = 0.0;
-                    const int2 rng = s_band[bb];
-                    for (int sg = rng.x; sg < rng.y; sg += 4) {
-                        const int l = rng.y - 1;
-                        const double q0 = pj2[sg], q1 = pj2[min(sg + 1, l)], q2 = pj2[min(sg + 2, l)], q3 = pj2[min(sg + 3, l)];
-                        sum += q0;
-                        if (sg + 1 < rng.y) sum += q1;
-                        if (sg + 2 < rng.y) sum += q2;
-                        if (sg + 3 < rng.y) sum += q3;
-                    }
-                    sum *= cbb;
-                    const double d = s_flux[bb] - sum;             // likelihood.py:821
-                    if (a.invcov) mflux[bb] = d;
-                    else acc = fma(d * d, s_ivar[bb], acc);        // :825
-                };
-                for (int bb = lane; bb < nb; bb += 64) band(bb);
-                if (a.invcov) {                                    // :823
-                    MBB_FM_ORDER();
-                    for (int i = lane; i < nb; i += 64) {
-                        double t = 0.0;
-                        const double *crow = (a.cov_in_lds ? s_invcov : a.invcov) + (size_t)i * nb;
-                        for (int jj = 0; jj < nb; ++jj) t = fma(crow[jj], mflux[jj], t);
-                        acc = fma(mflux[i], t, acc);
-                    }
-                }
-                acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
+            FM_EV(it, 5);
+            FM_EVV(it, 7, prow);
+            if (!have_sums) {
+                lds_wait(ctl + kFmQDone + b, q_need);
+                FM_T(1);
+                FM_EV(it, 4);
+                sums();
             }
             FM_TD(2, acc);
-            if (lane == 0) lds_post(ctl + kFmEDone, it + 1);       // buffer b may be written again
             {
                 // (every lane: the band total is in all of them)
                 double r;
@@ -329,6 +378,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     const int m_new = m_s + 1;
                     // the decision first, then the row as it is after this half-step, an element and its
                     // check word per lane; counts and chain are for the host: plain stores
+                    FM_EV(it, 6);
                     if (lane == 0)
                         __hip_atomic_store(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
                                            2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
@@ -354,7 +404,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 
     // =========================== C: the proposals, worked out ahead of their decisions =========
     {
-        const int cb = wave - nq - 1;                             // this wave's half of the ensemble
+        const int cb = role - 1;                                  // this wave's half of the ensemble
         const int vrow = lane >> 4, l16 = lane & 15, base = lane & 48;
         double *scr = cscr + (size_t)cb * 64;
         auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
@@ -462,6 +512,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 }
                 if (slot >= 0) scr[slot] = v;
                 FM_TD(0, v);
+                FM_EV(j, 0);
                 MBB_FM_ORDER();
                 // (a decision word that was not waited for reads as candidate 0)
                 const int cr = (int)(__shfl(dv, 0) & 1ull), cp = (int)(__shfl(dv, 1) & 1ull);
@@ -490,13 +541,23 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             double pen_u = 0.0, pen_g = 0.0;
             const double lT = lo[0], lL = lo[1];
 #include "mbb_walker_consts.inc"
+#ifdef MBB_STAMPS
+            {
+                asm volatile("" ::"v"(pen_u + pen_g + k.cbb));
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_last;
+                if (dt > t_acc[6]) t_acc[6] = dt;
+                if (t_acc[7] == 0 || dt < t_acc[7]) t_acc[7] = dt;
+            }
+#endif
             FM_TD(2, pen_u + pen_g + k.cbb);
+            FM_EV(j, 1);
             // (2) the two decisions of half-step j - 2: which row of lanes was right
             const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
             const unsigned long long v2 = spin(w2, (unsigned long long)flow_seq(hj, m_s), m_s > 0 && (l16 == 0 || (l16 == 1 && c1)), 1);
             const bool ar = m_s > 0 && (__shfl(v2, base + 0) & 1ull), ap = m_s > 0 && c1 && (__shfl(v2, base + 1) & 1ull);
             const int vsel = (ar ? 1 : 0) | (ap ? 2 : 0);
             FM_TD(3, v2);
+            FM_EV(j, 2);
             // the record buffer must be free: E is through with half-step j - 2
             if (j >= 2) lds_wait(ctl + kFmEDone, j - 1);
             FM_T(4);
@@ -510,6 +571,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 pr[7] = pen_u;
                 pr[8] = pen_g;
                 lds_post(ctl + kFmReady + hj, j + 1);
+#ifdef MBB_STAMPS
+                if (a.stamps && j >= niter - 64)
+                    a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + (j & 63)) * 8 + 3)] = __builtin_amdgcn_s_memrealtime();
+#endif
                 // the proposal, for the workgroups that form rows from it: element by element, each
                 // with its check word
                 double *rec = fv.prop + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFmWords;
@@ -521,6 +586,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         }
         FM_TOUT();
     }
+#undef FM_EV
+#undef FM_EVV
 #undef FM_T
 #undef FM_TD
 #undef FM_TOUT

@@ -174,7 +174,7 @@ struct mbb_ctx {
     long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
     long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
-    long opt_flowm = 0;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
+    long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
     size_t lds_granted[64] = {};   // dynamic-LDS ceiling already requested, per kernel variant

@@ -1269,14 +1269,17 @@ def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
             ("look-ahead launches", {"lookahead_sampler": 1, "flow_sampler": 0}),
-            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1})]
+            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0}),
+            ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     """The device sampler prepares the next half-step's proposals (draw, SED constructor,
     penalties) ahead of time, for both outcomes of each partner's pending move -- in extra
-    workgroups of every launch (k_lnlike SMODE 4) or, by default, in ONE launch per run whose
-    half-steps hand over row by row (SMODE 5).  Same draws and same arithmetic, so chain,
+    workgroups of every launch (k_lnlike SMODE 4), in ONE launch per run whose half-steps hand over
+    row by row (SMODE 5), or, by default, in one launch per run where the passband quadrature of both
+    candidates runs ahead of the partner's decision as well (k_flowm, form 7: one workgroup per pair of
+    walkers and candidate).  Same draws and same arithmetic, so chain,
     lnprob, final state and acceptance counts must be bitwise those of the plain train of one
     launch per half-step: every model variant, stored and unstored runs in sequence, shapes of
     the working-ahead workgroups other than the host's choice."""
@@ -1307,7 +1310,7 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     ref = None
     for flow, rows, waves in ((0, 0, 0), (0, 1, 16), (0, 4, 4), (0, 2, 3), (1, 0, 0), (1, 2, 4), (1, 4, 16), (1, 1, 7)):
         ctx = like.context
-        ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", flow)
+        ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", flow); ctx.set_option("merged_flow_sampler", 0)
         ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
         s = mbb.DeviceEnsembleSampler(100, 5, like, seed=3)
         out = s.run_mcmc(p0, 30)[:2] + (s.chain.copy(), s.naccepted.copy())
@@ -1318,6 +1321,7 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
         for x, y in zip(ref, out):
             assert np.array_equal(x, y), (flow, rows, waves)
     like.context.set_option("lookahead_rows", 0); like.context.set_option("lookahead_waves", 0)
+    like.context.set_option("merged_flow_sampler", 1)
 
 
 def test_lookahead_sampler_forms_with_priors_limits_and_long_runs(mbb, g_lnl):
@@ -1387,8 +1391,8 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
             pos, lnp, _ = s.run_mcmc(p0, nsteps)
             pos2, lnp2, _ = s.run_mcmc(None, 3)
             out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-            assert like.context.info("last_kernel_form") == {"plain": 1, "look-ahead launches": 4,
-                                                             "one launch, row by row": 5}[form]
+            assert like.context.info("last_kernel_form") == {"plain": 1, "look-ahead launches": 4, "one launch, row by row": 5,
+                                                             "one launch, quadrature ahead": 7}[form]
         for form, r in zip(_sampler_forms(None)[1:], out[1:]):
             for x, y in zip(out[0], r):
                 assert np.array_equal(x, y), (form[0], options)
@@ -1416,8 +1420,9 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     ctx = like.context
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(250, 5)))
     out = []
-    for rows, waves, form in ((1, 1, 4), (0, 0, 5)):                 # 500 + 125 workgroups do not fit 256 CUs
+    for rows, waves, merged, form in ((1, 1, 0, 4), (0, 0, 0, 5), (0, 0, 1, 7)):     # 500 + 125 workgroups do not fit 256 CUs
         ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
+        ctx.set_option("merged_flow_sampler", merged)
         s = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
         pos, lnp, _ = s.run_mcmc(p0, 4)
         assert ctx.info("last_kernel_form") == form and np.isfinite(lnp).all()
@@ -1427,6 +1432,16 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     pos2, lnp2, _ = s2.run_mcmc(p0, 4)
     for pos, lnp, ch in out:
         assert np.array_equal(pos, pos2) and np.array_equal(lnp, lnp2) and np.array_equal(ch, s2.chain)
+    # 300 walkers: 150 pairs x 2 candidates do not fit one per CU (form 7), 150 movers + 150 ahead do (form 5)
+    ctx.set_option("lookahead_sampler", 1)
+    p3 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(300, 5)))
+    s3 = mbb.DeviceEnsembleSampler(300, 5, like, seed=9)
+    r3 = s3.run_mcmc(p3, 4)[:2]
+    assert ctx.info("last_kernel_form") == 5
+    ctx.set_option("lookahead_sampler", 0)
+    s4 = mbb.DeviceEnsembleSampler(300, 5, like, seed=9)
+    r4 = s4.run_mcmc(p3, 4)[:2]
+    assert np.array_equal(r3[0], r4[0]) and np.array_equal(r3[1], r4[1]) and np.array_equal(s3.chain, s4.chain)
 
 
 def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, g_lnl):
@@ -1434,23 +1449,24 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
     that is not resident because another process holds CUs) ends with an error flag, not a hang;
     mbb_sampler_run then restores the state the run started from and does the same steps as a train
     of launches -- the caller gets the chain it would have got, and the context stays on the train."""
-    like = _cfg2_like(mbb, g_lnl)
-    ctx = like.context
-    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(100, 5)))
-    ctx.set_option("lookahead_sampler", 0)
-    s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
-    a = s0.run_mcmc(p0, 6)[:2] + (s0.run_mcmc(None, 5)[:2]) + (s0.chain.copy(), s0.naccepted.copy())
-    ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1)
-    s1 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
-    first = s1.run_mcmc(p0, 6)[:2]
-    assert ctx.info("last_kernel_form") == 5 and ctx.info("flow_fallbacks") == 0
-    ctx.set_option("flow_spin_log2", 1)                       # the second run gives up at once ...
-    second = s1.run_mcmc(None, 5)[:2]
-    assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 4      # ... and was redone
-    b = first + second + (s1.chain.copy(), s1.naccepted.copy())
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
-    ctx.set_option("flow_spin_log2", 0)
+    for merged, form in ((1, 7), (0, 5)):
+        like = _cfg2_like(mbb, g_lnl)
+        ctx = like.context
+        p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(100, 5)))
+        ctx.set_option("lookahead_sampler", 0)
+        s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
+        a = s0.run_mcmc(p0, 6)[:2] + (s0.run_mcmc(None, 5)[:2]) + (s0.chain.copy(), s0.naccepted.copy())
+        ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", merged)
+        s1 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
+        first = s1.run_mcmc(p0, 6)[:2]
+        assert ctx.info("last_kernel_form") == form and ctx.info("flow_fallbacks") == 0
+        ctx.set_option("flow_spin_log2", 1)                       # the second run gives up at once ...
+        second = s1.run_mcmc(None, 5)[:2]
+        assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 4      # ... and was redone
+        b = first + second + (s1.chain.copy(), s1.naccepted.copy())
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), form
+        ctx.set_option("flow_spin_log2", 0)
 
 
 def test_one_launch_sampler_ignores_records_left_in_reused_memory(mbb, g_lnl):
@@ -1460,12 +1476,13 @@ def test_one_launch_sampler_ignores_records_left_in_reused_memory(mbb, g_lnl):
     process-wide launch number, and a sampler's record memory starts zeroed)."""
     for k in range(8):
         res = []
-        for look in (1, 0):
+        for look, merged in ((1, 1), (1, 0), (0, 0)):
             like = _cfg2_like(mbb, g_lnl)                         # a context of its own each time
-            like.context.set_option("lookahead_sampler", look)
+            like.context.set_option("lookahead_sampler", look); like.context.set_option("merged_flow_sampler", merged)
             p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(100 + k).normal(size=(64, 5)))
             s = mbb.DeviceEnsembleSampler(64, 5, like, seed=4)     # the same seed: the same check-word arithmetic
             res.append(s.run_mcmc(p0, 3)[:2] + (s.chain.copy(),))
             del s, like
-        for x, y in zip(res[0], res[1]):
-            assert np.array_equal(x, y), k
+        for r in res[:2]:
+            for x, y in zip(r, res[2]):
+                assert np.array_equal(x, y), k

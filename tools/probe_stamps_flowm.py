@@ -26,16 +26,34 @@ st = np.zeros((nb * 4, 32), dtype=np.uint64)
 lib.mbb_stamps(ctx.h, st.ctypes.data_as(C.c_void_p), nb * 4)
 t = st.reshape(-1)[: nb * 16 * 8].reshape(nb, 16, 8).astype(np.float64) / (2 * NS)    # cycles per half-step
 nq = nwave - 3
+spread = nwave >= 12
+QW = [wv for wv in range(nwave) if wv not in (3, 7, 11)] if spread else list(range(nq))
+EW = 11 if spread else nq
+CW = (3, 7) if spread else (nq + 1, nq + 2)
+raw = st.reshape(-1)[: nb * 16 * 8].reshape(nb, 16, 8).astype(np.float64)
 med = lambda v: [int(x) for x in np.median(v, axis=0)]
 tot = t.sum(axis=2)
 print("cycles per half-step of the run (sum of a wave's parts, median over workgroups and waves): %d" % np.median(tot[:, :nwave]))
 print("Q waves 0..%d  [wait for record, units + reduce]:" % (nq - 1))
-for wv in range(nq):
+for wv in QW:
     print("   wave %2d" % wv, med(t[:, wv, :2]))
-print("E wave [global poll, wait for Q, band sums, publish]:", med(t[:, nq, :4]))
+print("E wave [global poll, wait for Q, band sums, publish]:", med(t[:, EW, :4]))
 for cb in range(2):
     print("C wave %d (per half-step; it works every other one) [draws + wait 1, staging, constructor, wait 2, wait E, hand-over]:" % cb,
-          med(t[:, nq + 1 + cb, :6]))
+          med(t[:, CW[cb], :6]), " constructor of one proposal: min %d max %d cycles (medians over workgroups)"
+          % (np.median(raw[:, CW[cb], 7]), np.median(raw[:, CW[cb], 6])))
 for c in range(2):
     sel = t[c::2]
-    print("candidate %d workgroups: E" % c, med(sel[:, nq, :4]), " C0", med(sel[:, nq + 1, :6]))
+    print("candidate %d workgroups: E" % c, med(sel[:, EW, :4]), " C0", med(sel[:, CW[0], :6]))
+
+big = np.zeros((32768 + nb, 32), dtype=np.uint64)
+lib.mbb_stamps(ctx.h, big.ctypes.data_as(C.c_void_p), 32768 + nb)
+hw = big.reshape(-1)[(1 << 20):(1 << 20) + nb * 16].reshape(nb, 16)
+simd = ((hw >> np.uint64(4)) & np.uint64(3)).astype(int)
+cu = ((hw >> np.uint64(8)) & np.uint64(15)).astype(int) + 16 * ((hw >> np.uint64(13)) & np.uint64(7)).astype(int) + 128 * ((hw >> np.uint64(32)) & np.uint64(7)).astype(int)
+print("SIMD of waves 0..15, first workgroups:")
+for g in range(4):
+    print("  ", simd[g].tolist())
+print("workgroups per (XCC, SE, CU): max %d; distinct CUs %d" % (np.bincount(cu[:, 0]).max(), len(set(cu[:, 0].tolist()))))
+same = sum(1 for g in range(nb) if len(set(simd[g][[3, 7, 11]].tolist())) == 1)
+print("workgroups whose waves 3, 7, 11 share one SIMD: %d of %d" % (same, nb))
