@@ -9,33 +9,37 @@
 // of the half that moves then, under the assumption c that its partner's pending move (half-step
 // j - 1) is rejected (c = 0) or accepted (c = 1).  Inside the workgroup three kinds of waves form a
 // pipeline, handing over through words in LDS (no workgroup barrier after the set-up):
-//   C  two waves, one per half of the ensemble (a proposal takes longer than a half-step).  A
-//      wave's four rows of 16 lanes run the constructor for the four outcomes of the two moves of
-//      half-step j - 2 the proposal depends on (the walker's own, and its partner's partner's for
+//   C  three waves, each taking every third half-step (a proposal takes ~1.5 half-steps of a wave's
+//      time).  A wave's four rows of 16 lanes run the constructor for the four outcomes of the two moves
+//      of half-step j - 2 the proposal depends on (the walker's own, and its partner's partner's for
 //      c = 1) -- the values either way are known once half-step j - 3 is decided -- and when those
 //      two decisions arrive only a selection is left: that row's constants go to LDS for Q, its
 //      proposal to the run's state (what other workgroups form their rows from).
 //   Q  the quadrature waves (the units of k_lnlike's phase 2, dealt the same way).
-//   E  one wave: band sums and lnL for this candidate (phase 3 of k_lnlike).  Then the partner's
-//      decision of half-step j - 1 says which of the two sibling workgroups holds the proposal the
-//      chain actually makes: that one does the accept test and publishes decision, row, chain entry.
+//   E  two waves, one per half of the ensemble: band sums and lnL for this candidate (phase 3 of
+//      k_lnlike), formed as soon as Q is through.  Then the partner's decision of half-step j - 1 says
+//      which of the two sibling workgroups holds the proposal the chain actually makes: that one does
+//      the accept test and publishes decision, row, chain entry.
 // A decision therefore depends on the one a half-step earlier only through a selection, on the one
 // two half-steps earlier through quadrature and band sums, and on the one three half-steps earlier
 // through the constructor: the chain per half-step is the largest of (hand-over + accept test),
 // (hand-over + quadrature + band sums) / 2 and (hand-over + constructor + quadrature + band sums) / 3
 // instead of their sum.  The price is twice the quadrature and up to four times the constructor
-// work, on CUs that were waiting.
+// work, on CUs that were waiting.  Measured (tools/probe_flowm.py, probe_chain_flowm.py; the bench
+// workload): 6.2 us per MCMC step against 10.2 for SMODE 5; what a half-step waits for is, in this
+// order, the quadrature (a third), the constructor (a quarter), and the hand-over of the decisions of
+// three half-steps back.
 // Same draws, same arithmetic per candidate, same order of every sum: the chain is bitwise that of
 // the launch train (SMODE 1).
 //
 // State of a run (FlowMView, in the allocation forms 5/6 use for theirs), everything filed under the
-// number m of the move it belongs to, mod kFlowSlots (mbb_flow_index.h; the lag guard keeps a
+// number m of the move it belongs to, mod kFmSlots (mbb_flow_index.h; the lag guard keeps a
 // slot from being overwritten under a reader):
-//   prop [nw][kFlowSlots][2][16]  the proposal of move m, per candidate: word 2i is coordinate i,
+//   prop [nw][kFmSlots][2][16]  the proposal of move m, per candidate: word 2i is coordinate i,
 //                                 word 2i + 1 its check word
-//   row  [kFlowSlots][nw][16]     the row after move m (T, beta, lambda0, alpha, fnorm, lnprob), same pairs;
+//   row  [kFmSlots][nw][16]     the row after move m (T, beta, lambda0, alpha, fnorm, lnprob), same pairs;
 //                                 slot 0 also holds what the launch found (m = 0)
-//   mseq [nw][kFlowSlots]         2 x (half-step of move m + 1) + (it was accepted): the decision
+//   mseq [nw][kFmSlots]         2 x (half-step of move m + 1) + (it was accepted): the decision
 //   done [8][16]                  workgroups through with half-step j, running total per j mod 8
 // A check word is (serial of the launch << 32 | half-step of the move + 1) XOR the bits of the value:
 // a reader takes an element when the pair fits, whenever and in whatever order the two stores arrive,
@@ -45,16 +49,18 @@
 #include "mbb_kernels.hip.h"
 
 // LDS control words (ints) of a k_flowm workgroup
-constexpr int kFmReady = 0;    // [2] C wave b: half-step + 1 of the record last handed to Q (buffer b)
-constexpr int kFmQDone = 2;    // [2] Q waves that have finished a unit pass over buffer b, running total
-constexpr int kFmEDone = 4;    //     E wave: half-step + 1 of the last record it is through with
+constexpr int kFmNC = 3;       // C waves: wave c takes the half-steps j = c mod kFmNC
+constexpr int kFmNB = 4;       // hand-over records in LDS: half-step j uses buffer j mod kFmNB
+constexpr int kFmReady = 0;    // [kFmNB] half-step + 1 of the record last handed to Q through buffer b
+constexpr int kFmQDone = 4;    // [kFmNB] Q waves that have finished a unit pass over buffer b, running total
+constexpr int kFmEDone = 8;    // [kFmNB] half-step + 1 of the last record of buffer b E is through with
 constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: proposal 0..4, (dim-1) ln z,
                                // ln u, the two penalties, the walker's row as it is (9..13)
 // dynamic LDS of a k_flowm launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds)
 {
-    return 2 * sizeof(WalkerK) + 8 * (2 * npart + nb + 2 * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (2 * 4 * 32) + 64 + 32;
+    return kFmNB * sizeof(WalkerK) + 8 * (kFmNB * npart + nb + kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (kFmNC * 64) + 64 + 32;
 }
 
 // an element and its check word
@@ -80,27 +86,30 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwave = blockDim.x >> 6, nq = nwave - 3;
+    const int nwave = blockDim.x >> 6, nq = nwave - kFmNC - 2;
     // Which wave does what.  The constructor is one long dependent chain and runs fastest on a SIMD it
-    // does not share with the quadrature's bursts: waves 3, 7 and 11 (one SIMD: a workgroup's waves go
-    // round the four in turn) are C0, C1 and E, every other wave is a Q wave, numbered in order.
-    // (Fewer than 12 waves: the last three.)
-    const bool spread = nwave >= 12;
-    const int role = spread ? ((wave == 3) ? 1 : (wave == 7) ? 2 : (wave == 11) ? 3 : 0)
-                            : (wave < nq ? 0 : (wave == nq ? 3 : wave - nq));      // 0 Q, 1 C0, 2 C1, 3 E
-    const int qi = spread ? wave - (wave > 3) - (wave > 7) - (wave > 11) : wave;   // Q wave number
+    // does not share with the quadrature's bursts: waves 3, 7, 11 and 15 (one SIMD: a workgroup's waves
+    // go round the four in turn) are the three C waves and E0, wave 14 is E1, the eleven others are Q
+    // waves, numbered in order.  (Fewer than 16 waves: the last five.)  Three C waves, a half-step in
+    // three each, and two E waves, one per half of the ensemble: a proposal takes ~1.5 half-steps of a
+    // wave's time, an E pass ~0.4, and one that had to queue behind the wave's previous one was what a
+    // half-step waited for most often (tools/probe_chain_flowm.py).
+    const bool spread = nwave == 16;
+    const int role = spread ? ((wave & 3) == 3 ? 1 + (wave >> 2) : (wave == 14 ? 2 + kFmNC : 0))
+                            : (wave < nq ? 0 : 1 + wave - nq);                    // 0 Q, 1..3 C, 4 E0, 5 E1
+    const int qi = spread ? wave - (wave >> 2) : wave;                           // Q wave number (14 is not one)
     const int nun = a.nunit, npart = a.npart, nb = a.nb;
     const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1;
     WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);                    // [2]
-    double *partial = reinterpret_cast<double *>(wk + 2);                   // [2][npart]
-    double *mflux = partial + 2 * (size_t)npart;                            // [nb]
+    double *partial = reinterpret_cast<double *>(wk + kFmNB);               // [kFmNB][npart]
+    double *mflux = partial + kFmNB * (size_t)npart;                        // [nb]
     double *prop = mflux + nb;                                              // [2][kFmProp]
-    double *s_flux = prop + 2 * kFmProp;                                    // [nb]
+    double *s_flux = prop + kFmNB * kFmProp;                                // [nb]
     double *s_ivar = s_flux + nb;                                           // [nb]
     double *s_invcov = s_ivar + nb;                                         // [nb*nb] when in LDS
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));   // [nb]
-    double *cscr = reinterpret_cast<double *>(s_band + nb + 1);             // [2][64] (room for [2][4][32])
-    int *ctl = reinterpret_cast<int *>(cscr + 2 * 4 * 32);                  // [16]
+    double *cscr = reinterpret_cast<double *>(s_band + nb + 1);             // [kFmNC][64]
+    int *ctl = reinterpret_cast<int *>(cscr + kFmNC * 64);                  // [16]
     const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15;
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
@@ -152,9 +161,9 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 // ... and when things happened in the launch's last 64 half-steps, on the clock all CUs share (100 MHz):
 // log[(workgroup * 64 + half-step mod 64) * 8 + event], tools/probe_chain_flowm.py
 #define FM_EV(jj, ev) do { if (lane == 0 && a.stamps && (jj) >= niter - 64) \
-        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 8 + (ev))] = __builtin_amdgcn_s_memrealtime(); } while (0)
+        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 16 + (ev))] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define FM_EVV(jj, ev, val) do { if (lane == 0 && a.stamps && (jj) >= niter - 64) \
-        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 8 + (ev))] = (unsigned long long)(val); } while (0)
+        a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + ((jj) & 63)) * 16 + (ev))] = (unsigned long long)(val); } while (0)
 #else
 #define FM_EV(jj, ev) do { } while (0)
 #define FM_EVV(jj, ev, val) do { } while (0)
@@ -185,6 +194,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+    // (the chains of C and E are what a half-step waits for: ahead of the Q wave they share a SIMD with)
+    if (role != 0) __builtin_amdgcn_s_setprio(3);
     // =========================== Q: the passband quadrature ====================================
     if (role == 0) {
         auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
@@ -196,9 +207,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         int tail_first = -1;
         if (qi < nun && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
         for (int it = 0; it < niter; ++it) {
-            const int b = it & 1;
+            const int b = it & (kFmNB - 1);
             lds_wait(ctl + kFmReady + b, it + 1);
             FM_T(0);
+            if (qi == 1) FM_EV(it, 14);
             const WalkerK *wkb = wk + b;
             double *part = partial + (size_t)b * npart;
             if (wkb->status == ROW_OK) {                          // wave-uniform
@@ -237,7 +249,14 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 }
             }
             MBB_FM_ORDER();
+#ifdef MBB_STAMPS
+            if (lane == 0) {
+                const int cnt = __hip_atomic_fetch_add(ctl + kFmQDone + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cnt + 1 == nq * ((it / kFmNB) + 1)) FM_EV(it, 15);      // the last Q wave through with this record
+            }
+#else
             if (lane == 0) __hip_atomic_fetch_add(ctl + kFmQDone + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             FM_T(1);
         }
         FM_TOUT();
@@ -245,12 +264,14 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     }
 
     // =========================== E: band sums, lnL, and the move if it is this candidate's =====
-    if (role == 3) {
-        for (int it = 0; it < niter; ++it) {
-            const int b = it & 1;
+    if (role > kFmNC) {
+        for (int it = role - 1 - kFmNC; it < niter; it += 2) {
+            const int b = it & (kFmNB - 1);
             const int L_step = a.step + (it >> 1), L_half = it & 1;
             const unsigned long long L_seed = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1);
             const int row = (L_half ? a.c_count : 0) + w, c_begin = L_half ? 0 : a.c_count;
+            // (the walker's partner in this half-step: the draw C made for the proposal; E's first look
+            // must not wait for C, so it is made again here -- E has two half-steps per pass)
             double zz, u3;
             int pj;
             stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
@@ -260,12 +281,12 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             // one loop, one round trip when everything is there: lane 21 the walker's lnprob as it is
             // (element 5 of its row after move m_s), lane 22 the partner's decision of half-step it - 1,
             // lane 23 the lag guard
-            const double *lnp_p = fv.row + ((size_t)(m_s % kFlowSlots) * a.nw + row) * kFmWords + 10;
+            const double *lnp_p = fv.row + ((size_t)(m_s % kFmSlots) * a.nw + row) * kFmWords + 10;
             const unsigned long long tag_s = serial32 | (unsigned long long)flow_seq(L_half, m_s);
-            const unsigned long long need_g = 2ull * (unsigned long long)a.n * (unsigned long long)(((it - kFlowLag) >> 3) + 1);
-            const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFlowSlots + (m_par % kFlowSlots)
-                                                        : fv.done + ((it - kFlowLag) & 7) * 16;
-            const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFlowLag);
+            const unsigned long long need_g = 2ull * (unsigned long long)a.n * (unsigned long long)(((it - kFmLag) / kFmRing) + 1);
+            const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFmSlots + (m_par % kFmSlots)
+                                                        : fv.done + ((it - kFmLag) & (kFmRing - 1)) * 16;
+            const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFmLag);
             // The band sums do not wait for the partner: as soon as Q is through they are formed, between
             // asking for the words and looking at the answers; whichever comes last -- the partner's
             // decision or the sums -- is followed by the accept test alone.
@@ -314,9 +335,13 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
                 }
                 MBB_FM_ORDER();
-                if (lane == 0) lds_post(ctl + kFmEDone, it + 1);       // buffer b may be written again
+                if (lane == 0) lds_post(ctl + kFmEDone + b, it + 1);   // buffer b may be written again
             };
-            const int q_need = nq * ((it >> 1) + 1);
+            const int q_need = nq * ((it / kFmNB) + 1);
+            FM_EV(it, 9);
+#ifdef MBB_STAMPS
+            unsigned long long t_ok = 0;
+#endif
             unsigned long long pv = 0;
             double lnp = 0.0;
             bool ok = !(watch || lane == 21), have_sums = false;
@@ -341,6 +366,9 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 // (... and looked at)
                 if (ask_l) { lnp = lv; ok = (lchk ^ (unsigned long long)__double_as_longlong(lv)) == tag_s; }
                 if (ask_w) { pv = wv; ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g); }
+#ifdef MBB_STAMPS
+                if ((ask_l || ask_w) && ok) t_ok = __builtin_amdgcn_s_memrealtime();
+#endif
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 ++spins;
                 if (spins > spin_limit ||
@@ -356,6 +384,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             FM_TD(0, lnp_cur);
             FM_EV(it, 5);
             FM_EVV(it, 7, prow);
+#ifdef MBB_STAMPS
+            { const unsigned long long t21 = __shfl(t_ok, 21), t22 = __shfl(t_ok, 22), t23 = __shfl(t_ok, 23);
+              FM_EVV(it, 10, t21); FM_EVV(it, 11, t22); FM_EVV(it, 12, t23); }
+#endif
             if (!have_sums) {
                 lds_wait(ctl + kFmQDone + b, q_need);
                 FM_T(1);
@@ -373,14 +405,16 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     if (a.has_gprior) r += pen_g;                  // :830-831
                 }
                 if (mine) {
-                    if (lane == 0 && (st >= 2 || r != r)) atomicMax(a.errflag, st >= 2 ? st : (int)ROW_NONFINITE);
+                    // (after a wait has given up -- error 9 -- the stages run on with whatever is in their
+                    // buffers: such a status must not outrank the 9 the host falls back on)
+                    if (lane == 0 && (st >= 2 || r != r)) atomicMax(a.errflag, (st >= 2 && st <= (int)ROW_NONFINITE) ? st : (int)ROW_NONFINITE);
                     const bool accept = (lnz4 + r - lnp_cur) > lnu;
                     const int m_new = m_s + 1;
                     // the decision first, then the row as it is after this half-step, an element and its
                     // check word per lane; counts and chain are for the host: plain stores
                     FM_EV(it, 6);
                     if (lane == 0)
-                        __hip_atomic_store(fv.mseq + (size_t)row * kFlowSlots + (m_new % kFlowSlots),
+                        __hip_atomic_store(fv.mseq + (size_t)row * kFmSlots + (m_new % kFmSlots),
                                            2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     const double lnp_new = accept ? r : lnp_cur;
@@ -388,13 +422,13 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #pragma unroll
                     for (int i = 0; i < 5; ++i) ve = ((lane & 7) == i) ? (accept ? q[i] : old5[i]) : ve;
                     if (lane < 6)
-                        fm_put(fv.row + ((size_t)(m_new % kFlowSlots) * a.nw + row) * kFmWords + 2 * lane, ve,
+                        fm_put(fv.row + ((size_t)(m_new % kFmSlots) * a.nw + row) * kFmWords + 2 * lane, ve,
                                serial32 | (unsigned long long)(it + 1));
                     else if (lane >= 8 && lane < 14 && a.chain6)
                         a.chain6[((size_t)it * a.n + w) * 6 + (lane - 8)] = ve;
                     if (lane == 0 && accept) atomicAdd(a.nacc + (size_t)L_half * a.n + w, 1u);
                 }
-                if (lane == 0) __hip_atomic_fetch_add(fv.done + (it & 7) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(fv.done + (it & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             FM_T(3);
         }
@@ -404,7 +438,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 
     // =========================== C: the proposals, worked out ahead of their decisions =========
     {
-        const int cb = role - 1;                                  // this wave's half of the ensemble
+        const int cb = role - 1;                                  // this wave takes the half-steps j = cb mod kFmNC
         const int vrow = lane >> 4, l16 = lane & 15, base = lane & 48;
         double *scr = cscr + (size_t)cb * 64;
         auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
@@ -424,7 +458,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             }
             return v;
         };
-        for (int j = cb; j < niter; j += 2) {
+        for (int j = cb; j < niter; j += kFmNC) {
             const int hj = j & 1;
             const int sb = hj ? a.c_count : 0, ob = hj ? 0 : a.c_count;    // the half that moves in j / the other
             const int tn = a.step + (j >> 1);
@@ -466,7 +500,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             //   lane 27..36  the same for the partner's partner                 -> scr[20..30)
             {
                 const bool has = m_s > 0;
-                const int so = (has ? m_s - 1 : 0) % kFlowSlots;
+                const int so = (has ? m_s - 1 : 0) % kFmSlots;
                 const unsigned long long tag_old = serial32 | (unsigned long long)flow_seq(hj, has ? m_s - 1 : 0);
                 const unsigned long long tag_g = serial32 | (unsigned long long)(g + 1);
                 const unsigned long long tag_o = serial32 | (unsigned long long)flow_seq(hj ^ 1, m_o);
@@ -476,7 +510,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 int slot = -1, kind = 0;                              // kind 1: a decision word, 2: an element
                 if (lane < 2) {
                     const int r = lane == 0 ? qr : qp;
-                    wsrc = fv.mseq + (size_t)(ob + r) * kFlowSlots + (m_q % kFlowSlots);
+                    wsrc = fv.mseq + (size_t)(ob + r) * kFmSlots + (m_q % kFmSlots);
                     need = (unsigned long long)flow_seq(hj ^ 1, m_q);
                     kind = (has && m_q > 0 && (lane == 0 || c1)) ? 1 : 0;
                 } else if (lane < 7) {
@@ -484,16 +518,17 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 } else if (lane < 12) {
                     src = fv.row + ((size_t)so * a.nw + pprow) * kFmWords + 2 * (lane - 7); tag = tag_old; slot = 15 + lane - 7; kind = c1 ? 2 : 0;
                 } else if (lane < 17) {
-                    src = fv.row + ((size_t)(m_o % kFlowSlots) * a.nw + prow) * kFmWords + 2 * (lane - 12); tag = tag_o; slot = 30 + lane - 12; kind = 2;
+                    src = fv.row + ((size_t)(m_o % kFmSlots) * a.nw + prow) * kFmWords + 2 * (lane - 12); tag = tag_o; slot = 30 + lane - 12; kind = 2;
                 } else if (lane < 27) {
                     const int c = (lane - 17) / 5, i = (lane - 17) - 5 * c;
-                    src = fv.prop + (((size_t)rown * kFlowSlots + (m_s % kFlowSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 5 + lane - 17;
+                    src = fv.prop + (((size_t)rown * kFmSlots + (m_s % kFmSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 5 + lane - 17;
                     kind = has ? 2 : 0;
                 } else if (lane < 37) {
                     const int c = (lane - 27) / 5, i = (lane - 27) - 5 * c;
-                    src = fv.prop + (((size_t)pprow * kFlowSlots + (m_s % kFlowSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 20 + lane - 27;
+                    src = fv.prop + (((size_t)pprow * kFmSlots + (m_s % kFmSlots)) * 2 + c) * kFmWords + 2 * i; tag = tag_g; slot = 20 + lane - 27;
                     kind = (has && c1) ? 2 : 0;
                 }
+                FM_EV(j, 13);
                 bool ok = kind == 0;
                 double v = 0.0;
                 unsigned long long dv = 0;
@@ -513,6 +548,9 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 if (slot >= 0) scr[slot] = v;
                 FM_TD(0, v);
                 FM_EV(j, 0);
+                // (the rows whose decisions this proposal waits for: partner, partner's partner, the two partners of j - 2)
+                FM_EVV(j, 8, (unsigned long long)prow | ((unsigned long long)pprow << 10) | ((unsigned long long)(ob + qr) << 20) |
+                                 ((unsigned long long)(ob + qp) << 30) | ((unsigned long long)(c1 ? 1 : 0) << 40) | ((unsigned long long)(m_s > 0 ? 1 : 0) << 41));
                 MBB_FM_ORDER();
                 // (a decision word that was not waited for reads as candidate 0)
                 const int cr = (int)(__shfl(dv, 0) & 1ull), cp = (int)(__shfl(dv, 1) & 1ull);
@@ -540,7 +578,16 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             k.pad = 0;
             double pen_u = 0.0, pen_g = 0.0;
             const double lT = lo[0], lL = lo[1];
+            // (2) the two decisions of half-step j - 2 say which row of lanes was right.  They are asked
+            // for once towards the end of the constructor, so that the answer is there when it is through
+            // (a decision that arrives later is polled for afterwards)
+            const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFmSlots + (m_s % kFmSlots);
+            const bool watch2 = m_s > 0 && (l16 == 0 || (l16 == 1 && c1));
+            const unsigned long long need2 = (unsigned long long)flow_seq(hj, m_s);
+            unsigned long long v2 = 0;
+#define MBB_WC_AFTER_PROLOGUE if (watch2) v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #include "mbb_walker_consts.inc"
+#undef MBB_WC_AFTER_PROLOGUE
 #ifdef MBB_STAMPS
             {
                 asm volatile("" ::"v"(pen_u + pen_g + k.cbb));
@@ -551,33 +598,32 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #endif
             FM_TD(2, pen_u + pen_g + k.cbb);
             FM_EV(j, 1);
-            // (2) the two decisions of half-step j - 2: which row of lanes was right
-            const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFlowSlots + (m_s % kFlowSlots);
-            const unsigned long long v2 = spin(w2, (unsigned long long)flow_seq(hj, m_s), m_s > 0 && (l16 == 0 || (l16 == 1 && c1)), 1);
+            if (__builtin_amdgcn_ballot_w64(watch2 && (v2 >> 1) < need2) != 0) v2 = spin(w2, need2, watch2, 1);
             const bool ar = m_s > 0 && (__shfl(v2, base + 0) & 1ull), ap = m_s > 0 && c1 && (__shfl(v2, base + 1) & 1ull);
             const int vsel = (ar ? 1 : 0) | (ap ? 2 : 0);
             FM_TD(3, v2);
             FM_EV(j, 2);
             // the record buffer must be free: E is through with half-step j - 2
-            if (j >= 2) lds_wait(ctl + kFmEDone, j - 1);
+            const int bj = j & (kFmNB - 1);
+            if (j >= kFmNB) lds_wait(ctl + kFmEDone + bj, j - kFmNB + 1);
             FM_T(4);
             if (vrow == vsel && l16 == 0) {
-                wk[hj] = k;
-                double *pr = prop + hj * kFmProp;
+                wk[bj] = k;
+                double *pr = prop + bj * kFmProp;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) { pr[i] = p[i]; pr[9 + i] = snv[i]; }
                 pr[5] = 4.0 * lo[2];                              // (dim - 1) ln z, dim = 5
                 pr[6] = lo[3];                                    // ln u
                 pr[7] = pen_u;
                 pr[8] = pen_g;
-                lds_post(ctl + kFmReady + hj, j + 1);
+                lds_post(ctl + kFmReady + bj, j + 1);
 #ifdef MBB_STAMPS
                 if (a.stamps && j >= niter - 64)
-                    a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + (j & 63)) * 8 + 3)] = __builtin_amdgcn_s_memrealtime();
+                    a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + (j & 63)) * 16 + 3)] = __builtin_amdgcn_s_memrealtime();
 #endif
                 // the proposal, for the workgroups that form rows from it: element by element, each
                 // with its check word
-                double *rec = fv.prop + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFmWords;
+                double *rec = fv.prop + (((size_t)rown * kFmSlots + (m_next % kFmSlots)) * 2 + cand) * kFmWords;
                 const unsigned long long tag = serial32 | (unsigned long long)(j + 1);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) fm_put(rec + 2 * i, p[i], tag);

@@ -52,8 +52,8 @@ MBB_FLOWM_EXT(true, true)
 constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)   // = flowm_lds() of mbb_flowm.hip.h
 {
-    return 2 * sizeof(WalkerK) + 8 * (2 * npart + nb + 2 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (2 * 4 * 32) + 64 + 32;
+    return 4 * sizeof(WalkerK) + 8 * (4 * npart + nb + 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (3 * 64) + 64 + 32;
 }
 #include "mbb_host_tables.h"
 
@@ -599,7 +599,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     void (*kern)(const LikeArgs);
     int vi_of_kernel = 0;
     if (sl && sl->merged) {
-        // sampler form 7: 2 n workgroups of (quadrature waves + 3), every one resident; its own LDS plan
+        // sampler form 7: 2 n workgroups of (quadrature waves + 5), every one resident; its own LDS plan
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
         a.m_count = sl->m_count;
@@ -610,8 +610,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.spec = sl->spec;
         a.spec_cfg = (int)((c->opt_flow_spin_log2 & 0x3f) << 24);
         a.n_ahead = 0;
-        const int nq = std::min(threads / 64, 13);
-        const int thr = (nq + 3) * 64;
+        const int nq = std::min(threads / 64, 11);
+        const int thr = (nq + 5) * 64;
         a.cov_in_lds = (c->has_cov && flowm_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
         const size_t sm = flowm_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
         const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;

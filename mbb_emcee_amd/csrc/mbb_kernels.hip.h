@@ -1372,18 +1372,22 @@ struct FlowMView {
     unsigned long long *mseq, *done;
 };
 constexpr int kFmWords = 16;   // words per proposal / per row
+constexpr int kFmSlots = 4;    // slots per row (moves filed mod this)
+constexpr int kFmLag = 4;      // a workgroup at half-step j waits until every workgroup is through with j - kFmLag
+constexpr int kFmRing = 8;     // completion counters, by half-step mod this (a power of two >= 2 kFmLag)
+// (8 slots and a lag of 8 were tried: 6.49 against 6.29 us per step -- the lag guard is not what a half-step waits for)
 __host__ __device__ constexpr size_t flowm_words(size_t nw)
 {
-    return nw * ((size_t)kFlowSlots * 2 * kFmWords + kFlowSlots * kFmWords + kFlowSlots) + 8 * 16;
+    return nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmSlots) + kFmRing * 16;
 }
 static_assert(flowm_words(1000) <= spec_words(1000) && flowm_words(2) <= spec_words(2), "form 7 lives in the allocation of forms 5/6");
 __host__ __device__ __forceinline__ FlowMView flowm_view(double *spec, int nw)
 {
     FlowMView v;
     v.prop = spec;
-    v.row = spec + (size_t)nw * kFlowSlots * 2 * kFmWords;
-    v.mseq = reinterpret_cast<unsigned long long *>(v.row + (size_t)nw * kFlowSlots * kFmWords);
-    v.done = v.mseq + (size_t)nw * kFlowSlots;
+    v.row = spec + (size_t)nw * kFmSlots * 2 * kFmWords;
+    v.mseq = reinterpret_cast<unsigned long long *>(v.row + (size_t)nw * kFmSlots * kFmWords);
+    v.done = v.mseq + (size_t)nw * kFmSlots;
     return v;
 }
 // Form 7: slot 0 of the rows from the sampler's rows, decision words and counters clear.
@@ -1398,7 +1402,7 @@ static __global__ void k_flowm_init(const double *pos6, double *spec, int nw, un
         pair[0] = v;
         reinterpret_cast<unsigned long long *>(pair)[1] = (serial << 32) ^ (unsigned long long)__double_as_longlong(v);
     }
-    const int nwords = nw * kFlowSlots + 8 * 16;                  // mseq and done are contiguous
+    const int nwords = nw * kFmSlots + kFmRing * 16;                  // mseq and done are contiguous
     for (int k = i; k < nwords; k += gridDim.x * blockDim.x) fv.mseq[k] = 0ull;
 }
 
@@ -1409,7 +1413,7 @@ static __global__ void k_flowm_finish(double *pos6, double *spec, int nw, int nh
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw * 6) return;
     const int row = i / 6, e = i - 6 * row;
-    const int slot = flow_cnt(row < nw / 2 ? 0 : 1, nhalf) % kFlowSlots;
+    const int slot = flow_cnt(row < nw / 2 ? 0 : 1, nhalf) % kFmSlots;
     pos6[i] = __hip_atomic_load(fv.row + ((size_t)slot * nw + row) * kFmWords + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

@@ -25,11 +25,12 @@ print("form", ctx.info("last_kernel_form"), "grid", nb, "waves", nwave, "%.3f us
 st = np.zeros((nb * 4, 32), dtype=np.uint64)
 lib.mbb_stamps(ctx.h, st.ctypes.data_as(C.c_void_p), nb * 4)
 t = st.reshape(-1)[: nb * 16 * 8].reshape(nb, 16, 8).astype(np.float64) / (2 * NS)    # cycles per half-step
-nq = nwave - 3
-spread = nwave >= 12
-QW = [wv for wv in range(nwave) if wv not in (3, 7, 11)] if spread else list(range(nq))
-EW = 11 if spread else nq
-CW = (3, 7) if spread else (nq + 1, nq + 2)
+nq = nwave - 5
+spread = nwave == 16
+QW = [wv for wv in range(nwave) if (wv & 3) != 3 and wv != 14] if spread else list(range(nq))
+CW = (3, 7, 11) if spread else (nq, nq + 1, nq + 2)
+EWS = (15, 14) if spread else (nq + 3, nq + 4)
+EW = EWS[0]
 raw = st.reshape(-1)[: nb * 16 * 8].reshape(nb, 16, 8).astype(np.float64)
 med = lambda v: [int(x) for x in np.median(v, axis=0)]
 tot = t.sum(axis=2)
@@ -37,9 +38,10 @@ print("cycles per half-step of the run (sum of a wave's parts, median over workg
 print("Q waves 0..%d  [wait for record, units + reduce]:" % (nq - 1))
 for wv in QW:
     print("   wave %2d" % wv, med(t[:, wv, :2]))
-print("E wave [global poll, wait for Q, band sums, publish]:", med(t[:, EW, :4]))
-for cb in range(2):
-    print("C wave %d (per half-step; it works every other one) [draws + wait 1, staging, constructor, wait 2, wait E, hand-over]:" % cb,
+for e in EWS:
+    print("E wave %d (per half-step; it works every other one) [words (+ the sums, when Q is through first), wait for Q, band sums after the words, decide + publish]:" % e, med(t[:, e, :4]))
+for cb in range(3):
+    print("C wave %d (per half-step; it works every third one) [draws + wait 1, staging, constructor, wait 2, wait E, hand-over]:" % cb,
           med(t[:, CW[cb], :6]), " constructor of one proposal: min %d max %d cycles (medians over workgroups)"
           % (np.median(raw[:, CW[cb], 7]), np.median(raw[:, CW[cb], 6])))
 for c in range(2):
