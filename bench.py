@@ -274,6 +274,10 @@ def main():
              collective="unavailable: %d ranks on %d device(s)" % (world, ndev), valid_for_scaling=False)
     like, flux = make_likelihood(local_rank % ndev)     # one GPU per rank on a real node
     ctx = like._sync_device()
+    if os.environ.get("MBB_BENCH_PLAIN_TRAIN"):
+        # profiler passes only (tools/run_profiles.sh): the same chain as a launch per half-step, the
+        # form that computes nothing twice -- its counters are the algorithmic work of a half-step
+        ctx.set_option("lookahead_sampler", 0)
     nq, nb = ctx.info("nq"), ctx.info("nb")
     base["config"]["nq"] = nq
     half = NW_PER_GPU // 2
@@ -455,12 +459,19 @@ def main():
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = ctx.info("last_kernel_form")
         out["config"] = dict(out["config"])
-        if form in (5, 6):
+        if form in (5, 6, 7):
             nlaunch = (args.steps + 4095) // 4096
-            kern_label = ("k_lnlike<thick,alpha,one-launch look-ahead run,staged>: %d workgroups move walkers, %d work "
-                          "ahead" % (half, ctx.info("last_workgroups_ahead")))
-            out["config"]["sampler_form"] = ("one launch per 4096 steps%s (k_lnlike SMODE %d): the timed region is %d launch(es) "
-                                             "of %d half-steps" % (" on every rank" if form == 6 else "", form, nlaunch, 2 * args.steps))
+            if form == 7:
+                kern_label = ("k_flowm<thick,alpha,staged>: %d workgroups, one per (pair of walkers, candidate); constructor, "
+                              "quadrature and accept test of a half-step in waves of their own" % ctx.info("last_grid"))
+                out["config"]["sampler_form"] = ("one launch per 4096 steps, the quadrature of both candidates ahead of the partner's "
+                                                 "decision (k_flowm, form 7): the timed region is %d launch(es) of %d half-steps"
+                                                 % (nlaunch, 2 * args.steps))
+            else:
+                kern_label = ("k_lnlike<thick,alpha,one-launch look-ahead run,staged>: %d workgroups move walkers, %d work "
+                              "ahead" % (half, ctx.info("last_workgroups_ahead")))
+                out["config"]["sampler_form"] = ("one launch per 4096 steps%s (k_lnlike SMODE %d): the timed region is %d launch(es) "
+                                                 "of %d half-steps" % (" on every rank" if form == 6 else "", form, nlaunch, 2 * args.steps))
             out["kernel_avg_us"] = stream_ms * 1e3 / nlaunch
         else:
             kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
@@ -551,7 +562,8 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     # first half of round 2 timed), and with the look-ahead as extra workgroups of each launch
     forms = {}
     for name, opts in (("one_launch_per_half_step", {"lookahead_sampler": 0}),
-                       ("one_launch_per_half_step_with_lookahead", {"lookahead_sampler": 1, "flow_sampler": 0})):
+                       ("one_launch_per_half_step_with_lookahead", {"lookahead_sampler": 1, "flow_sampler": 0}),
+                       ("one_launch_per_run_proposals_ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0})):
         for o, v in opts.items():
             ctx.set_option(o, v)
         s2 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
@@ -562,7 +574,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
         forms[name] = {"stream_us_per_step": ctx.elapsed_ms(f0, f1) * 1e3 / ksteps,
                        "evals_per_s": NW_PER_GPU * ksteps / (ctx.elapsed_ms(f0, f1) * 1e-3)}
         del s2
-    ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1)
+    ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", 1)
     forms["note"] = "the other forms of the device sampler, same chain bit for bit (stream time, HIP events)"
     out["other_sampler_forms"] = forms
 
@@ -582,18 +594,20 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     # numbers of half-steps, so its counters are taken per half-step (all launches of the
     # profiled run / the half-steps they cover: tools/summarize_valu.py) and priced against
     # the half-step time measured above; a launch of the timed region is 2 K of those.
-    kname = "k_lnlike<false, false, %d, true>" % form
+    kname = "k_flowm<false, false, true>" if form == 7 else "k_lnlike<false, false, %d, true>" % form
     pm, pm_src = measured_valu("pmc_valu_cfg2*.json", kname)
     per_launch = 1.0
-    if pm and form == 5 and "counters_per_half_step" in pm:
+    if pm and form in (5, 7) and "counters_per_half_step" in pm:
         pm = dict(pm)
         pm["counters_per_launch"] = pm["counters_per_half_step"]
         per_launch = 2.0 * min(args.steps, 4096)
-    elif form == 5:
+    elif form in (5, 7):
         pm = None
     roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
-    if roof and form == 5:
-        roof["unit_of_counts"] = "one half-step (125 walkers moved, 250 proposals prepared ahead)"
+    if roof and form in (5, 7):
+        roof["unit_of_counts"] = ("one half-step (125 walkers moved; the quadrature of 250 candidates and the constructor of up to "
+                                  "1000 variants run for them)" if form == 7 else
+                                  "one half-step (125 walkers moved, 250 proposals prepared ahead)")
         roof["half_steps_per_launch"] = per_launch
         roof["fp64_flops_per_launch"] = roof["fp64_flops_per_launch"] * per_launch
         roof["fp64_flops_per_half_step"] = roof["fp64_flops_per_launch"] / per_launch
@@ -601,11 +615,30 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
         roof["fp64_wave_instructions_per_half_step"] = roof.pop("fp64_wave_instructions_per_launch")
         roof["kernel_us"] = k_us * per_launch
         roof["half_step_us"] = k_us
-        roof["note"] = ("the counts include the proposals prepared for the outcome that did not happen (half of the "
-                        "constructor work) and the instructions spent polling")
+        roof["note"] = (("the counts include the work for outcomes that did not happen -- half of the quadrature, up to three "
+                         "quarters of the constructor -- and the instructions spent polling; `useful_fp64_flops_per_half_step` "
+                         "is the same chain's count in the form that computes nothing twice (the plain launch train)")
+                        if form == 7 else
+                        ("the counts include the proposals prepared for the outcome that did not happen (half of the "
+                         "constructor work) and the instructions spent polling"))
+    if roof and form == 7:
+        # `achieved` is algorithmic work over time: the fp64 flops of a half-step in the form that computes
+        # nothing twice (the plain launch of 125 walkers, counted in its own profiler pass); what the launch
+        # executes, outcomes that did not happen included, is kept beside it
+        plain, plain_src = measured_valu("pmc_valu_plain*.json", "k_lnlike<false, false, 1, true>")
+        roof["executed_tflops"] = roof["achieved"]
+        roof["executed_fp64_flops_per_half_step"] = roof["fp64_flops_per_half_step"]
+        if plain:
+            useful = plain["fp64_flops_per_launch"]
+            roof["useful_fp64_flops_per_half_step"] = useful
+            roof["achieved"] = useful / (k_us * 1e-6) / 1e12
+            roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
+            roof["useful_counters_source"] = plain_src
+        else:
+            roof["note"] += "; no summary of the plain launch found: `achieved` is the executed count"
     alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
     traffic, traffic_src = measured_traffic(kname)
-    if form == 5:
+    if form in (5, 7):
         f = newest_profile("pmc_traffic*.json")
         traffic = None
         try:
@@ -620,7 +653,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
            "algorithmic_bytes_per_launch": alg_bytes * per_launch, "algorithmic_bytes_per_half_step": alg_bytes,
            "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per half-step.  "
                    + ("Per half-step; the tables are staged once per launch, what crosses the fabric every half-step "
-                      "is the hand-over between workgroups (records, rows, the words they poll)" if form == 5 else
+                      "is the hand-over between workgroups (records, rows, the words they poll)" if form in (5, 7) else
                       "The traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
                       "kernel code reaching each of the 8 XCD L2s once per launch")}
     if roof is None:
@@ -629,10 +662,12 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     roof["traffic"] = traffic
     roof["kernel_avg_us"] = k_us
     roof["sample_arithmetic"] = arith
-    roof["why_far_below"] = ("a half-step of 125 walkers is latency: one workgroup per walker, 9 chunks of samples per "
-                             "SIMD between two workgroup barriers (a wave's chunk pairs one after the other: dependent LDS look-ups), the "
-                             "band sums and the accept test of one lane, then ~0.6 us until the partner's workgroup on "
-                             "another XCD sees the decision; see cfg5 for the same arithmetic when the chip is full")
+    roof["why_far_below"] = ("a half-step of 125 walkers is a chain of latencies, not a stream: constructor (one dependent chain of "
+                             "fp64 transcendentals on 16 lanes), quadrature (12 chunks of samples per SIMD, three dependent LDS "
+                             "look-ups per sample), band sums and accept test, then ~1 us until the workgroups that depend on the "
+                             "decision see it across XCDs.  Form 7 runs those stages ahead of the decisions they depend on, for every "
+                             "outcome still possible, so a half-step is the longest of three shorter chains instead of their sum; "
+                             "see cfg5 for the same arithmetic when the chip is full")
     out["roofline"] = roof
     out["roofline_hbm"] = hbm
 

@@ -195,6 +195,10 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * "lookahead_sampler" (default 1; 0: the plain train of one launch per half-step),
  * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row;
  * 0: the next half-step's proposals prepared by extra workgroups of every launch),
+ * "merged_flow_sampler" (default 1: in that one launch the passband quadrature of both proposals a
+ * walker can end up making, and the SED constructor for every outcome still open, run ahead of the
+ * decisions they depend on -- one workgroup per pair of walkers and candidate, ensembles up to two
+ * walkers per CU ("form 7"); 0: only the proposals are prepared ahead ("form 5")),
  * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
  * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),

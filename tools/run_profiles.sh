@@ -23,9 +23,12 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 echo "traffic done"
 timeout -k 10 300 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu_cfg2 -- python3 bench.py $SHORT > $O/valu_cfg2.log 2>&1 || exit 5
 timeout -k 10 400 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu -- python3 tools/bench_cfg5.py --quick > $O/valu.log 2>&1 || exit 6
+# the same chain as a train of plain launches: the algorithmic work of a half-step (nothing computed twice)
+MBB_BENCH_PLAIN_TRAIN=1 timeout -k 10 300 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu_plain -- python3 bench.py $SHORT > $O/valu_plain.log 2>&1 || exit 7
 echo "valu done"
 python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $HS > /dev/null
 python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "" $HS > /dev/null
+python3 tools/summarize_valu.py $O/pmc_valu_plain $O/pmc_valu_plain.json "MBB_BENCH_PLAIN_TRAIN=1 rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "the sampler as one plain launch per half-step" > /dev/null
 python3 tools/summarize_valu.py $O/pmc_valu $O/pmc_valu_cfg5.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 tools/bench_cfg5.py --quick" > /dev/null
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
 ls $O
