@@ -20,3 +20,11 @@ constexpr int kFlowLag = 4;        // a mover of half-step j waits until every m
 MBB_FLOW_HD constexpr int flow_cnt(int h, int j) { return (j - h + 1) > 0 ? (j - h + 1) >> 1 : 0; }
 // what a row's word says once its m-th move is published: the half-step of that move plus one
 MBB_FLOW_HD constexpr int flow_seq(int h, int m) { return m > 0 ? h + 2 * m - 1 : 0; }
+
+// ---- sampler form 7 (k_flowm, mbb_flowm.hip.h): the same numbering of half-steps and moves
+constexpr int kFmSlots = 4;    // slots per row (moves filed mod this)
+constexpr int kFmLag = 4;      // a workgroup at half-step j waits until every workgroup is through with j - kFmLag
+constexpr int kFmRing = 8;     // completion counters, by half-step mod this (a power of two >= 2 kFmLag)
+// (8 slots and a lag of 8 were tried: 6.49 against 6.29 us per step -- the lag guard is not what a half-step waits for)
+constexpr int kFmNC = 3;       // C waves of a workgroup: wave c takes the half-steps j = c mod kFmNC
+constexpr int kFmNB = 4;       // hand-over records in a workgroup's LDS: half-step j uses buffer j mod kFmNB

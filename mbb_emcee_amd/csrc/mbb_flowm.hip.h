@@ -49,8 +49,7 @@
 #include "mbb_kernels.hip.h"
 
 // LDS control words (ints) of a k_flowm workgroup
-constexpr int kFmNC = 3;       // C waves: wave c takes the half-steps j = c mod kFmNC
-constexpr int kFmNB = 4;       // hand-over records in LDS: half-step j uses buffer j mod kFmNB
+// (kFmNC C waves, kFmNB hand-over records in LDS: mbb_flow_index.h)
 constexpr int kFmReady = 0;    // [kFmNB] half-step + 1 of the record last handed to Q through buffer b
 constexpr int kFmQDone = 4;    // [kFmNB] Q waves that have finished a unit pass over buffer b, running total
 constexpr int kFmEDone = 8;    // [kFmNB] half-step + 1 of the last record of buffer b E is through with

@@ -289,3 +289,9 @@ extern "C" int mbbh_flow_index(int h, int j, int m, int *cnt, int *seq, int *slo
     return 0;
 }
 
+// ... and the constants of sampler form 7 (tests/_flowm_model.py)
+extern "C" int mbbh_flowm_consts(int *slots, int *lag, int *ring, int *nc, int *nb)
+{
+    *slots = kFmSlots; *lag = kFmLag; *ring = kFmRing; *nc = kFmNC; *nb = kFmNB;
+    return 0;
+}

@@ -1372,10 +1372,7 @@ struct FlowMView {
     unsigned long long *mseq, *done;
 };
 constexpr int kFmWords = 16;   // words per proposal / per row
-constexpr int kFmSlots = 4;    // slots per row (moves filed mod this)
-constexpr int kFmLag = 4;      // a workgroup at half-step j waits until every workgroup is through with j - kFmLag
-constexpr int kFmRing = 8;     // completion counters, by half-step mod this (a power of two >= 2 kFmLag)
-// (8 slots and a lag of 8 were tried: 6.49 against 6.29 us per step -- the lag guard is not what a half-step waits for)
+// (kFmSlots, kFmLag, kFmRing: mbb_flow_index.h)
 __host__ __device__ constexpr size_t flowm_words(size_t nw)
 {
     return nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmSlots) + kFmRing * 16;

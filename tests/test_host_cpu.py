@@ -488,3 +488,33 @@ def test_flow_protocol_model():
     # the same without the guard: they run on, and the sleeper wakes up to slots that were reused
     with pytest.raises(FM.Violation):
         FM.run(ix, n2, 14, random.Random(1), guard=False, partner=avoid0, stall=(0, 4, 5000))
+
+
+def test_flowm_protocol_model():
+    """The hand-over protocol of sampler form 7 (k_flowm: one workgroup per pair of walkers and candidate,
+    constructor / quadrature / accept test in waves of their own), restated on the host with the kernel's
+    index arithmetic and constants (mbb_flow_index.h) and run in random and adversarial order, every store
+    landing at a random later time: with the lag guard no slot -- proposal, row, decision word -- is
+    reused under a reader and every run completes; a stalled constructor wave stops what depends on it
+    and nothing else; without the guard the same adversary gets a slot overwritten."""
+    import random
+    import _flow_model as FM
+    import _flowm_model as F7
+    LC, lib = _hosttables_lib()
+    ix = FM.Index(lib)
+    slots, lag, ring, nc, nb = F7.consts(lib)
+    assert (slots, lag, ring, nc, nb) == (4, 4, 8, 3, 4)
+    assert lag <= 2 * slots - 4 and ring >= 2 * lag and (ring & (ring - 1)) == 0     # what the kernel's comments derive
+    for seed in range(8):
+        rng = random.Random(seed)
+        lead, events, finished = F7.run(ix, lib, n2=rng.choice((2, 3, 5)), nsteps=10, rng=rng)
+        assert finished and lead <= lag + nb, (seed, lead)
+    # adversary: nobody needs pair 0 as a partner; its candidate-0 workgroup's constructor sleeps through
+    # half-step 4: the others run ahead until the guard stops them, the sleeper wakes up to intact slots
+    n2 = 4
+    avoid0 = lambda r, j: 1 + (r + j) % (n2 - 1)
+    lead, events, finished = F7.run(ix, lib, n2, 10, random.Random(1), partner=avoid0, stall=((0, 0), 4, 20000))
+    assert finished and lead <= lag + nb
+    with pytest.raises(FM.Violation):
+        F7.run(ix, lib, n2, 10, random.Random(1), guard=False, partner=avoid0, stall=((0, 0), 4, 20000))
+
