@@ -39,12 +39,16 @@
 //                                 word 2i + 1 its check word
 //   row  [kFmSlots][nw][16]     the row after move m (T, beta, lambda0, alpha, fnorm, lnprob), same pairs;
 //                                 slot 0 also holds what the launch found (m = 0)
-//   mseq [nw][kFmSlots]         2 x (half-step of move m + 1) + (it was accepted): the decision
-//   done [8][16]                  workgroups through with half-step j, running total per j mod 8
+//   mseq [nw][kFmSlots]         the decision: (serial of the launch << 32) | 2 x (half-step of move m + 1) + (it was accepted)
+//   done [2][kFmRing][16]       workgroups through with half-step j, running total per j mod kFmRing; a launch
+//                                 uses one of the two sets and clears the other for the sampler's next launch
 // A check word is (serial of the launch << 32 | half-step of the move + 1) XOR the bits of the value:
 // a reader takes an element when the pair fits, whenever and in whatever order the two stores arrive,
 // so nobody waits for stores to land or raises a flag after them, and nothing left in memory by an
-// earlier run ever fits.
+// earlier run ever fits.  That also makes a run ONE launch with nothing before or after it: a
+// workgroup files its own two walkers' rows as it finds them (slot 0) when it starts -- whoever needs
+// them polls the check words like any others -- and the workgroup that decides a row's last move of the
+// launch stores it back into the sampler's rows.
 #pragma once
 #include "mbb_kernels.hip.h"
 
@@ -116,6 +120,11 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
     const FlowMView fv = flowm_view(a.spec, a.nw);
     const unsigned long long serial32 = a.flow_serial << 32;
+    unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16;    // this launch's counters
+    // a decision word of this launch whose half-step + 1 is at least `need`
+    auto dec_ok = [&](unsigned long long v, unsigned long long need) {
+        return (v >> 32) == (serial32 >> 32) && ((v & 0xffffffffull) >> 1) >= need;
+    };
     const int niter = a.persist;
 
     // ---- set-up, once per launch: tables -> LDS, control words clear --------------------------
@@ -141,6 +150,15 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             for (int i = tid; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
         }
         if (tid < 16) ctl[tid] = 0;
+        // the launch's own set-up of the run's state (no kernel before this one): this pair's two
+        // rows as the sampler holds them -> slot 0, with this launch's check words (candidate 0's
+        // workgroup does it); workgroup 0 clears the completion counters of the sampler's NEXT launch
+        if (cand == 0 && tid < 12) {
+            const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
+            fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
+        }
+        if (blockIdx.x == 0 && tid < kFmRing * 16)
+            __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // diagnostic build: cycles a wave spends in each part of its loop, summed over the launch
@@ -284,7 +302,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             const unsigned long long tag_s = serial32 | (unsigned long long)flow_seq(L_half, m_s);
             const unsigned long long need_g = 2ull * (unsigned long long)a.n * (unsigned long long)(((it - kFmLag) / kFmRing) + 1);
             const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFmSlots + (m_par % kFmSlots)
-                                                        : fv.done + ((it - kFmLag) & (kFmRing - 1)) * 16;
+                                                        : done_set + ((it - kFmLag) & (kFmRing - 1)) * 16;
             const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFmLag);
             // The band sums do not wait for the partner: as soon as Q is through they are formed, between
             // asking for the words and looking at the answers; whichever comes last -- the partner's
@@ -364,7 +382,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 }
                 // (... and looked at)
                 if (ask_l) { lnp = lv; ok = (lchk ^ (unsigned long long)__double_as_longlong(lv)) == tag_s; }
-                if (ask_w) { pv = wv; ok = (lane == 22 ? pv >> 1 : pv) >= (lane == 22 ? need_p : need_g); }
+                if (ask_w) { pv = wv; ok = lane == 22 ? dec_ok(pv, need_p) : pv >= need_g; }
 #ifdef MBB_STAMPS
                 if ((ask_l || ask_w) && ok) t_ok = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -414,20 +432,23 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     FM_EV(it, 6);
                     if (lane == 0)
                         __hip_atomic_store(fv.mseq + (size_t)row * kFmSlots + (m_new % kFmSlots),
-                                           2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull), __ATOMIC_RELAXED,
+                                           serial32 | (2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     const double lnp_new = accept ? r : lnp_cur;
                     double ve = lnp_new;
 #pragma unroll
                     for (int i = 0; i < 5; ++i) ve = ((lane & 7) == i) ? (accept ? q[i] : old5[i]) : ve;
-                    if (lane < 6)
+                    if (lane < 6) {
                         fm_put(fv.row + ((size_t)(m_new % kFmSlots) * a.nw + row) * kFmWords + 2 * lane, ve,
                                serial32 | (unsigned long long)(it + 1));
+                        // the row's last move of the launch: back into the sampler's rows (no kernel after this one)
+                        if (it + 2 >= niter) a.pos6[(size_t)row * 6 + lane] = ve;
+                    }
                     else if (lane >= 8 && lane < 14 && a.chain6)
                         a.chain6[((size_t)it * a.n + w) * 6 + (lane - 8)] = ve;
                     if (lane == 0 && accept) atomicAdd(a.nacc + (size_t)L_half * a.n + w, 1u);
                 }
-                if (lane == 0) __hip_atomic_fetch_add(fv.done + (it & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_fetch_add(done_set + (it & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             FM_T(3);
         }
@@ -440,12 +461,12 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         const int cb = role - 1;                                  // this wave takes the half-steps j = cb mod kFmNC
         const int vrow = lane >> 4, l16 = lane & 15, base = lane & 48;
         double *scr = cscr + (size_t)cb * 64;
-        auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch, int shift) {
+        auto spin = [&](const unsigned long long *word, unsigned long long need, bool watch) {    // for decision words
             unsigned long long v = 0;
             long long spins = 0;
             for (;;) {
                 bool ok = true;
-                if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (v >> shift) >= need; }
+                if (watch) { v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = dec_ok(v, need); }
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                 ++spins;
                 if (spins > spin_limit ||
@@ -534,7 +555,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 long long spins = 0;
                 for (;;) {
                     if (kind == 2 && !ok) ok = fm_get(src, tag, v);
-                    if (kind == 1 && !ok) { dv = __hip_atomic_load(wsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = (dv >> 1) >= need; }
+                    if (kind == 1 && !ok) { dv = __hip_atomic_load(wsrc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = dec_ok(dv, need); }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                     ++spins;
                     if (spins > spin_limit ||
@@ -597,7 +618,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #endif
             FM_TD(2, pen_u + pen_g + k.cbb);
             FM_EV(j, 1);
-            if (__builtin_amdgcn_ballot_w64(watch2 && (v2 >> 1) < need2) != 0) v2 = spin(w2, need2, watch2, 1);
+            if (__builtin_amdgcn_ballot_w64(watch2 && !dec_ok(v2, need2)) != 0) v2 = spin(w2, need2, watch2);
             const bool ar = m_s > 0 && (__shfl(v2, base + 0) & 1ull), ap = m_s > 0 && c1 && (__shfl(v2, base + 1) & 1ull);
             const int vsel = (ar ? 1 : 0) | (ap ? 2 : 0);
             FM_TD(3, v2);

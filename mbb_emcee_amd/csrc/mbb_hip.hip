@@ -536,7 +536,8 @@ struct SamplerLaunch {
     bool spec_first;              // the run's first launch: nobody moves
     bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
     bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
-    unsigned long long serial = 0;   // ... the number of its launch (set up with it: k_flowm_init)
+    unsigned long long serial = 0;   // ... the number of its launch (in its check words and decision words)
+    int parity = 0;               // ... which of the two sets of completion counters it uses
 };
 
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -608,7 +609,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.persist = sl->persist;
         a.flow_serial = c->flow_serial = sl->serial;
         a.spec = sl->spec;
-        a.spec_cfg = (int)((c->opt_flow_spin_log2 & 0x3f) << 24);
+        a.spec_cfg = (int)((c->opt_flow_spin_log2 & 0x3f) << 24) | (sl->parity & 1);
         a.n_ahead = 0;
         const int nq = std::min(threads / 64, 11);
         const int thr = (nq + 5) * 64;
@@ -817,6 +818,8 @@ struct mbb_sampler_state {
     double *d_bak = nullptr;             // one-launch run: the rows and counts it started from (R x 6 doubles, R counts)
     bool flow_used = false;              // the last enqueue took the one-launch form
     double *d_spec = nullptr;            // look-ahead run: records [rows][2][kSpecRec] + state [2][rows][8]
+    int spec_form = 0;                   // the sampler form whose state d_spec holds (0: none / not to be trusted)
+    int flowm_parity = 0;                // form 7: the set of completion counters the next launch uses
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
@@ -945,7 +948,7 @@ static int allgather_bytes(mbb_ctx *c, void *base, size_t bytes_per_rank)
     return MBB_OK;
 }
 
-static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store)
+static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store, bool backup = true)
 {
     s->flow_used = false;
     ShardPlan p;
@@ -1063,16 +1066,28 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             sl.spec = s->d_spec;
             // what the run starts from, kept so that a run that times out (a workgroup that is not
             // resident: another process on the GPU) can be redone as a launch train (mbb_sampler_run)
-            if (!s->d_bak) HIPCHK(hipMalloc((void **)&s->d_bak, R * 6 * sizeof(double) + R * sizeof(unsigned int)));
-            HIPCHK(hipMemcpyAsync(s->d_bak, s->d_pos6, R * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(s->d_bak + R * 6, s->d_nacc, R * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
-            s->flow_used = true;
+            // (mbb_sampler_advance_async does not redo anything: no copy there)
+            if (backup) {
+                if (!s->d_bak) HIPCHK(hipMalloc((void **)&s->d_bak, R * 6 * sizeof(double) + R * sizeof(unsigned int)));
+                HIPCHK(hipMemcpyAsync(s->d_bak, s->d_pos6, R * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync(s->d_bak + R * 6, s->d_nacc, R * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
+            }
+            s->flow_used = backup;
+            if (merged && s->spec_form != 7) {
+                // form 7 finds its completion counters cleared by the launch before it; after another form
+                // (or a run that gave up) has used the memory, once from here
+                const FlowMView fvh = flowm_view(s->d_spec, (int)R);
+                HIPCHK(hipMemsetAsync(fvh.done, 0, 2 * kFmRing * 16 * sizeof(unsigned long long), c->stream));
+                s->flowm_parity = 0;
+            }
+            s->spec_form = merged ? 7 : 5;
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
                 if (merged) {
+                    // one launch, nothing before or after it: it files the rows it finds and stores the last ones back
                     sl.serial = ++g_flow_serial;
-                    hipLaunchKernelGGL(k_flowm_init, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream,
-                                       s->d_pos6, s->d_spec, (int)R, sl.serial);
+                    sl.parity = s->flowm_parity;
+                    s->flowm_parity ^= 1;
                 } else {
                     hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
                                        s->d_pos6, s->d_spec, (int)R);
@@ -1087,13 +1102,15 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.merged = merged;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 // the sampler's rows from the slots the launch's last moves went to
-                hipLaunchKernelGGL(merged ? k_flowm_finish : k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0,
-                                   c->stream, s->d_pos6, s->d_spec, (int)R, 2 * nt);
+                if (!merged)
+                    hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream, s->d_pos6,
+                                       s->d_spec, (int)R, 2 * nt);
                 HIPCHK(hipGetLastError());
             }
             s->steps_done += (unsigned long long)nsteps;
             return MBB_OK;
         }
+        s->spec_form = 4;
         hipLaunchKernelGGL(k_spec_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
                            s->d_pos6, s->d_spec, (int)R);
         HIPCHK(hipGetLastError());
@@ -1202,6 +1219,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
             HIPCHK(hipMemcpyAsync(s->d_nacc, s->d_bak + (size_t)R * 6, (size_t)R * sizeof(unsigned int), hipMemcpyDeviceToDevice,
                                   c->stream));
             s->steps_done -= (unsigned long long)nsteps;
+            s->spec_form = 0;
             c->opt_flow = 0;
             ++c->flow_fallbacks;
             return mbb_sampler_run(c, sp, nsteps, stretch_a, chain, lnprob, pos_out, lnprob_out, naccepted);
@@ -1241,7 +1259,7 @@ extern "C" int mbb_sampler_advance_async(mbb_ctx *c, void *sp, int nsteps, doubl
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0) return fail(MBB_ERR_ARG, "bad sampler arguments");
-    return sampler_enqueue(c, s, nsteps, stretch_a, false);
+    return sampler_enqueue(c, s, nsteps, stretch_a, false, false);
 }
 
 // ---- SED-level entry points -------------------------------------------------

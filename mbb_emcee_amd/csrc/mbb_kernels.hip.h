@@ -1375,7 +1375,7 @@ constexpr int kFmWords = 16;   // words per proposal / per row
 // (kFmSlots, kFmLag, kFmRing: mbb_flow_index.h)
 __host__ __device__ constexpr size_t flowm_words(size_t nw)
 {
-    return nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmSlots) + kFmRing * 16;
+    return nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmSlots) + 2 * kFmRing * 16;
 }
 static_assert(flowm_words(1000) <= spec_words(1000) && flowm_words(2) <= spec_words(2), "form 7 lives in the allocation of forms 5/6");
 __host__ __device__ __forceinline__ FlowMView flowm_view(double *spec, int nw)
@@ -1387,33 +1387,6 @@ __host__ __device__ __forceinline__ FlowMView flowm_view(double *spec, int nw)
     v.done = v.mseq + (size_t)nw * kFmSlots;
     return v;
 }
-// Form 7: slot 0 of the rows from the sampler's rows, decision words and counters clear.
-static __global__ void k_flowm_init(const double *pos6, double *spec, int nw, unsigned long long serial)
-{
-    const FlowMView fv = flowm_view(spec, nw);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nw * 6) {
-        const int row = i / 6, e = i - 6 * row;
-        const double v = pos6[i];
-        double *pair = fv.row + (size_t)row * kFmWords + 2 * e;
-        pair[0] = v;
-        reinterpret_cast<unsigned long long *>(pair)[1] = (serial << 32) ^ (unsigned long long)__double_as_longlong(v);
-    }
-    const int nwords = nw * kFmSlots + kFmRing * 16;                  // mseq and done are contiguous
-    for (int k = i; k < nwords; k += gridDim.x * blockDim.x) fv.mseq[k] = 0ull;
-}
-
-// Form 7, when a launch of `nhalf` half-steps has ended: the sampler's rows from the slots the last moves went to.
-static __global__ void k_flowm_finish(double *pos6, double *spec, int nw, int nhalf)
-{
-    const FlowMView fv = flowm_view(spec, nw);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw * 6) return;
-    const int row = i / 6, e = i - 6 * row;
-    const int slot = flow_cnt(row < nw / 2 ? 0 : 1, nhalf) % kFmSlots;
-    pos6[i] = __hip_atomic_load(fv.row + ((size_t)slot * nw + row) * kFmWords + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // SMODE 6: tells every rank that this rank's copy is set up for run `run` (which = 0) or that
 // its launch of that run has ended (which = 1; with the top bit set if the launch gave up: what it
 // stored into the peers' copies after that is not to be trusted, so they must fail too).  One wave.
