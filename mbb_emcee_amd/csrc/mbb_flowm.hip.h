@@ -62,7 +62,7 @@ constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: 
 // dynamic LDS of a k_flowm launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds)
 {
-    return kFmNB * sizeof(WalkerK) + 8 * (kFmNB * npart + nb + kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+    return kFmNB * sizeof(WalkerK) + 8 * (kFmNB * npart + 2 * nb + kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
            8 * (nb + 2) + 8 * (kFmNC * 64) + 64 + 32;
 }
 
@@ -105,8 +105,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1;
     WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);                    // [2]
     double *partial = reinterpret_cast<double *>(wk + kFmNB);               // [kFmNB][npart]
-    double *mflux = partial + kFmNB * (size_t)npart;                        // [nb]
-    double *prop = mflux + nb;                                              // [2][kFmProp]
+    double *mflux_all = partial + kFmNB * (size_t)npart;                    // [2][nb]: a scratch row per E wave
+    double *prop = mflux_all + 2 * nb;                                      // [kFmNB][kFmProp]
     double *s_flux = prop + kFmNB * kFmProp;                                // [nb]
     double *s_ivar = s_flux + nb;                                           // [nb]
     double *s_invcov = s_ivar + nb;                                         // [nb*nb] when in LDS
@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 
     // =========================== E: band sums, lnL, and the move if it is this candidate's =====
     if (role > kFmNC) {
+        double *mflux = mflux_all + (size_t)(role - 1 - kFmNC) * nb;     // (the two E waves run side by side)
         for (int it = role - 1 - kFmNC; it < niter; it += 2) {
             const int b = it & (kFmNB - 1);
             const int L_step = a.step + (it >> 1), L_half = it & 1;

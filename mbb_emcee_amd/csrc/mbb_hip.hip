@@ -52,7 +52,7 @@ MBB_FLOWM_EXT(true, true)
 constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)   // = flowm_lds() of mbb_flowm.hip.h
 {
-    return 4 * sizeof(WalkerK) + 8 * (4 * npart + nb + 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+    return 4 * sizeof(WalkerK) + 8 * (4 * npart + 2 * nb + 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
            8 * (nb + 2) + 8 * (3 * 64) + 64 + 32;
 }
 #include "mbb_host_tables.h"

@@ -1412,6 +1412,71 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
         compare(lambda: _cfg2_like(mbb, g_lnl), 50, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 33, options)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_sampler_configurations_all_forms_equal(mbb, seed):
+    """The device sampler's forms on random configurations -- band subsets from single delta bands to
+    13 bands (more units than quadrature waves, bands sharing chunks, more than 8 bands), random model
+    variant, priors, limits, peak-wavelength terms, diagonal or full covariance, random ensemble size
+    and run lengths, random workgroup width and unit size: every look-ahead form that the size allows
+    gives the chain of the plain launch train bit for bit, stored and unstored runs in sequence."""
+    rng = np.random.RandomState(7000 + seed)
+    pool = ["PACS_70um", "PACS_100um", "PACS_160um", "SPIRE_250um", "SPIRE_350um", "SPIRE_500um",
+            "SCUBA2_450um", "SCUBA2_850um", "Bolocam_1.1mm", "MAMBO2_1.2mm", "GISMO_2mm",
+            "LABOCA_870um", "MIPS_160um", "X_box_850um_60", "ALMA_alma_343", "ALMA_alma_230",
+            "S_gauss_345_10", "D_dsb_300_20_6", "Y_delta_1300um"]
+    nb = int(rng.choice([1, 2, 3, 5, 8, 13]))
+    names = [str(x) for x in rng.choice(pool, nb, replace=(nb > 8))]
+    opthin, noalpha = bool(rng.randint(2)), bool(rng.randint(2))
+    truth = np.array([rng.uniform(10, 30), rng.uniform(1.2, 2.4), rng.uniform(100, 700),
+                      rng.uniform(2.0, 4.5), rng.uniform(10, 80)])
+    nw = int(rng.choice([10, 12, 34, 128, 250, 256, 300]))
+    nsteps = int(rng.choice([3, 11, 40]))
+    opts = {"block_threads": int(rng.choice([0, 0, 512, 768])), "seg_chunks": int(rng.choice([0, 0, 2, 6]))}
+    cov_seed, prior_seed = rng.randint(1 << 30), rng.randint(1 << 30)
+    p0 = truth * (1.0 + 0.02 * rng.normal(size=(nw, 5)))
+    res, forms = [], []
+    for form, fopts in _sampler_forms(None):
+        like = mbb.likelihood(opthin=opthin, noalpha=noalpha, response=True)
+        for o, v in opts.items():
+            if v:
+                like.context.set_option(o, v)
+        like.set_phot(names, np.ones(nb), np.ones(nb))
+        flux = like.model_flux(truth)[0]
+        unc = 0.08 * flux + 0.3
+        like.set_phot(names, flux, unc)
+        r2 = np.random.RandomState(cov_seed)
+        if nb > 1 and r2.rand() < 0.5:
+            A = r2.normal(0, 1, (nb, nb))
+            like.set_cov(np.diag(unc ** 2) + 0.02 * np.median(unc) ** 2 * A.dot(A.T))
+        r3 = np.random.RandomState(prior_seed)
+        for i in range(6):
+            if r3.rand() < 0.3:
+                centre = truth[i] if i < 5 else 200.0
+                like.set_gaussian_prior(i, centre * r3.uniform(0.95, 1.05), abs(centre) * r3.uniform(0.05, 0.3))
+        if r3.rand() < 0.4:
+            like.set_uplim("T", truth[0] * 1.02)
+        if r3.rand() < 0.3:
+            like.set_uplim("lambda_peak", 220.0)
+        if r3.rand() < 0.3:
+            like.set_lowlim("beta", truth[1] * 0.97)
+        for o, v in fopts.items():
+            like.context.set_option(o, v)
+        s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=seed)
+        a = s.run_mcmc(p0, nsteps)
+        b = s.run_mcmc(None, 7, storechain=False)
+        c = s.run_mcmc(None, 2)
+        res.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+        forms.append(like.context.info("last_kernel_form"))
+    for form, r in zip(_sampler_forms(None)[1:], res[1:]):
+        for x, y in zip(res[0], r):
+            assert np.array_equal(x, y, equal_nan=True), (seed, form[0], names, nw, opts)
+    assert forms[0] == 1
+    if nw <= 256:
+        assert forms[3] == 7, forms                         # every (pair, candidate) has a CU
+    elif nw <= 500:
+        assert forms[3] == 5 and forms[2] == 5, forms
+
+
 def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     """The one-launch run needs every workgroup on the GPU at once.  A shape of the working-ahead
     workgroups that does not fit (forced through the options here; too many walkers elsewhere) is

@@ -8,8 +8,15 @@ import mbb_emcee_amd as mbb
 from bench import make_likelihood, TRUTH
 
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-for nw in (256, 254, 130, 64, 18):
+for nw in (256, 254, 130, 64, 18, -250):
     like, flux = make_likelihood(0)
+    if nw < 0:
+        # a covariance matrix: the two accept-test waves of a workgroup each need a scratch row of their own
+        nw = -nw
+        unc = 0.1 * flux + 1.0
+        A = np.random.RandomState(3).normal(size=(8, 8))
+        like.set_cov(np.diag(unc ** 2) + 0.02 * np.median(unc) ** 2 * A.dot(A.T))
+        print("with a covariance matrix:")
     ctx = like._sync_device()
     p0 = np.asarray(TRUTH) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
     res = []
