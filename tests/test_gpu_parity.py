@@ -4,6 +4,7 @@ the reference and with the CPU oracle.  Needs an MI355X: `pytest -m gpu`.
 Tolerances: band flux / f_nu rtol 1e-12, xmerge atol 1e-10,
 lnL |d| <= 1e-10 max(1, |lnL|), -inf must match exactly.
 """
+import os
 import numpy as np
 import pytest
 
@@ -1412,7 +1413,8 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
         compare(lambda: _cfg2_like(mbb, g_lnl), 50, 20, [12.0, 1.8, 600.0, 3.0, 40.0], 33, options)
 
 
-@pytest.mark.parametrize("seed", range(10))
+# (MBB_TEST_RANDOM_SAMPLER_SEEDS=n: more of them, for a one-off sweep)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MBB_TEST_RANDOM_SAMPLER_SEEDS", "10"))))
 def test_random_sampler_configurations_all_forms_equal(mbb, seed):
     """The device sampler's forms on random configurations -- band subsets from single delta bands to
     13 bands (more units than quadrature waves, bands sharing chunks, more than 8 bands), random model
