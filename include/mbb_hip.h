@@ -188,7 +188,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
- * "virtual_ranks", "debug", "persistent_sampler" (1: a single-GPU sampler run of up to one
+ * "virtual_ranks", "debug", "roof_threads" / "roof_wgs_per_cu" (measurement only: the geometry of
+ * mbb_roof_probe), "persistent_sampler" (1: a single-GPU sampler run of up to one
  * walker per CU is ONE launch, its half-steps handing over inside the kernel -- same chains,
  * measured slower than the default 0), "xchg_spin_max" (polls before a launch waiting for a peer
  * gives up); the look-ahead forms of the single-GPU sampler, same chains bit for bit:

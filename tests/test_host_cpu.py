@@ -518,3 +518,14 @@ def test_flowm_protocol_model():
     with pytest.raises(FM.Violation):
         F7.run(ix, lib, n2, 10, random.Random(1), guard=False, partner=avoid0, stall=((0, 0), 4, 20000))
 
+
+def test_every_option_is_documented_in_the_header():
+    """mbb_set_option's names (the strcmp chain in mbb_hip.hip) all appear in include/mbb_hip.h."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "mbb_emcee_amd", "csrc", "mbb_hip.hip")).read()
+    hdr = open(os.path.join(root, "include", "mbb_hip.h")).read()
+    opts = set(re.findall(r'!strcmp\(name, "([a-z_0-9]+)"\)\) c->opt', src))
+    assert len(opts) >= 20
+    assert [o for o in sorted(opts) if '"%s"' % o not in hdr] == []
+
