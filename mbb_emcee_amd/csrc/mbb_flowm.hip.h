@@ -57,6 +57,7 @@
 constexpr int kFmReady = 0;    // [kFmNB] half-step + 1 of the record last handed to Q through buffer b
 constexpr int kFmQDone = 4;    // [kFmNB] Q waves that have finished a unit pass over buffer b, running total
 constexpr int kFmEDone = 8;    // [kFmNB] half-step + 1 of the last record of buffer b E is through with
+constexpr int kFmStaged = 12;  //        Q and E waves that have copied their share of the tables to LDS
 constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: proposal 0..4, (dim-1) ln z,
                                // ln u, the two penalties, the walker's row as it is (9..13)
 // dynamic LDS of a k_flowm launch besides the staged passband tables (bytes)
@@ -127,39 +128,20 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     };
     const int niter = a.persist;
 
-    // ---- set-up, once per launch: tables -> LDS, control words clear --------------------------
-    {
-        const int nt = (int)blockDim.x;
-        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
-        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
-        double2 *lb = reinterpret_cast<double2 *>(s_pb);
-        double2 *lc = reinterpret_cast<double2 *>(s_pc);
-        for (int i = tid; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
-        for (int i = tid; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
-        if (!OPTHIN)
-            for (int i = tid; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
-        for (int b = tid; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
-        if (a.cov_in_lds)
-            for (int i = tid; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
-        if (STAGE) {
-            const int n2 = a.nchunk * 32;
-            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu), *g1 = reinterpret_cast<const double2 *>(a.lnnu),
-                          *g2 = reinterpret_cast<const double2 *>(a.wt);
-            double2 *l0 = reinterpret_cast<double2 *>(s_nu), *l1 = reinterpret_cast<double2 *>(s_lnnu),
-                    *l2 = reinterpret_cast<double2 *>(s_wt);
-            for (int i = tid; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-        }
-        if (tid < 16) ctl[tid] = 0;
-        // the launch's own set-up of the run's state (no kernel before this one): this pair's two
-        // rows as the sampler holds them -> slot 0, with this launch's check words (candidate 0's
-        // workgroup does it); workgroup 0 clears the completion counters of the sampler's NEXT launch
-        if (cand == 0 && tid < 12) {
-            const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
-            fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
-        }
-        if (blockIdx.x == 0 && tid < kFmRing * 16)
-            __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- set-up, once per launch ---------------------------------------------------------------
+    // control words clear; this pair's two rows as the sampler holds them -> slot 0 of the run's state,
+    // with this launch's check words (no kernel before this one; candidate 0's workgroup does it);
+    // workgroup 0 clears the completion counters of the sampler's NEXT launch.  The tables the
+    // quadrature and the band sums need go to LDS from the Q and E waves, behind a counter of their
+    // own: the C waves start on the launch's first proposals meanwhile (a launch's fixed cost is what
+    // a short run is made of: tools/probe_flowm_short.py).
+    if (tid < 16) ctl[tid] = 0;
+    if (cand == 0 && tid < 12) {
+        const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
+        fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
     }
+    if (blockIdx.x == 0 && tid < kFmRing * 16)
+        __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // diagnostic build: cycles a wave spends in each part of its loop, summed over the launch
     // -> stamps[(workgroup * 16 + wave) * 8 + part] (tools/probe_stamps_flowm.py)
@@ -211,6 +193,35 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
+    if (role == 0 || role > kFmNC) {
+        // tables -> LDS: the Q and E waves' threads, numbered through
+        const int ns = nq + 2, si = role == 0 ? qi : nq + (role - 1 - kFmNC);
+        const int t0 = si * 64 + lane, nt = ns * 64;
+        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+        double2 *lb = reinterpret_cast<double2 *>(s_pb);
+        double2 *lc = reinterpret_cast<double2 *>(s_pc);
+        for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+        for (int i = t0; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
+        if (!OPTHIN)
+            for (int i = t0; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
+        for (int bb = t0; bb < nb; bb += nt) { s_flux[bb] = a.flux[bb]; s_ivar[bb] = a.ivar[bb]; s_band[bb] = a.band_rng[bb]; }
+        if (a.cov_in_lds)
+            for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
+        if (STAGE) {
+            const int n2 = a.nchunk * 32;
+            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu), *g1 = reinterpret_cast<const double2 *>(a.lnnu),
+                          *g2 = reinterpret_cast<const double2 *>(a.wt);
+            double2 *l0 = reinterpret_cast<double2 *>(s_nu), *l1 = reinterpret_cast<double2 *>(s_lnnu),
+                    *l2 = reinterpret_cast<double2 *>(s_wt);
+            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        }
+        // every share is in LDS before any of these waves reads a table
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        MBB_FM_ORDER();
+        if (lane == 0) __hip_atomic_fetch_add(ctl + kFmStaged, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_wait(ctl + kFmStaged, ns);
+    }
     // (the chains of C and E are what a half-step waits for: ahead of the Q wave they share a SIMD with)
     if (role != 0) __builtin_amdgcn_s_setprio(3);
     // =========================== Q: the passband quadrature ====================================
