@@ -202,54 +202,39 @@ def emit(obj):
     print(json.dumps(obj), flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 250 000-walker launch")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config objects (cfg1, cfg4)")
+    ap.add_argument("--no-fit", action="store_true", help="skip the end-to-end fit timings")
     ap.add_argument("--no-extras", action="store_true", help="timed region only (profiler passes)")
     ap.add_argument("--exchange", choices=("auto", "rccl", "ipc"), default="auto",
                     help="N > 1: how the moved state rows travel after each launch (auto: the one-hop "
                          "peer-write exchange, RCCL all-gather if that cannot be brought up)")
+    ap.add_argument("--exchange-order", choices=("fastest", "simplest"), default="fastest",
+                    help="N > 1, --exchange auto: which exchange is tried first for the timed run -- the one "
+                         "expected to be fastest (one launch per run across the ranks, then one launch per "
+                         "half-step with peer writes, then RCCL) or the simplest (the reverse).  Whichever is "
+                         "timed, the others are rehearsed afterwards and reported in `exchange_validation`")
+    ap.add_argument("--no-validate", action="store_true",
+                    help="N > 1: do not rehearse the exchanges the timed run did not use")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than devices (rehearsal of the N > 1 path on one GPU; "
                          "needs --exchange ipc; the line is marked invalid for scaling)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    N = args.gpus
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # gloo announces its connections on stdout; the line printed at the end must be the
-        # only thing there
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-    if N != world:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (N, world))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
+def base_line(args, world):
+    """The fields of the line that do not depend on anything measured (no GPU touched)."""
     try:
         metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
     except Exception:
         metric = "walker-likelihood evals/sec (+ MCMC steps/sec), 250 walkers x 8 bands"
-    base = {"metric": metric, "value": None, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+    return {"metric": metric, "value": None, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2/cfg3: 8-band PACS+SPIRE+SCUBA2_850+Bolocam passband integration "
@@ -257,6 +242,159 @@ def main():
                                    "the device-resident stretch move, two dependent half-steps per step",
                        "walkers_per_gpu": NW_PER_GPU, "walkers": NW_PER_GPU * world, "bands": 8,
                        "nq": 2209, "half_steps_per_step": 2}}
+
+
+# ---------------------------------------------------------------------------------------
+# The supervisor.  `python bench.py --gpus N` with N > 1 is started by the driver either
+# bare or under torch.distributed.run.  Either way the process the driver started never
+# touches the GPU: it starts the rank(s) as fresh child processes (the role of emcee's
+# pool, mbb_fit.py:80-81 / run_mbb_emcee.py:166-167), collects what rank 0 prints, and
+# prints ONE line.  A rank that dies while the exchanges the timed run did not use are
+# being rehearsed therefore cannot take the measured line with it.
+# ---------------------------------------------------------------------------------------
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def supervise(args):
+    import subprocess
+    launched = "WORLD_SIZE" in os.environ            # under torch.distributed.run: one rank per supervisor
+    world = int(os.environ.get("WORLD_SIZE", args.gpus))
+    my_rank = int(os.environ.get("RANK", "0"))
+    base = base_line(args, world)
+    if args.gpus != world:
+        if my_rank == 0:
+            emit(dict(base, error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)))
+        return 2
+    if world < 1 or world > 64:
+        emit(dict(base, error="--gpus %d: not a rank count" % args.gpus))
+        return 2
+    ranks = [my_rank] if launched else list(range(world))
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs, lines = {}, []
+    for r in ranks:
+        env = dict(os.environ, MBB_BENCH_WORKER="1", WORLD_SIZE=str(world), RANK=str(r),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+        if not launched:
+            env["LOCAL_RANK"] = str(r)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        try:
+            # rank 0's stdout is collected; the other ranks have nothing to say there
+            procs[r] = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno())
+        except OSError as e:
+            for pr in procs.values():
+                pr.kill()
+            emit(dict(base, error="cannot start rank %d: %r" % (r, e)))
+            return 2
+
+    def collect(pipe):
+        for raw in iter(pipe.readline, b""):
+            lines.append(raw.decode("utf-8", "replace").strip())
+    th = None
+    if 0 in procs:
+        th = threading.Thread(target=collect, args=(procs[0].stdout,), daemon=True)
+        th.start()
+    deadline = time.time() + float(os.environ.get("MBB_BENCH_DEADLINE_S", "1500"))
+    timed_out = False
+    for r, pr in procs.items():
+        try:
+            pr.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            timed_out = True
+    if timed_out:
+        for pr in procs.values():
+            if pr.poll() is None:
+                pr.kill()                  # exactly the processes started above
+        for pr in procs.values():
+            pr.wait()
+    if th is not None:
+        th.join(timeout=10.0)
+    rcs = {r: pr.returncode for r, pr in procs.items()}
+    worst = 0
+    for rc in rcs.values():
+        if rc != 0:
+            worst = max(worst, 128 - rc if rc < 0 else rc)
+    if my_rank != 0:
+        return worst
+    main_line, parts = None, {}
+    for ln in lines:
+        try:
+            obj = json.loads(ln)
+        except ValueError:
+            continue
+        if not isinstance(obj, dict):
+            continue
+        if "_part" in obj:
+            parts[obj["_part"]] = obj.get("data")
+        elif "metric" in obj and main_line is None:
+            main_line = obj
+    if main_line is None:
+        main_line = dict(base, error="rank 0 ended with status %s without a line" % rcs.get(0))
+        worst = worst or 1
+    main_line.update(parts)
+    bad = {str(r): rc for r, rc in rcs.items() if rc != 0}
+    if bad and main_line.get("value") is not None:
+        # the measured line stands; what died afterwards is said beside it
+        main_line["ranks_ended_badly"] = bad
+    if timed_out:
+        main_line["supervisor_timeout"] = True
+    emit(main_line)
+    return worst
+
+
+def main():
+    args = parse_args()
+    if os.environ.get("MBB_BENCH_WORKER") == "1" or (args.gpus == 1 and "WORLD_SIZE" not in os.environ):
+        return worker(args)
+    sys.exit(supervise(args))
+
+
+class Watchdog(Exception):
+    pass
+
+
+def guarded(fn, seconds):
+    """Run fn on a thread and give it `seconds`; a stream that never drains must not hang the bench."""
+    box = {}
+
+    def run():
+        try:
+            box["ret"] = fn()
+        except BaseException as e:          # noqa
+            box["err"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout=seconds)
+    if th.is_alive():
+        raise Watchdog()
+    if "err" in box:
+        raise box["err"]
+    return box.get("ret")
+
+
+EXCHANGE_TEXT = {
+    "none": "none",
+    "ipc": "one-hop peer writes, one launch per run: every decision, moved row and progress word is "
+           "stored into every rank's copy of the run's state as it is made (hipIpc mappings, system "
+           "scope) and a row's half-step starts when the rows it depends on are done, on whatever "
+           "GPU; no collective library",
+    "ipc-launches": "one-hop peer writes: the lane that accepts a move stores the state row (6 f64) "
+                    "into every rank's copy of the ensemble (hipIpc mappings, system scope) and the "
+                    "launch's last walker raises a flag in every peer; no collective library",
+    "rccl": "in-place ncclAllGather of %d state rows x 6 f64 per launch (RCCL via C-ABI)" % (NW_PER_GPU // 2)}
+
+
+def worker(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    base = base_line(args, world)
 
     def fail(code, **kw):
         """A failed run still prints its line (rank 0) and leaves with a non-zero status."""
@@ -267,8 +405,45 @@ def main():
         sys.stdout.flush()
         os._exit(code)          # a wedged stream would also hang interpreter teardown
 
+    try:
+        return worker_body(args, rank, world, local_rank, base, fail)
+    except SystemExit:
+        raise
+    except BaseException as e:              # noqa -- whatever it was, the driver gets a line
+        import traceback
+        traceback.print_exc()
+        fail(1, error="%s: %s" % (type(e).__name__, e))
+
+
+def worker_body(args, rank, world, local_rank, base, fail):
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # gloo announces its connections on stdout; the line printed at the end must be the
+        # only thing there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            import datetime
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=600))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
     from mbb_emcee_amd import _native
-    ndev = max(1, _native.load().mbb_device_count())
+    ndev = _native.load().mbb_device_count()
+    if ndev <= 0:
+        fail(2, error="no ROCm device on this box: the likelihood path has no CPU fall-back",
+             collective="unavailable: no device")
     if world > ndev and not (args.oversubscribe and args.exchange in ("ipc", "auto")):
         fail(2, error="%d ranks on %d device(s): RCCL needs one device per rank" % (world, ndev),
              collective="unavailable: %d ranks on %d device(s)" % (world, ndev), valid_for_scaling=False)
@@ -282,23 +457,33 @@ def main():
     base["config"]["nq"] = nq
     half = NW_PER_GPU // 2
 
-    # ---- N > 1: the exchange of the moved state rows; then one guarded rehearsal of
-    # exactly what the timed loop does.  "auto" tries the one-hop peer-write exchange and
-    # falls back to the RCCL all-gather if it cannot be set up or its rehearsal fails on
-    # any rank.  A collective that never returns is a failure of the run, not something to
-    # time around: the line says so and the exit status is non-zero.
+    # ---- N > 1: the exchange of the moved state rows.  Every exchange is trusted only after a
+    # guarded rehearsal of exactly what the timed loop does (60 steps, then every rank's copy of
+    # the ensemble and the unsharded sampler's state must have the same CRC).  The first exchange of
+    # the order that passes carries the timed run; the others are rehearsed and timed afterwards,
+    # outside `value`, so that one run on a multi-GPU node says which of the three protocols survive
+    # xGMI (`exchange_validation`).  A collective that never returns is a failure of the run, not
+    # something to time around: the line says so and the exit status is non-zero.
     import mbb_emcee_amd as mbb
     allw = walkers(world)
     nwt = NW_PER_GPU * world
-    # "ipc": the one-hop exchange, first as ONE launch per run on every rank (k_lnlike SMODE 6:
-    # decisions, rows and words stored into every rank's copy as they are made), then, should that
-    # not come up or not agree, as one launch per half-step with the rows exchanged after it
-    modes = {"auto": ["ipc", "ipc-launches", "rccl"], "ipc": ["ipc", "ipc-launches"], "rccl": ["rccl"]}[args.exchange]
-    if world > ndev and not os.environ.get("MBB_BENCH_TRY_ONE_LAUNCH"):
-        modes = ["ipc-launches"]        # (ranks sharing a device: their kernels cannot all be resident)
+    # "ipc": the one-hop exchange as ONE launch per run on every rank (k_lnlike SMODE 6: decisions, rows
+    # and words stored into every rank's copy as they are made); "ipc-launches": one launch per half-step
+    # with the rows exchanged after it; "rccl": one launch per half-step and an in-place ncclAllGather
+    all_modes = ["ipc", "ipc-launches", "rccl"]
+    modes = {"auto": list(all_modes), "ipc": ["ipc", "ipc-launches"], "rccl": ["rccl"]}[args.exchange]
+    if args.exchange_order == "simplest":
+        modes.reverse()
+    skipped = {}
+    if world > ndev:
+        # (ranks sharing a device: no RCCL, and their one-launch kernels cannot all be resident)
+        skipped["rccl"] = "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev)
+        modes = [m for m in modes if m != "rccl"]
+        if not os.environ.get("MBB_BENCH_TRY_ONE_LAUNCH"):
+            skipped["ipc"] = "skipped: ranks sharing a device cannot all keep a one-launch run resident"
+            modes = [m for m in modes if m != "ipc"]
     if world == 1:
         modes = ["none"]
-    collective, tried, smp = "none", [], None
 
     def all_ok(ok):
         if dist is None:
@@ -308,7 +493,47 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag[0]) == 1
 
-    for mode in modes:
+    def ranks_agree_on(crc):
+        """every rank must hold the same ensemble, bit for bit"""
+        if dist is None:
+            return True
+        import torch
+        lo = torch.tensor([float(crc)], dtype=torch.float64)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool(lo[0] == hi[0])
+
+    ref_crc = {}
+
+    def unsharded_crc():
+        """rank 0 runs the same 60 steps of the whole ensemble by itself: a walker's result does not depend
+        on the launch that evaluates it, so a sharded run must agree with it bit for bit"""
+        if "crc" not in ref_crc:
+            like_ref, _ = make_likelihood(local_rank % ndev)
+            sref = mbb.DeviceEnsembleSampler(nwt, 5, like_ref, seed=11)
+            pr, lr, _ = sref.run_mcmc(allw[:nwt], 60, storechain=False)
+            ref_crc["crc"] = ensemble_crc(pr, lr)
+            del sref, like_ref
+        return ref_crc["crc"]
+
+    class Hung(Exception):
+        pass
+
+    def run_mode(mode, steps, warmup):
+        """Set the exchange up, rehearse it, time `steps` dependent MCMC steps.  Returns a dict with `ok`;
+        when ok the sampler is still alive in it (the caller tears it down)."""
+        res = {"ok": False, "why": "", "smp": None}
+
+        def teardown():
+            res["smp"] = None                      # (the sampler lives in the exchange buffer: it goes first)
+            import gc
+            gc.collect()
+            try:
+                ctx.sync()
+                ctx.xchg_close() if mode.startswith("ipc") else (ctx.comm_destroy() if mode == "rccl" else None)
+            except Exception:
+                pass
+        res["teardown"] = teardown
         ok, why = True, ""
         try:
             if mode in ("ipc", "ipc-launches"):
@@ -316,29 +541,21 @@ def main():
                 parallel.ipc_exchange_setup(ctx, rank, world, dist, max_rows=max(4096, nwt))
                 ctx.set_option("sharded_flow_sampler", 1 if mode == "ipc" else 0)
                 ctx.set_option("flow_spin_log2", 20)      # (a run that cannot proceed gives up within seconds)
-                collective = ("one-hop peer writes, one launch per run: every decision, moved row and progress word is "
-                              "stored into every rank's copy of the run's state as it is made (hipIpc mappings, system "
-                              "scope) and a row's half-step starts when the rows it depends on are done, on whatever "
-                              "GPU; no collective library" if mode == "ipc" else
-                              "one-hop peer writes: the lane that accepts a move stores the state row (6 f64) "
-                              "into every rank's copy of the ensemble (hipIpc mappings, system scope) and the "
-                              "launch's last walker raises a flag in every peer; no collective library")
             elif mode == "rccl":
                 uid = [ctx.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
-                ctx.comm_init(world, rank, uid[0])
-                collective = "in-place ncclAllGather of %d state rows x 6 f64 per launch (RCCL via C-ABI)" % half
+                guarded(lambda: ctx.comm_init(world, rank, uid[0]), 120.0)
+        except Watchdog:
+            raise Hung("%s: ncclCommInitRank did not return within 120 s" % mode)
         except Exception as e:
             ok, why = False, "set-up: " + repr(e)
         if not all_ok(ok):
-            tried.append("%s %s" % (mode, why or "set-up failed on another rank"))
-            try:
-                ctx.xchg_close() if mode.startswith("ipc") else ctx.comm_destroy()
-            except Exception:
-                pass
-            continue
+            res["why"] = why or "set-up failed on another rank"
+            teardown()
+            return res
         smp = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=11)
-        state = {"ok": False, "err": None}
+        res["smp"] = smp
+        state = {"ok": False, "err": None, "crc": rank}
 
         def rehearse():
             try:
@@ -348,75 +565,54 @@ def main():
                 state["ok"] = bool(np.all(np.isfinite(lnp_r)))
             except Exception as e:           # noqa
                 state["err"] = repr(e)
-
-        th = threading.Thread(target=rehearse, daemon=True)
-        th.start()
-        th.join(timeout=120.0)
-        if th.is_alive():
-            fail(4, error="the exchange did not return within 120 s", collective_hung=True, hang=collective)
-        def ranks_agree_on(crc):
-            """every rank must hold the same ensemble, bit for bit"""
-            if dist is None:
-                return True
-            import torch
-            lo = torch.tensor([float(crc)], dtype=torch.float64)
-            hi = lo.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            return bool(lo[0] == hi[0])
-
-        def teardown():
-            nonlocal smp
-            smp = None                      # (the sampler lives in the exchange buffer: it goes first)
-            import gc
-            gc.collect()
-            try:
-                ctx.sync()
-                ctx.xchg_close() if mode.startswith("ipc") else (ctx.comm_destroy() if mode == "rccl" else None)
-            except Exception:
-                pass
-
+        try:
+            guarded(rehearse, 120.0)
+        except Watchdog:
+            raise Hung("%s: the rehearsal did not return within 120 s" % mode)
         if not all_ok(state["ok"]):
-            tried.append("%s rehearsal: %s" % (mode, state["err"] or "failed on another rank"))
-            smp = None
+            res["why"] = "rehearsal: %s" % (state["err"] or "failed on another rank")
             teardown()
-            continue
+            return res
         if not ranks_agree_on(state["crc"]):
-            tried.append("%s rehearsal: the ranks' copies of the ensemble differ after 60 steps" % mode)
-            smp = None
+            res["why"] = "rehearsal: the ranks' copies of the ensemble differ after 60 steps"
             teardown()
-            continue
+            return res
         if world > 1:
-            # ... and it is the chain of the UNSHARDED sampler: rank 0 runs the same 60 steps of the whole
-            # ensemble by itself (a walker's result does not depend on the launch that evaluates it, so the
-            # two must agree bit for bit); an exchange that is consistently wrong on every rank ends here
+            # ... and it is the chain of the UNSHARDED sampler; an exchange that is consistently wrong
+            # on every rank ends here
             ok_ref = True
             if rank == 0:
                 try:
-                    like_ref, _ = make_likelihood(local_rank % ndev)
-                    sref = mbb.DeviceEnsembleSampler(nwt, 5, like_ref, seed=11)
-                    pr, lr, _ = sref.run_mcmc(allw[:nwt], 60, storechain=False)
-                    ok_ref = ensemble_crc(pr, lr) == state["crc"]
-                    del sref, like_ref
+                    ok_ref = unsharded_crc() == state["crc"]
                 except Exception as e:       # noqa
                     ok_ref, state["err"] = False, repr(e)
             if not all_ok(ok_ref):
-                tried.append("%s rehearsal: differs from the unsharded sampler's chain after 60 steps" % mode)
-                smp = None
+                res["why"] = "rehearsal: differs from the unsharded sampler's chain after 60 steps"
                 teardown()
-                continue
-            base["config"]["rehearsal"] = "60 steps: every rank's copy and the unsharded sampler's state have the same CRC"
+                return res
+            res["rehearsal"] = "60 steps: every rank's copy and the unsharded sampler's state have the same CRC"
 
         # ---- the timed region: K dependent MCMC steps ----------------------------
-        smp.advance_async(args.warmup)
-        ctx.sync(); barrier()
-        e0, e1 = ctx.event(), ctx.event()
-        t0 = time.perf_counter()
-        ctx.record(e0)
-        smp.advance_async(args.steps)
-        ctx.record(e1)
-        ctx.sync(); barrier()
-        elapsed = time.perf_counter() - t0
-        stream_ms = ctx.elapsed_ms(e0, e1)
+        def timed():
+            smp.advance_async(warmup)
+            ctx.sync(); barrier()
+            e0, e1 = ctx.event(), ctx.event()
+            t0 = time.perf_counter()
+            ctx.record(e0)
+            smp.advance_async(steps)
+            ctx.record(e1)
+            ctx.sync(); barrier()
+            return time.perf_counter() - t0, ctx.elapsed_ms(e0, e1)
+        try:
+            elapsed, stream_ms = guarded(timed, 300.0)
+        except Watchdog:
+            raise Hung("%s: the timed run did not return within 300 s" % mode)
+        except Exception as e:               # noqa
+            elapsed, stream_ms, state["err"] = None, None, repr(e)
+        if not all_ok(elapsed is not None):
+            res["why"] = "timed run: %s" % (state["err"] or "failed on another rank")
+            teardown()
+            return res
         if dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64)
@@ -429,24 +625,44 @@ def main():
             crc = ensemble_crc(pos_end, lnp_end)
         except Exception as e:
             fine, crc, state["err"] = False, rank, repr(e)
-        if all_ok(fine) and ranks_agree_on(crc):
+        if not (all_ok(fine) and ranks_agree_on(crc)):
+            # a number measured on an exchange that lost or mixed up rows is not a number
+            res["why"] = "timed run: %s" % ("the ranks' copies of the ensemble differ afterwards"
+                                            if fine else (state["err"] or "non-finite state"))
+            teardown()
+            return res
+        res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, form=ctx.info("last_kernel_form"),
+                   us_per_step=1e6 * elapsed / steps)
+        return res
+
+    tried, validation, run = [], dict(skipped), None
+    mode = None
+    for mode in modes:
+        try:
+            r = run_mode(mode, args.steps, args.warmup)
+        except Hung as e:
+            fail(4, error=str(e), collective_hung=True, hang=EXCHANGE_TEXT[mode],
+                 collective_fallback_from=tried)
+        if r["ok"]:
+            run = r
             break
-        # a number measured on an exchange that lost or mixed up rows is not a number
-        tried.append("%s timed run: %s" % (mode, "the ranks' copies of the ensemble differ afterwards"
-                                                 if fine else (state["err"] or "non-finite state")))
-        smp = None
-        teardown()
-    if smp is None:
+        tried.append("%s %s" % (mode, r["why"]))
+        validation[mode] = {"ok": False, "why": r["why"]}
+    if run is None:
         fail(3, error="no exchange gave a valid run: " + "; ".join(tried),
-             collective="unavailable: " + "; ".join(tried))
+             collective="unavailable: " + "; ".join(tried), exchange_validation=validation or None)
+    smp, elapsed, stream_ms = run["smp"], run["elapsed"], run["stream_ms"]
     mode_used = mode
-    ranks_agree = True
-    base["config"]["collective"] = collective
+    base["config"]["collective"] = EXCHANGE_TEXT[mode_used]
+    if "rehearsal" in run:
+        base["config"]["rehearsal"] = run["rehearsal"]
     if tried:
         base["config"]["collective_fallback_from"] = tried
     if world > ndev:
         base["valid_for_scaling"] = False
         base["config"]["note"] = "%d ranks share %d device(s): a rehearsal of the exchange, not a scaling point" % (world, ndev)
+    validation[mode_used] = {"ok": True, "us_per_step": run["us_per_step"], "steps": args.steps,
+                             "kernel_form": run["form"], "why": "carried the timed run"}
 
     if rank == 0:
         out = dict(base)
@@ -455,9 +671,9 @@ def main():
                     "stream_us_per_step": stream_ms * 1e3 / args.steps,
                     # (sharded: the counts of this rank's own walkers)
                     "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps),
-                    "ranks_agree": ranks_agree})
+                    "ranks_agree": True})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
-        form = ctx.info("last_kernel_form")
+        form = run["form"]
         out["config"] = dict(out["config"])
         if form in (5, 6, 7):
             nlaunch = (args.steps + 4095) // 4096
@@ -488,17 +704,49 @@ def main():
                                "launch_slot_us": k_us,
                                "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                                        "achieved_GBps": alg_bytes / (k_us * 1e-6) / 1e9, "peak_GBps": HBM_PEAK_GBS}}
-        emit(out)
+        emit(out)               # (N > 1: held by the supervisor until this process has ended)
     barrier()
+    smp = None
+    run["smp"] = None
     if world > 1:
-        ctx.sync()
-        smp = None
-        import gc
-        gc.collect()
-        if mode_used == "rccl":
-            ctx.comm_destroy()
-        elif mode_used.startswith("ipc"):
-            ctx.xchg_close()
+        run["teardown"]()
+        # ---- the exchanges the timed run did not use: the same rehearsal and a short timed run each,
+        # outside `value`.  The measured line is already with the supervisor; whatever happens here
+        # only adds to it.
+        if not args.no_validate:
+            vsteps = max(50, min(args.steps, 500))
+            hung = None
+            for m in all_modes:
+                if m in validation:
+                    continue
+                if m not in modes and args.exchange != "auto":
+                    validation[m] = {"ok": None, "why": "not asked for (--exchange %s)" % args.exchange}
+                    continue
+                try:
+                    r = run_mode(m, vsteps, 50)
+                except Hung as e:
+                    validation[m] = {"ok": False, "why": str(e), "hung": True}
+                    hung = m
+                    break
+                except Exception as e:           # noqa
+                    validation[m] = {"ok": False, "why": repr(e)}
+                    continue
+                if r["ok"]:
+                    validation[m] = {"ok": True, "us_per_step": r["us_per_step"], "steps": vsteps,
+                                     "kernel_form": r["form"],
+                                     "why": "rehearsal and a timed run of %d steps after the measured one" % vsteps}
+                    r["smp"] = None
+                    r["teardown"]()
+                else:
+                    validation[m] = {"ok": False, "why": r["why"]}
+            if rank == 0:
+                emit({"_part": "exchange_validation", "data": validation})
+            if hung is not None:
+                sys.stdout.flush()
+                os._exit(0)             # the measured run was valid; a wedged stream would hang teardown
+        elif rank == 0:
+            emit({"_part": "exchange_validation", "data": validation})
+        barrier()
         dist.destroy_process_group()
 
 

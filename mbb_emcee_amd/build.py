@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "mbb_host_tables.cpp")      # host-only table builders
 SRC_FLOW = os.path.join(HERE, "csrc", "mbb_flow.hip")             # the one-launch sampler kernel, own flags
+DEVICE_FLAGS = []        # flags of both device translation units
 FLOW_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
 DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
@@ -35,37 +36,50 @@ def hipcc():
     raise RuntimeError("hipcc not found; cannot build the MI355X likelihood library")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=None):
+    lib = lib or LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
 def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
-    if not force and not needs_build():
-        return LIB
-    # three objects (the two device translation units in parallel), then one link
-    common = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + list(extra_flags)
-    if verbose:
-        common.append("-Rpass-analysis=kernel-resource-usage")
+    """Builds `out` (default: the in-tree library) when it is missing or older than a source and
+    returns its path.  Processes that import at the same time (the ranks of a sharded test) take a
+    file lock, compile into an object directory of their own tag, and the finished library replaces
+    the old one in one rename, so nobody ever maps a half-written file."""
+    import fcntl
+    target = out or LIB
+    if not force and not needs_build(target):
+        return target
     objdir = os.path.join(HERE, "csrc", "_obj" + obj_tag)
     os.makedirs(objdir, exist_ok=True)
-    jobs = [(SRC, os.path.join(objdir, "mbb_hip.o"), []),
-            (SRC_FLOW, os.path.join(objdir, "mbb_flow.o"), FLOW_FLAGS),
-            (SRC_HOST, os.path.join(objdir, "mbb_host_tables.o"), [])]
-    procs = []
-    for src, obj, flags in jobs:
-        cmd = common + flags + ["-c", src, "-o", obj]
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build(target):       # another process built it while we waited
+            return target
+        # three objects (the two device translation units in parallel), then one link
+        common = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + DEVICE_FLAGS + list(extra_flags)
         if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", out or LIB] +
-                          [obj for _, obj, _ in jobs] + ["-ldl"])
-    return LIB
+            common.append("-Rpass-analysis=kernel-resource-usage")
+        jobs = [(SRC, os.path.join(objdir, "mbb_hip.o"), []),
+                (SRC_FLOW, os.path.join(objdir, "mbb_flow.o"), FLOW_FLAGS),
+                (SRC_HOST, os.path.join(objdir, "mbb_host_tables.o"), [])]
+        procs = []
+        for src, obj, flags in jobs:
+            cmd = common + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        tmp = "%s.tmp.%d" % (target, os.getpid())
+        subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] +
+                              [obj for _, obj, _ in jobs] + ["-ldl"])
+        os.replace(tmp, target)
+    return target
 
 
 if __name__ == "__main__":

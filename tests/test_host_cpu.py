@@ -205,6 +205,41 @@ def test_no_gpu_fails_loudly():
         like(np.array([10.0, 2.0, 600.0, 3.0, 40.0]))
 
 
+def _run_bench(argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MBB_BENCH_WORKER")}
+    env.update(env_extra or {})
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = [ln for ln in pr.stdout.decode().splitlines() if ln.strip()]
+    return pr.returncode, out
+
+
+@pytest.mark.parametrize("argv", [["--gpus", "2"], ["--gpus", "2", "--oversubscribe"], ["--gpus", "1"]])
+def test_bench_starts_its_own_ranks_and_always_prints_one_line(argv):
+    """`python bench.py --gpus N` as the driver runs it, without a launcher: the ranks are started as
+    child processes (the role of emcee's pool, reference mbb_fit.py:80-81).  Without a GPU the run
+    fails -- with exactly one JSON line on stdout and a non-zero status, never a bare traceback."""
+    import json
+    from mbb_emcee_amd import _native
+    if _native.load().mbb_device_count() > 0:
+        pytest.skip("a GPU is present: the GPU suite runs the real thing")
+    rc, out = _run_bench(argv + ["--steps", "3", "--warmup", "1"])
+    assert rc != 0
+    assert len(out) == 1, out
+    line = json.loads(out[0])
+    assert line["value"] is None and line["n_gpus"] == int(argv[1]) and "error" in line
+    assert line["metric"].startswith("walker-likelihood")
+
+
+def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
+    import json
+    rc, out = _run_bench(["--gpus", "3"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                           "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert rc == 2 and len(out) == 1
+    assert "WORLD_SIZE=2" in json.loads(out[0])["error"]
+
+
 def test_c_abi_exports_every_declared_symbol():
     """Every function declared in include/mbb_hip.h is exported by the in-tree
     library and bound with a signature in _native.SIGNATURES."""
