@@ -477,10 +477,10 @@ def worker_body(args, rank, world, local_rank, base, fail):
     skipped = {}
     if world > ndev:
         # (ranks sharing a device: no RCCL, and their one-launch kernels cannot all be resident)
-        skipped["rccl"] = "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev)
+        skipped["rccl"] = {"ok": None, "why": "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev)}
         modes = [m for m in modes if m != "rccl"]
         if not os.environ.get("MBB_BENCH_TRY_ONE_LAUNCH"):
-            skipped["ipc"] = "skipped: ranks sharing a device cannot all keep a one-launch run resident"
+            skipped["ipc"] = {"ok": None, "why": "skipped: ranks sharing a device cannot all keep a one-launch run resident"}
             modes = [m for m in modes if m != "ipc"]
     if world == 1:
         modes = ["none"]
@@ -810,7 +810,6 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     # first half of round 2 timed), and with the look-ahead as extra workgroups of each launch
     forms = {}
     for name, opts in (("one_launch_per_half_step", {"lookahead_sampler": 0}),
-                       ("one_launch_per_half_step_with_lookahead", {"lookahead_sampler": 1, "flow_sampler": 0}),
                        ("one_launch_per_run_proposals_ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0})):
         for o, v in opts.items():
             ctx.set_option(o, v)

@@ -189,13 +189,13 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug", "roof_threads" / "roof_wgs_per_cu" (measurement only: the geometry of
- * mbb_roof_probe), "persistent_sampler" (1: a single-GPU sampler run of up to one
- * walker per CU is ONE launch, its half-steps handing over inside the kernel -- same chains,
- * measured slower than the default 0), "xchg_spin_max" (polls before a launch waiting for a peer
- * gives up); the look-ahead forms of the single-GPU sampler, same chains bit for bit:
+ * mbb_roof_probe), "xchg_spin_max" (polls before a launch waiting for a peer
+ * gives up); the forms of the single-GPU sampler, same chains bit for bit:
  * "lookahead_sampler" (default 1; 0: the plain train of one launch per half-step),
- * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row;
- * 0: the next half-step's proposals prepared by extra workgroups of every launch),
+ * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row, the
+ * proposals prepared ahead of the decisions they depend on; 0: the plain train as well),
+ * "flow_min_steps" (runs shorter than this take the plain train: a one-launch run costs ~14 us
+ * beside its steps; default from profiles/r03/flowm_short_runs.txt),
  * "merged_flow_sampler" (default 1: in that one launch the passband quadrature of both proposals a
  * walker can end up making, and the SED constructor for every outcome still open, run ahead of the
  * decisions they depend on -- one workgroup per pair of walkers and candidate, ensembles up to two
@@ -205,7 +205,11 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),
  * "flow_spin_log2" (0 = 22: log2 of the polls before a wait
  * inside the one-launch run gives up; mbb_sampler_run then redoes the run as a launch train and
- * counts it in mbb_get_info "flow_fallbacks").  mbb_get_info "last_kernel_form" says which form ran. */
+ * counts it in mbb_get_info "flow_fallbacks"; the next run takes the one-launch form again, and only
+ * three give-ups in a row rest it for the next 16 runs -- mbb_get_info "flow_resting" says how many of
+ * those are left.  mbb_sampler_advance_async keeps nothing to redo a run from: there a give-up surfaces
+ * at the next mbb_sampler_run as MBB_ERR_STATE and the sampler wants mbb_sampler_set_state again).
+ * mbb_get_info "last_kernel_form" says which form ran. */
 int mbb_set_option(mbb_ctx *ctx, const char *name, long value);
 int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 

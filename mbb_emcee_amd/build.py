@@ -14,7 +14,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "mbb_host_tables.cpp")      # host-only table builders
 SRC_FLOW = os.path.join(HERE, "csrc", "mbb_flow.hip")             # the one-launch sampler kernel, own flags
-DEVICE_FLAGS = []        # flags of both device translation units
+# Both device translation units: no contraction of a product and a sum the source keeps apart.  The
+# sampler forms (k_lnlike SMODE 1/2/5/6, k_flowm) are held to one another bit for bit, and the shared
+# arithmetic is inlined into each of them: with the compiler free to contract, whether a given a*b+c
+# rounds once or twice depends on the code around it.  Every intended fused multiply-add is an explicit
+# fma() in the source (tools/fma_audit.py lists the kernels whose fp64 fma/mul/add counts differ between
+# the two settings: none in the sample loop; profiles/r03/fma_audit.txt).
+DEVICE_FLAGS = ["-ffp-contract=off"]
 FLOW_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
 DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),

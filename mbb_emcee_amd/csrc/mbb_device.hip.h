@@ -159,10 +159,10 @@ __device__ __forceinline__ void vlog(double (&out)[K], A... arg)
 __device__ __forceinline__ void h_and_dh(double y, double E, double &h, double &dh)
 {
     const double rE = m_div(1.0, E);
-    const double hh = y * rE, dd = (1.0 - hh - y) * rE;
+    const double hh = y * rE, dd = (fma(-y, rE, 1.0) - y) * rE;
     const bool tiny = y < 1e-4, big = !(y < 700.0);
-    h = big ? 0.0 : (tiny ? 1.0 - 0.5 * y + y * y * (1.0 / 12.0) : hh);
-    dh = big ? 0.0 : (tiny ? -0.5 + y * (1.0 / 6.0) : dd);
+    h = big ? 0.0 : (tiny ? fma(y * y, 1.0 / 12.0, fma(-0.5, y, 1.0)) : hh);
+    dh = big ? 0.0 : (tiny ? fma(y, 1.0 / 6.0, -0.5) : dd);
 }
 
 // Root of alpha_merge_eqn (modified_blackbody.py:122-151)
@@ -285,9 +285,12 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
         double h, dh;
         h_and_dh(y, E, h, dh);
         const double om = 1.0 - em;
-        const double A = 3.0 + alpha + beta * h;
-        const double g = x - om * A;
-        const double dg = x * (1.0 - em * A) - om * beta * beta * dh * y;
+        // (every fused multiply-add is written out: the library is built with -ffp-contract=off, so
+        // that this arithmetic rounds the same wherever it is inlined -- the sampler forms are held
+        // to one another bit for bit)
+        const double A = fma(beta, h, 3.0 + alpha);
+        const double g = fma(-om, A, x);
+        const double dg = fma(x, fma(-em, A, 1.0), -(om * beta * beta * dh * y));
         if (iters) *iters = it + 1;
         if (g == 0.0) { xroot = x; yroot = y; status = ROW_OK; if (PB && kappa && it == 0) *kappa = k0; break; }
         if (g < 0.0) ulo = u; else uhi = u;
@@ -295,15 +298,15 @@ __device__ inline double thick_merge_root(double alpha, double beta, double lx0,
         if (fabs(step) <= 1e-6) {
             // x e^step and y e^(beta step) to third order: exact to 1e-24
             u += step;
-            xroot = x * (1.0 + step * (1.0 + step * (0.5 + step * (1.0 / 6.0))));
+            xroot = x * fma(step, fma(step, fma(step, 1.0 / 6.0, 0.5), 1.0), 1.0);
             const double bs = beta * step;
-            yroot = y * (1.0 + bs * (1.0 + bs * (0.5 + bs * (1.0 / 6.0))));
+            yroot = y * fma(bs, fma(bs, fma(bs, 1.0 / 6.0, 0.5), 1.0), 1.0);
             status = ROW_OK;
             // kappa is stationary at the root: d ln kappa / du = s(u) = A - x/(1 - e^-x) =
             // -g/(1 - e^-x), zero there (it IS the merge condition), so over the step
             // ln kappa changes by s step + s' step^2/2 = s step/2 (s = -s' step to first
             // order): kappa(root) = kappa(u) (1 + s step / 2), error O(step^3) < 1e-18
-            if (PB && kappa && it == 0) *kappa = k0 * (1.0 - 0.5 * step * m_div(g, om));
+            if (PB && kappa && it == 0) *kappa = k0 * fma(-0.5 * step, m_div(g, om), 1.0);
             break;
         }
         double un = u + step;
@@ -334,7 +337,7 @@ __device__ inline double thin_fixed_point(double a)
     double x = (xf > 0.0f && xf <= af) ? (double)xf : a;
     for (int it = 0; it < 60; ++it) {
         const double e = m_exp(-x);
-        const double F = x - a * (1.0 - e), dF = 1.0 - a * e;
+        const double F = fma(-a, 1.0 - e, x), dF = fma(-a, e, 1.0);
         const double step = m_div(-F, dF);
         x += step;
         if (fabs(step) <= 1e-8 * fabs(x)) break;       // quadratic: next error < 1 ulp

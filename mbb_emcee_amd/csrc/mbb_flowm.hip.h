@@ -333,9 +333,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 if (st == ROW_OK) {
                     const double *pj2 = partial + (size_t)b * npart;
                     auto band = [&](const int bb) {                    // band flux, fixed order (k_lnlike, phase 3)
-                        // (no contraction: there the product and the difference are separate roundings --
-                        // the model flux is also an output of that kernel -- and the chain must be the same bits)
-#pragma clang fp contract(off)
+                        // (the product and the difference are separate roundings, as there: the library is
+                        // built with -ffp-contract=off and every fused multiply-add is an explicit fma())
                         double sum = 0.0;
                         const int2 rng = s_band[bb];
                         for (int sg = rng.x; sg < rng.y; sg += 4) {
@@ -430,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
                 else if (st != ROW_OK) r = __builtin_nan("");
                 else {
-                    r = fma(-0.5, acc, pen_u);                     // :828 (one rounding there too)
+                    r = fma(-0.5, acc, pen_u);                     // :828
                     if (a.has_gprior) r += pen_g;                  // :830-831
                 }
                 if (mine) {

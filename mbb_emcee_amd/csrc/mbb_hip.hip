@@ -158,7 +158,6 @@ struct mbb_ctx {
     long opt_wpb = 0, opt_threads = 0, opt_seg_chunks = 4, opt_debug = 0;
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
-    long opt_persist = 0;     // 1: single-GPU sampler runs are ONE launch (measured slower: see k_lnlike, SMODE 3)
     long opt_roof_wgs = 0, opt_roof_threads = 0;   // measurement: geometry of mbb_roof_probe
     long opt_vranks = 0;      // testing: run a sampler as this many shards on one GPU
     long opt_bar_params = 1;  // host path: write the parameter rows into device memory through the BAR
@@ -168,10 +167,15 @@ struct mbb_ctx {
     long opt_spin = 2;        // 0 block on the stream; 1 poll hipStreamQuery (measured: no gain);
                               // 2 watch the result slots in pinned memory (zero-copy batches <= 8192 rows)
     long last_stage = 0;
-    long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals one launch ahead (SMODE 4)
+    long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals ahead of the decisions they depend on
     unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
     long opt_flow_spin_log2 = 0;   // one-launch run: log2 of the polls before a wait gives up (0: the kernel's 22)
     long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
+    // A give-up is a property of the moment (a co-tenant holding CUs), not of the context: the next run
+    // takes the one-launch form again.  Only kFlowStrikes give-ups in a row rest it, for kFlowRest runs.
+    long flow_strikes = 0, flow_rest = 0;
+    long opt_flow_min_steps = 2;   // runs shorter than this take the launch train (a one-launch run costs
+                                   // ~14 us beside its steps: 16.9 us for one step against 15.7)
     long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
@@ -500,14 +504,13 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
 }
 
 // Look-ahead sampler runs: how the workgroups that work ahead are shaped.  One row of 16 lanes
-// per candidate proposal -- 2 per walker of a half (k_lnlike SMODE 4), 4 in a one-launch run,
-// where a row keeps to one half (SMODE 5) -- `rows` of them per wave, `aw` such waves per
+// per candidate proposal -- 4 per walker of a half: a row keeps to one half (SMODE 5, 6) --
+// `rows` of them per wave, `aw` such waves per
 // workgroup.  A constructor is one dependent chain and a wave alone on its SIMD runs it fastest,
 // so the candidates are spread as thinly as the CUs the movers leave free allow.
-static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, bool one_launch, int &rows, int &aw,
-                           int &n_ahead)
+static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, int &rows, int &aw, int &n_ahead)
 {
-    const int pairs = (one_launch ? 4 : 2) * half, free_cus = c->cu_count - movers;
+    const int pairs = 4 * half, free_cus = c->cu_count - movers;
     static const int plan[5][2] = {{1, 4}, {2, 4}, {4, 4}, {4, 8}, {4, 16}};
     rows = 1; aw = 4;
     for (int i = 0; i < 5; ++i) {
@@ -519,6 +522,7 @@ static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, 
     n_ahead = (pairs + rows * aw - 1) / (rows * aw);
 }
 
+constexpr long kFlowStrikes = 3, kFlowRest = 16;
 static std::atomic<unsigned long long> g_flow_serial{0};   // one-launch sampler runs started in this process (their check words)
 
 struct SamplerLaunch {
@@ -529,11 +533,8 @@ struct SamplerLaunch {
     double stretch_a;
     unsigned long long seed;
     unsigned long long xseq;      // > 0: one-hop exchange, number of this launch
-    int persist;                  // > 0: this many half-steps in one launch (k_lnlike SMODE 3)
-    unsigned int *gbar;           // its arrival counters
-    double *spec;                 // != nullptr: look-ahead run (k_lnlike SMODE 4), records + state
-    int spec_cfg;                 // LikeArgs::spec_cfg
-    bool spec_first;              // the run's first launch: nobody moves
+    int persist;                  // > 0: this many half-steps in one launch (SMODE 5, 6, form 7)
+    double *spec;                 // != nullptr: the one-launch run's device state
     bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
     bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
     unsigned long long serial = 0;   // ... the number of its launch (in its check words and decision words)
@@ -548,7 +549,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (n <= 0) return MBB_OK;
     LikeArgs a;
     a.xargs = nullptr;
-    a.persist = 0; a.gbar = nullptr;
+    a.persist = 0; a.spec = nullptr;
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
     a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
     a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
@@ -648,23 +649,22 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
         a.nw_src = sl->nw_src;
         if (sl->xseq) a.xargs = c->x.d_args;
-        a.persist = sl->persist; a.gbar = sl->gbar;
+        a.persist = sl->persist;
         if (sl->spec) {
             a.xargs = nullptr;
-            if (sl->persist) a.flow_serial = c->flow_serial = ++g_flow_serial;
+            a.flow_serial = c->flow_serial = ++g_flow_serial;
             // first the workgroups that prepare the next half-step -- one row of 16 lanes per
             // (walker, candidate), `rows` of them per wave, `aw` such waves per workgroup -- then
             // the movers.  A constructor is one dependent chain: a wave alone on its SIMD runs it
             // fastest, so the candidates are spread as thinly as the CUs the movers leave free allow.
             int rows, aw, n_ahead;
-            lookahead_plan(c, grid, threads, sl->persist > 0 ? sl->m_count : sl->c_count, sl->persist > 0, rows, aw, n_ahead);
+            lookahead_plan(c, grid, threads, sl->m_count, rows, aw, n_ahead);
             a.spec = sl->spec;
-            a.spec_cfg = sl->spec_cfg | (rows << 8) | (aw << 16) |
-                         (sl->persist ? (int)((c->opt_flow_spin_log2 & 0x3f) << 24) : 0);
+            a.spec_cfg = (rows << 8) | (aw << 16) | (int)((c->opt_flow_spin_log2 & 0x3f) << 24);
             a.n_ahead = n_ahead;
-            if (sl->persist && a.n_ahead + grid > c->cu_count)
+            if (a.n_ahead + grid > c->cu_count)
                 return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
-            grid = a.n_ahead + (sl->spec_first ? 0 : grid);
+            grid = a.n_ahead + grid;
             c->last_grid = grid;
         }
     } else {
@@ -673,18 +673,20 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.stretch_a = 2.0; a.seed = 0;
     }
     {
-        const int smode = !sl ? 0 : (sl->spec ? (sl->persist ? (sl->xflow ? 6 : 5) : 4) : (sl->persist ? 3 : (sl->xseq ? 2 : 1)));
-        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 14 + smode * 2 + (stage ? 1 : 0);
+        // forms: 0 the likelihood of given rows, 1 the half-step, 2 the half-step with the one-hop
+        // exchange, 5 / 6 the one-launch look-ahead run on one GPU / across ranks (slots 3, 4)
+        const int smode = !sl ? 0 : (sl->spec ? (sl->xflow ? 6 : 5) : (sl->xseq ? 2 : 1));
+        const int slot = smode >= 5 ? smode - 2 : smode;
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 10 + slot * 2 + (stage ? 1 : 0);
         c->last_smode = smode;
-        c->last_ahead = smode >= 4 ? a.n_ahead : 0;
+        c->last_ahead = smode >= 5 ? a.n_ahead : 0;
         vi_of_kernel = vi;
 #define MBB_VARIANTS(OT, NA)                                                                        \
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
         k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>,           \
-        k_lnlike<OT, NA, 3, false>, k_lnlike<OT, NA, 3, true>, k_lnlike<OT, NA, 4, false>,          \
-        k_lnlike<OT, NA, 4, true>, k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>,           \
+        k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>,                                      \
         k_lnlike<OT, NA, 6, false>, k_lnlike<OT, NA, 6, true>
-        static void (*const table[56])(const LikeArgs) = {
+        static void (*const table[40])(const LikeArgs) = {
             MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
             MBB_VARIANTS(true, true)};
 #undef MBB_VARIANTS
@@ -814,10 +816,9 @@ struct mbb_sampler_state {
     bool pos6_owned = true;              // false: the rows live in the context's exchange buffer
     unsigned int *d_nacc = nullptr;      // [shards][2][nsrc*per], launch-local order
     int *d_err = nullptr;
-    unsigned int *d_gbar = nullptr;      // arrival counters of the one-launch run (8 x 128 bytes)
     double *d_bak = nullptr;             // one-launch run: the rows and counts it started from (R x 6 doubles, R counts)
     bool flow_used = false;              // the last enqueue took the one-launch form
-    double *d_spec = nullptr;            // look-ahead run: records [rows][2][kSpecRec] + state [2][rows][8]
+    double *d_spec = nullptr;            // one-launch run: its device state (FlowView or FlowMView, spec_words(rows))
     int spec_form = 0;                   // the sampler form whose state d_spec holds (0: none / not to be trusted)
     int flowm_parity = 0;                // form 7: the set of completion counters the next launch uses
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
@@ -847,7 +848,6 @@ extern "C" int mbb_sampler_create(mbb_ctx *c, int nwalkers, unsigned long long s
     }
     HIPCHK(hipMalloc((void **)&s->d_nacc, R * sizeof(unsigned int)));
     HIPCHK(hipMalloc((void **)&s->d_err, sizeof(int)));
-    HIPCHK(hipMalloc((void **)&s->d_gbar, 1024));
     HIPCHK(hipMemset(s->d_nacc, 0, R * sizeof(unsigned int)));
     HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
     *out = s;
@@ -863,7 +863,7 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s->pos6_owned) free_dev(s->d_pos6);
     else if (c->x.users > 0) --c->x.users;
-    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_gbar); free_dev(s->d_spec);
+    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_spec);
     free_dev(s->d_bak);
     delete s;
     return MBB_OK;
@@ -969,8 +969,8 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     SamplerLaunch sl;
     sl.pos6 = s->d_pos6; sl.errflag = s->d_err; sl.nw = s->rows(); sl.nw_src = nw;
     sl.stretch_a = stretch_a; sl.c_count = half; sl.m_count = p.per;
-    sl.xseq = 0; sl.persist = 0; sl.gbar = nullptr;
-    sl.spec = nullptr; sl.spec_cfg = 0; sl.spec_first = false;
+    sl.xseq = 0; sl.persist = 0;
+    sl.spec = nullptr;
     // A sharded ensemble with the one-hop exchange, one launch per run (k_lnlike SMODE 6): every rank
     // moves its share of each half and prepares their proposals ahead, decisions / rows / words go
     // into every rank's copy of the run's state (behind the rows in the exchange buffer) at system
@@ -981,7 +981,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     {
         int wpb_x = 0, thr_x = 0, la_rows, la_aw, la_ahead;
         pick_geometry(c, (int)nl, wpb_x, thr_x);
-        lookahead_plan(c, (int)nl, thr_x, p.per, true, la_rows, la_aw, la_ahead);
+        lookahead_plan(c, (int)nl, thr_x, p.per, la_rows, la_aw, la_ahead);
         if (p.xchg && c->opt_lookahead && c->opt_flow && c->opt_xflow && s->nsrc == 1 && nsteps > 0 && wpb_x == 1 &&
             la_ahead + (int)nl <= c->cu_count && (size_t)s->rows() <= c->x.cap_rows) {
             const size_t R = (size_t)s->rows();
@@ -1006,7 +1006,6 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.chain6 = store ? s->d_chain6 + ((((size_t)c->x.rank * nsteps + t0) * 2) * nl) * 6 : nullptr;
                 sl.nacc = s->d_nacc + (size_t)c->x.rank * 2 * nl;
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
-                sl.spec_cfg = 0; sl.spec_first = false;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 hipLaunchKernelGGL(k_flow_post, dim3(1), dim3(64), 0, c->stream, c->x.d_flowx, (int)R, 1, fxh.run,
                                    (const int *)s->d_err);
@@ -1020,34 +1019,19 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             return MBB_OK;
         }
     }
-    // Option "persistent_sampler" 1 -- one GPU, one ensemble, at most one walker per CU: the
-    // whole run in ONE launch per 4096 steps (k_lnlike SMODE 3: every workgroup is resident,
-    // the half-steps hand over inside the kernel).  Off by default: measured slower.
     int wpb_1 = 0, thr_1 = 0;
     pick_geometry(c, (int)nl, wpb_1, thr_1);
-    if (c->opt_persist && p.shards == 1 && !p.collective && s->nsrc == 1 && (int)nl <= c->cu_count && nsteps > 0 &&
-        wpb_1 == 1) {
-        for (int t0 = 0; t0 < nsteps; t0 += 4096) {
-            const int nt = std::min(4096, nsteps - t0);
-            HIPCHK(hipMemsetAsync(s->d_gbar, 0, 1024, c->stream));
-            sl.s_begin = 0; sl.c_begin = half; sl.step = t0; sl.half = 0;
-            sl.persist = 2 * nt; sl.gbar = s->d_gbar;
-            sl.chain6 = store ? s->d_chain6 + ((size_t)t0 * 2 * nl) * 6 : nullptr;
-            sl.nacc = s->d_nacc;
-            sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
-            if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
-        }
-        s->steps_done += (unsigned long long)nsteps;
-        return MBB_OK;
-    }
-    // Option "lookahead_sampler" (default 1) -- one GPU, one ensemble, one walker per workgroup:
-    // every launch carries extra workgroups that prepare the NEXT half-step's proposals (draw,
-    // SED constructor, penalties) for both outcomes of each partner's pending move, so that a
-    // mover's workgroup starts from a finished record instead of the ~4 us dependent chain of
-    // the constructor (k_lnlike SMODE 4).  Same draws, same arithmetic: chains are bitwise
-    // those of the plain launch train.  One extra launch per run prepares its first half-step.
-    if (c->opt_lookahead && p.shards == 1 && !p.collective && s->nsrc == 1 && nsteps > 0 && wpb_1 == 1 &&
-        (int)nl + (2 * (int)nl + 63) / 64 <= c->cu_count && s->rows() <= kPolyBDoubles / 8) {
+    // Option "lookahead_sampler" (default 1) -- one GPU, one ensemble, one walker per workgroup, every
+    // workgroup resident: the run is ONE launch per 4096 steps in which the next half-steps' proposals
+    // (draw, SED constructor, penalties) are prepared for both outcomes of each partner's pending move
+    // while this half-step is being decided, so that a mover starts from a finished record instead
+    // of the ~4 us dependent chain of the constructor.  Same draws, same arithmetic: chains are
+    // bitwise those of the plain launch train, which is what larger ensembles, several sources and
+    // very short runs take.
+    const bool resting = c->flow_rest > 0;
+    if (resting && nsteps > 0) --c->flow_rest;
+    if (c->opt_lookahead && c->opt_flow && !resting && p.shards == 1 && !p.collective && s->nsrc == 1 &&
+        nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps) && wpb_1 == 1) {
         const size_t R = (size_t)s->rows();
         if (!s->d_spec) {
             // zeroed: the records of a one-launch run are taken by their check words, and freshly
@@ -1056,10 +1040,10 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             HIPCHK(hipMemsetAsync(s->d_spec, 0, spec_words(R) * sizeof(double), c->stream));
         }
         int la_rows, la_aw, la_ahead;
-        lookahead_plan(c, (int)nl, thr_1, half, true, la_rows, la_aw, la_ahead);
+        lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead);
         // form 7 where every (pair, candidate) gets a CU of its own; else form 5
         const bool merged = c->opt_flowm && 2 * (int)nl <= c->cu_count;
-        if (c->opt_flow && (merged || la_ahead + (int)nl <= c->cu_count)) {
+        if (merged || la_ahead + (int)nl <= c->cu_count) {
             // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
@@ -1098,7 +1082,6 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.chain6 = store ? s->d_chain6 + ((size_t)t0 * 2 * nl) * 6 : nullptr;
                 sl.nacc = s->d_nacc;
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
-                sl.spec_cfg = 0; sl.spec_first = false;
                 sl.merged = merged;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 // the sampler's rows from the slots the launch's last moves went to
@@ -1110,34 +1093,9 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             s->steps_done += (unsigned long long)nsteps;
             return MBB_OK;
         }
-        s->spec_form = 4;
-        hipLaunchKernelGGL(k_spec_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
-                           s->d_pos6, s->d_spec, (int)R);
-        HIPCHK(hipGetLastError());
-        int cur[2] = {0, 0};                                  // slot of each half's current state
-        sl.spec = s->d_spec;
-        sl.chain6 = nullptr; sl.nacc = s->d_nacc;
-        const unsigned long long key0 = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + 1ull);
-        // the launch "before" the first one: second half moving at step -1, nobody actually moves
-        sl.s_begin = half; sl.c_begin = 0; sl.step = -1; sl.half = 1;
-        sl.seed = key0 - 0x9E3779B97F4A7C15ull;
-        sl.spec_cfg = cur[1] | (cur[0] << 1) | 4; sl.spec_first = true;
-        if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
-        sl.spec_first = false;
-        for (int t = 0; t < nsteps; ++t)
-            for (int h = 0; h < 2; ++h) {
-                sl.s_begin = h ? half : 0; sl.c_begin = h ? 0 : half;
-                sl.step = t; sl.half = h;
-                sl.chain6 = store ? s->d_chain6 + (((size_t)t * 2 + h) * nl) * 6 : nullptr;
-                sl.nacc = s->d_nacc + (size_t)h * nl;
-                sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t + 1ull);
-                sl.spec_cfg = cur[h] | (cur[1 - h] << 1);
-                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
-                cur[h] ^= 1;
-            }
-        s->steps_done += (unsigned long long)nsteps;
-        return MBB_OK;
+        // (no room for the workgroups that work ahead: the launch train)
     }
+    sl.spec = nullptr; sl.merged = false; sl.persist = 0;
     for (int t = 0; t < nsteps; ++t)
         for (int h = 0; h < 2; ++h) {
             const int hb = h ? half : 0;
@@ -1213,22 +1171,32 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         if (err == 8) return fail(MBB_ERR_RCCL, "the exchange timed out: a peer did not post its launch");
         if (err == 9 && s->flow_used && s->d_bak) {
             // The one-launch run gave up waiting (not every workgroup was resident): back to the state it
-            // started from and the same steps as a train of launches -- the same chain.  The context keeps
-            // to the launch train from here on (option "flow_sampler" 1 turns the one-launch form back on).
+            // started from and the same steps as a train of launches -- the same chain.  The next run takes
+            // the one-launch form again; kFlowStrikes give-ups in a row rest it for kFlowRest runs.
             HIPCHK(hipMemcpyAsync(s->d_pos6, s->d_bak, (size_t)R * 6 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(s->d_nacc, s->d_bak + (size_t)R * 6, (size_t)R * sizeof(unsigned int), hipMemcpyDeviceToDevice,
                                   c->stream));
             s->steps_done -= (unsigned long long)nsteps;
             s->spec_form = 0;
-            c->opt_flow = 0;
             ++c->flow_fallbacks;
-            return mbb_sampler_run(c, sp, nsteps, stretch_a, chain, lnprob, pos_out, lnprob_out, naccepted);
+            if (++c->flow_strikes >= kFlowStrikes) { c->flow_strikes = 0; c->flow_rest = kFlowRest; }
+            const long keep = c->opt_flow;
+            c->opt_flow = 0;                                   // (this redo only)
+            rc = mbb_sampler_run(c, sp, nsteps, stretch_a, chain, lnprob, pos_out, lnprob_out, naccepted);
+            c->opt_flow = keep;
+            return rc;
         }
-        if (err == 9) return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step");
+        if (err == 9) {
+            // (an asynchronous advance, or a sharded run: nothing was kept to redo it from)
+            s->spec_form = 0;
+            return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step; the ensemble it "
+                                       "left behind is not a state of the chain: set the sampler's state again");
+        }
         g_err = "lnprob returned NaN or the SED constructor rejected a proposal (row status " +
                 std::to_string(err) + ")";
         return MBB_ERR_ARG;
     }
+    if (s->flow_used) c->flow_strikes = 0;                  // a one-launch run that went through
     for (int i = 0; i < R; ++i) {
         if (pos_out) for (int k = 0; k < 5; ++k) pos_out[(size_t)i * 5 + k] = rows[(size_t)i * 6 + k];
         if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
@@ -1573,11 +1541,11 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
-    else if (!strcmp(name, "persistent_sampler")) c->opt_persist = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
+    else if (!strcmp(name, "flow_min_steps")) c->opt_flow_min_steps = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;
     else if (!strcmp(name, "lookahead_rows")) c->opt_la_rows = value;
     else if (!strcmp(name, "lookahead_waves")) c->opt_la_waves = value;
@@ -1606,6 +1574,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "last_threads")) *value = c->last_threads;
     else if (!strcmp(name, "last_grid")) *value = c->last_grid;
     else if (!strcmp(name, "flow_fallbacks")) *value = c->flow_fallbacks;
+    else if (!strcmp(name, "flow_resting")) *value = c->flow_rest;
     else if (!strcmp(name, "last_kernel_form")) *value = c->last_smode;     // k_lnlike's SMODE of the last launch
     else if (!strcmp(name, "last_workgroups_ahead")) *value = c->last_ahead;
     else if (!strcmp(name, "last_smem")) *value = c->last_smem;

@@ -95,11 +95,8 @@ struct LikeArgs {
     int step, half;
     // (arguments of variants that never meet share storage, so that the block stays at 480
     // bytes for every variant)
-    int persist;              // SMODE 3, 5: half-steps in this launch (step = number of the first step)
-    union {
-        unsigned int *gbar;   // SMODE 3: eight arrival counters, 128 bytes apart, zero at launch
-        double *spec;         // SMODE 4, 5: the look-ahead run's device state, see spec_* below
-    };
+    int persist;              // SMODE 5, 6, form 7: half-steps in this launch (step = number of the first step)
+    double *spec;             // SMODE 5, 6, form 7: the one-launch run's device state (FlowView / FlowX / FlowMView)
     // ---- independent sources sharing the band tables (cfg5): flux/ivar are
     // [nsrc*nb]; plain mode: source = row / rows_per_src; sampler mode: the state is
     // [nsrc][nw_src][6] and a launch covers nsrc * c_count walkers
@@ -112,11 +109,9 @@ struct LikeArgs {
     // tools/lat_kernarg.hip, profiles/r02/lat_kernarg.txt)
     union {
         const XchgArgs *xargs;
-        // ---- look-ahead half-steps (SMODE 4, 5): see k_lnlike
+        // ---- one-launch runs (SMODE 5, 6, form 7): see k_lnlike, k_flowm
         struct {
-            int spec_cfg;     // bit 0: slot of the moving half's state, bit 1: of the other half's,
-                              // bit 2: a run's first launch (works ahead for itself, moves nothing)
-                              // (bits 0-2: SMODE 4 only);
+            int spec_cfg;     // bit 0: form 7, which of the two sets of completion counters this launch uses;
                               // bits 8-15: candidates per wave (1, 2 or 4 rows of 16 lanes),
                               // bits 16-23: waves of a workgroup working ahead that take candidates,
                               // bits 24-31: SMODE 5, log2 of the polls before a wait gives up (0: 22)
@@ -128,14 +123,13 @@ struct LikeArgs {
 #ifndef MBB_STAMPS
 static_assert(sizeof(LikeArgs) == 480, "the argument block: every launch of every variant pays for its size");
 #endif
-constexpr int kSpecRec = 32;  // doubles per record: WalkerK (13), proposal (5), 4 ln z, ln u, the two penalties
-// Device state of a look-ahead run, one allocation of 8-byte words (nw = state rows).
-// SMODE 4: records [nw][2][kSpecRec] at 0, state [2][nw][8] at 64 nw, accept flags [2][nw] at 80 nw.
+// Device state of a one-launch run, one allocation of 8-byte words (nw = state rows).
+// A record: WalkerK (13 words), proposal (5), 4 ln z, ln u, the two penalties = 22 elements.
 // SMODE 5 (FlowView): everything a row publishes is indexed by the number m of the move it
 // belongs to, mod kFlowSlots -- a mover more than four half-steps ahead of the slowest waits, so
 // four slots are never overwritten under a reader:
 //   rec   [nw][kFlowSlots][2][kFlowRec]  the proposal records of move m, one per candidate: word
-//                   2c is element c of the record (the order of SMODE 4's), word 2c + 1 is
+//                   2c is element c of the record, word 2c + 1 is
 //                   (half-step of the move + 1) XOR that element's bits -- a reader takes an element
 //                   when the pair fits, whenever and in whatever order the two stores arrive, so
 //                   the writer neither waits for its stores nor raises a flag after them
@@ -228,10 +222,10 @@ __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsign
 {
     unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * step + half), 0u, 0u};
     philox4x32(c4, (unsigned int)seed, (unsigned int)(seed >> 32));
-    const double u1 = ((double)(c4[0] >> 5) * 67108864.0 + (double)(c4[1] >> 6)) * (1.0 / 9007199254740992.0);
+    const double u1 = fma((double)(c4[0] >> 5), 67108864.0, (double)(c4[1] >> 6)) * (1.0 / 9007199254740992.0);   // (exact)
     const double u2 = (double)c4[2] * (1.0 / 4294967296.0);
     u3 = ((double)c4[3] + 0.5) * (1.0 / 4294967296.0);
-    const double sq = (stretch_a - 1.0) * u1 + 1.0;
+    const double sq = fma(stretch_a - 1.0, u1, 1.0);
     zz = sq * sq / stretch_a;
     pj = (int)(u2 * (double)c_count);
     if (pj >= c_count) pj = c_count - 1;
@@ -247,30 +241,23 @@ __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsign
 // SMODE: 0 the likelihood of given rows; 1 the stretch-move half-step; 2 the half-step of a
 // sharded run with the one-hop exchange (its own instantiation: carried as run-time
 // branches and extra arguments in the single-GPU sampler kernel it cost that kernel 0.75 us
-// per launch); 3 a whole run of half-steps in ONE launch (single GPU, single source, one
-// walker per workgroup, every workgroup resident): the tables are staged once and the
-// dependence between half-steps is carried by a fence-free hand-off inside the kernel
-// instead of a kernel boundary -- the moved row goes out with write-through (sc1) stores
-// from one lane, that lane then adds to its XCD's arrival counter, and the next half-step's
-// prologue wave polls the eight counters and reads its rows with sc1 loads
-// (MI355X_MICROARCH.md, "Valid forms"; tools/lat_grid_barrier.hip: 2.5 us per hand-off).
-// Measured (tools/probe_persist.py): 21.2 us per step against 15.5 with one launch per
-// half-step -- the body of a half-step is 7.6 us either way and a dependent kernel
-// boundary costs this launch train far less than the hand-off -- so the host uses it only
-// on request (option "persistent_sampler" 1); chains are bitwise the same.
-// 4 and 5, the look-ahead forms: the proposals of the NEXT half-step --
-// draw, SED constructor, penalties -- are prepared while this one is being decided, for both
-// outcomes of each partner's pending move, by workgroups of their own (blockIdx < n_ahead); a
-// mover picks the record its partner's accept flag points at and starts at the quadrature.
-// 4: one launch per half-step, the records cross the kernel boundary.  5: one launch per run;
-// a row's half-step starts when the rows it depends on are done (FlowView: per-row words
-// polled with bounded spins, write-through stores, no grid-wide barrier).  Bitwise the chain
-// of SMODE 1; 9.9 us per step against 15.6 (SMODE 1) and 15.3 (SMODE 4).
+// per launch).
+// 5 and 6, the one-launch look-ahead run: a whole run of half-steps in ONE
+// launch, every workgroup resident; the proposals of the NEXT half-step -- draw, SED constructor,
+// penalties -- are prepared while this one is being decided, for both outcomes of each partner's
+// pending move, by workgroups of their own (blockIdx < n_ahead); a mover picks the record its
+// partner's decision points at and starts at the quadrature; a row's half-step starts when the
+// rows it depends on are done (FlowView: per-row words polled with bounded spins, write-through
+// stores, no grid-wide barrier).  6: the same across the ranks of a sharded ensemble.  Bitwise the
+// chain of SMODE 1; 9.9 us per step against 15.6.
+// (Rounds 1-2 also had SMODE 3, a one-launch run behind a grid-wide hand-off, and SMODE 4, the
+// look-ahead as extra workgroups of every launch of a train: both measured slower than what
+// replaced them -- profiles/r02/persistent_sampler.txt, lookahead_notes.txt -- and removed in round 3.)
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
 __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 {
-    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, XF = SMODE == 6, FLOW = SMODE == 5 || XF,
-                   PERSIST = SMODE == 3 || FLOW, SPEC = SMODE == 4 || FLOW;
+    static_assert(SMODE == 0 || SMODE == 1 || SMODE == 2 || SMODE == 5 || SMODE == 6, "no such sampler form");
+    constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, XF = SMODE == 6, FLOW = SMODE == 5 || XF;
     // SMODE 6, the one-launch run of a sharded ensemble: this rank's copy of the run's state and
     // its peers'; words and rows that cross GPUs are read and written at system scope
     const FlowX *const fx = XF ? reinterpret_cast<const FlowX *>(a.spec) : nullptr;
@@ -312,7 +299,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
-    const int w0 = (SMODE >= 4 ? (int)blockIdx.x - a.n_ahead : (int)blockIdx.x) * W;
+    const int w0 = (FLOW ? (int)blockIdx.x - a.n_ahead : (int)blockIdx.x) * W;
     // SMODE 5: polls before a wait gives up and ends the run with error 9 (~1.5 us each)
     // (taken from the argument block where it is needed, not kept in registers across the chains; once
     // the error flag is up, every wait notices within a few polls and the run drains)
@@ -325,7 +312,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]);
     PIN(a.unit_tab); PIN(a.lnl); PIN(a.status); PIN(a.model_flux); PIN(a.invcov); PIN(a.nsrc);
     PIN(a.debug); PIN(a.flux); PIN(a.ivar); PIN(a.rows_per_src);
-    if constexpr (SMODE >= 4) {
+    if constexpr (FLOW) {
         // a mover starts from loads, not from arithmetic: everything its first instructions need
         PIN(a.spec); PIN(a.n_ahead); PIN(a.spec_cfg); PIN(a.s_begin); PIN(a.c_begin); PIN(a.c_count);
         PIN(a.step); PIN(a.half); PIN(a.seed); PIN(a.stretch_a); PIN(a.nw); PIN(a.poly_b); PIN(a.poly_c);
@@ -355,7 +342,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // and the index table into this CU's L1, so that nothing after the barrier waits
     // on L2; without spare waves every wave stages first.
     const int pwaves = min(nwave, (16 * W + 63) >> 6);
-    if ((!SPEC || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
+    if ((!FLOW || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
         const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
         const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
         const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
@@ -370,7 +357,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         double2 *l2 = reinterpret_cast<double2 *>(s_wt);
         constexpr int nB = kPolyBDoubles / 2, nC = OPTHIN ? 0 : kPolyCDoubles / 2;
         const int n2 = STAGE ? a.nchunk * 32 : 0;              // double2 elements per passband array
-        if constexpr (!SPEC) {
+        if constexpr (!FLOW) {
             // table by table, a sweep at a time: the copy trickles along beside the constructor
             // (asked for all at once it fills the CU's load queue and the constructor wave's own
             // few loads wait behind it: +15 % on the 125-walker launch)
@@ -381,8 +368,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
             for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
         } else {
-            // A mover of a look-ahead run has no constructor to hide the copy behind (it ran a
-            // launch ago), so every table is asked for before the first one is stored: one
+            // A mover of a look-ahead run has no constructor to hide the copy behind (other
+            // workgroups run it), so every table is asked for before the first one is stored: one
             // exposed round trip for the lot (~3500 cycles at the start of a launch, when nothing
             // is in L2 yet) instead of one per table and sweep.  Up to three sweeps per table go
             // through registers; what is left (few staging threads, long tables) follows in
@@ -455,61 +442,41 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     int4 us_first = make_int4(0, 0, 0, 0);
     if (wave < nunit) us_first = a.unit_tab[wave % nun];
     int tail_first = -1;                  // ... and (a one-launch run) should it be a tail chunk, the slot of this lane's row
-    if (PERSIST && wave < nunit && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
+    if (FLOW && wave < nunit && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
 
-    // ---- SMODE 4, the workgroups that work ahead -------------------------------------------
-    // Row (16 lanes) `pair` = (walker of the half that moves NEXT, candidate): the walker's
-    // proposal for the next half-step, its SED constants and penalties, under the assumption
-    // that its partner -- one of this launch's movers -- stays (candidate 0) or moves to the
-    // proposal it is being tested on right now (candidate 1; re-derived here from the same
-    // draw and the same rows, so it is the value the mover's own record holds).  Everything
-    // read is state no workgroup of this launch writes: movers write the other slot.
-    if constexpr (SPEC) {
+    // ---- the workgroups that work ahead --------------------------------------------------
+    // Row (16 lanes) `pair` = (walker, candidate): the walker's proposal for its next half-step,
+    // its SED constants and penalties, under the assumption that its partner -- moving in the
+    // half-step before -- stays (candidate 0) or moves to the proposal it is being tested on
+    // (candidate 1; formed again here from the same draw and the same rows, so it is the value
+    // the mover's own record holds).
+    if constexpr (FLOW) {
         if ((int)blockIdx.x < a.n_ahead) {
             const int rpw = (a.spec_cfg >> 8) & 0xff, aw = (a.spec_cfg >> 16) & 0xff;
             const int pair = ((int)blockIdx.x * aw + wave) * rpw + (lane >> 4);
-            const bool first = !FLOW && ((a.spec_cfg >> 2) & 1);   // SMODE 4, nobody is moving: candidate 0 only
-            // SMODE 5: a row of lanes keeps to one half of the ensemble, every other half-step
-            // (a proposal takes about a half-step to prepare; what can be fetched before the
-            // decision it waits for is fetched during the half-step in between)
-            const int wh = FLOW ? (pair >> 1) & 1 : 0;
-            const bool active = wave < aw && (lane >> 4) < rpw && pair < (FLOW ? 4 * a.m_count : 2 * a.c_count) &&
-                                !(first && (pair & 1));
-            const int loc = FLOW ? pair >> 2 : pair >> 1, cand = pair & 1;
-            double *lst = s_pb;
-            if constexpr (!FLOW) {
-                // the ensemble as this launch found it -> LDS (the polynomial table's place, which
-                // these workgroups do not use): every row from the slot nobody writes in this launch
-                const double2 *g = reinterpret_cast<const double2 *>(a.spec + (size_t)a.nw * 2 * kSpecRec);
-                double2 *l = reinterpret_cast<double2 *>(lst);
-                for (int i = tid; i < a.nw * 4; i += (int)blockDim.x) {
-                    const int row = i >> 2;
-                    const bool mov = row >= a.s_begin && row < a.s_begin + a.c_count;
-                    const int slot = mov ? (a.spec_cfg & 1) : ((a.spec_cfg >> 1) & 1);
-                    l[i] = g[(size_t)slot * a.nw * 4 + i];
-                }
-            } else if (wave >= aw) {
-                return;                                       // SMODE 5: nothing is shared, spare waves leave
-            }
+            // a row of lanes keeps to one half of the ensemble, every other half-step (a proposal
+            // takes about a half-step to prepare; what can be fetched before the decision it waits
+            // for is fetched during the half-step in between)
+            const int wh = (pair >> 1) & 1;
+            const bool active = wave < aw && (lane >> 4) < rpw && pair < 4 * a.m_count;
+            const int loc = pair >> 2, cand = pair & 1;
+            if (wave >= aw) return;                           // nothing is shared, spare waves leave
             // SMODE 5: half-step j of the run is prepared as soon as the rows it starts from are
             // there -- the state as of the start of half-step j - 1 -- while j - 1 is still moving
             const FlowView fv = peer_view(xrank);
-            const int nj = FLOW ? a.persist : 1;
-            for (int j = wh; j < nj; j += FLOW ? 2 : 1) {
+            const int nj = a.persist;
+            for (int j = wh; j < nj; j += 2) {
             // the draws: the walker's own for the half-step being prepared, and the one its
             // partner is moving on meanwhile
-            const int hj = FLOW ? (j & 1) : (a.half ^ 1);
-            const int sb = FLOW ? (hj ? a.c_count : 0) : a.c_begin;      // the half that moves then / the other
-            const int ob = FLOW ? (hj ? 0 : a.c_count) : a.s_begin;
-            const int tn = FLOW ? a.step + (j >> 1) : a.step + a.half;
-            const unsigned long long seed_n =
-                FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j >> 1)
-                     : (a.half ? a.seed + 0x9E3779B97F4A7C15ull : a.seed);
-            const int tp = FLOW ? a.step + ((j - 1) >> 1) : a.step, hp = hj ^ 1;
-            const unsigned long long seed_p =
-                FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((j - 1) >> 1) : a.seed;
-            const bool c1 = cand && (!FLOW || j > 0);
-            const int rown = sb + (FLOW ? a.s_begin : 0) + loc;      // (SMODE 5/6: s_begin = this rank's offset in a half)
+            const int hj = j & 1;
+            const int sb = hj ? a.c_count : 0;      // the half that moves then / the other
+            const int ob = hj ? 0 : a.c_count;
+            const int tn = a.step + (j >> 1);
+            const unsigned long long seed_n = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(j >> 1);
+            const int tp = a.step + ((j - 1) >> 1), hp = hj ^ 1;
+            const unsigned long long seed_p = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)((j - 1) >> 1);
+            const bool c1 = cand && j > 0;
+            const int rown = sb + a.s_begin + loc;      // (s_begin = this rank's offset in a half)
             STAMP(11);
             double zz = 1.0, u3 = 0.5, zp = 1.0, up;
             int pj = 0, pjp = 0;
@@ -518,8 +485,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 if (c1) stretch_draw(ob + pj, tp, hp, seed_p, a.stretch_a, a.c_count, zp, pjp, up);
             }
             double snv[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, cpos[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, cpv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-            int m_next = 0;                                   // SMODE 5: the number of the move being prepared
-            if constexpr (FLOW) {
+            int m_next = 0;                                   // the number of the move being prepared
+            {
                 // The rows this proposal starts from -- the walker's own and, for candidate 1, its
                 // partner's partner -- made their last move in half-step j - 2.  Such a row is put
                 // together here from what was known before that move was decided: the row as it
@@ -656,13 +623,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int i = 0; i < 5; ++i) { snv[i] = scr[(ar ? 5 : 0) + i]; cpv[i] = scr[(ap ? 15 : 10) + i]; cpos[i] = scr[20 + i]; }
-            } else {
-                __syncthreads();
-                if (active) {
-                    const double *sn = lst + (size_t)rown * 8, *sp = lst + (size_t)(ob + pj) * 8, *cp = lst + (size_t)(sb + pjp) * 8;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) { snv[i] = sn[i]; cpos[i] = sp[i]; if (c1) cpv[i] = cp[i]; }
-                }
             }
             if (active) {
                 if (c1) {
@@ -683,9 +643,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 const double lT = lo[0], lL = lo[1];
 #include "mbb_walker_consts.inc"
                 if ((tid & 15) == 0) {
-                    double *rec = FLOW ? fv.rec + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFlowRec
-                                       : a.spec + ((size_t)rown * 2 + cand) * kSpecRec;
-                    if constexpr (FLOW) {
+                    double *rec = fv.rec + (((size_t)rown * kFlowSlots + (m_next % kFlowSlots)) * 2 + cand) * kFlowRec;
+                    {
                         // element by element, each with its check word; nothing to wait for
                         const unsigned long long tag = (a.flow_serial << 32) | (unsigned long long)(j + 1);
                         auto put = [&](int c, double v) {
@@ -700,14 +659,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #pragma unroll
                         for (int i = 0; i < 5; ++i) put(13 + i, p[i]);
                         put(18, 4.0 * lo[2]); put(19, lo[3]); put(20, pen_u); put(21, pen_g);
-                    } else {
-                        *reinterpret_cast<WalkerK *>(rec) = k;
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) rec[13 + i] = p[i];
-                        rec[18] = 4.0 * lo[2];                    // (dim - 1) ln z
-                        rec[19] = lo[3];                          // ln u
-                        rec[20] = pen_u;
-                        rec[21] = pen_g;
                     }
                 }
                 STAMPD(10, pen_u + pen_g);
@@ -718,10 +669,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         }
     }
 
-    // PERSIST: a.persist half-steps in this launch; otherwise one pass with the launch's values
-    unsigned xcc = 0;
-    if (PERSIST) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u; }
-    const int niter = PERSIST ? a.persist : 1;
+    // FLOW: a.persist half-steps in this launch; otherwise one pass with the launch's values
+    const int niter = FLOW ? a.persist : 1;
     // SMODE 5, wave 0: the workgroup's two walkers (one of each half) as they are, element l in
     // lane l < 8 -- nobody else writes them; and the row whose word is still to be published
     double own_half[2] = {0.0, 0.0};
@@ -731,24 +680,23 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     unsigned long long cnt_seen = 0;
     int cnt_it = -1;
     for (int it = 0; it < niter; ++it) {
-    const int L_step = PERSIST ? a.step + (it >> 1) : a.step, L_half = PERSIST ? (it & 1) : a.half;
-    const int L_s_begin = PERSIST ? (L_half ? a.c_count : 0) + (FLOW ? a.s_begin : 0) : a.s_begin;
-    const int L_c_begin = PERSIST ? (L_half ? 0 : a.c_count) : a.c_begin;
-    const unsigned long long L_seed = PERSIST ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1) : a.seed;
-    double *const L_chain6 = (PERSIST && a.chain6) ? a.chain6 + (size_t)it * a.n * 6 : a.chain6;
-    unsigned int *const L_nacc = PERSIST ? a.nacc + (size_t)L_half * a.n : a.nacc;
+    const int L_step = FLOW ? a.step + (it >> 1) : a.step, L_half = FLOW ? (it & 1) : a.half;
+    const int L_s_begin = FLOW ? (L_half ? a.c_count : 0) + a.s_begin : a.s_begin;
+    const int L_c_begin = FLOW ? (L_half ? 0 : a.c_count) : a.c_begin;
+    const unsigned long long L_seed = FLOW ? a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1) : a.seed;
+    double *const L_chain6 = (FLOW && a.chain6) ? a.chain6 + (size_t)it * a.n * 6 : a.chain6;
+    unsigned int *const L_nacc = FLOW ? a.nacc + (size_t)L_half * a.n : a.nacc;
 
-    // SMODE 4, a mover: its proposal record was written by the launch before; wave 0 picks the
-    // candidate its partner's accept flag says and lays it out in LDS as phase 1 would have
+    // A mover of a one-launch run: its proposal record was written by a workgroup working ahead; wave 0
+    // picks the candidate its partner's decision says and lays it out in LDS as phase 1 would have
     double own_reg = 0.0;          // lane l < 8 of wave 0: element l of the walker's state row
-    if constexpr (SPEC) {
+    if constexpr (FLOW) {
         if (wave == 0) {
             const int row = L_s_begin + w0;                   // one ensemble, one walker per workgroup
             const FlowView fv = peer_view(xrank);
-            const double *rec = FLOW ? fv.rec + ((size_t)row * kFlowSlots + ((flow_cnt(L_half, it) + 1) % kFlowSlots)) * 2 * kFlowRec
-                                     : a.spec + (size_t)row * 2 * kSpecRec;
+            const double *rec = fv.rec + ((size_t)row * kFlowSlots + ((flow_cnt(L_half, it) + 1) % kFlowSlots)) * 2 * kFlowRec;
             double r0 = 0.0, r1 = 0.0, flag = 0.0;
-            if constexpr (FLOW) {
+            {
                 STAMP(11);
                 // SMODE 5: this half-step starts when both candidates of the walker's record are
                 // there and its partner's move of the half-step before is decided (and nobody is
@@ -837,24 +785,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 }
                 flag = (need_p > 0 && (__shfl(pv, 22) & 1ull)) ? 1.0 : 0.0;
                 STAMP(12);
-            } else {
-            const double *st8 = a.spec + (size_t)a.nw * 2 * kSpecRec;
-            // everything this wave needs is asked for at once, ahead of the other waves' table
-            // copies in the CU's queue -- all the other half's accept flags too (the partner is
-            // known only after the draw; at most 256 walkers per half: the host checks)
-            const double *flg = st8 + (size_t)2 * a.nw * 8 + (size_t)((a.spec_cfg >> 1) & 1) * a.nw + L_c_begin;
-            double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
-            if (lane < kSpecRec) { r0 = rec[lane]; r1 = rec[kSpecRec + lane]; }
-            if (lane < 8) own_reg = st8[((size_t)(a.spec_cfg & 1) * a.nw + row) * 8 + lane];
-            if (lane < a.c_count) f0 = flg[lane];
-            if (lane + 64 < a.c_count) f1 = flg[lane + 64];
-            if (lane + 128 < a.c_count) f2 = flg[lane + 128];
-            if (lane + 192 < a.c_count) f3 = flg[lane + 192];
-            double zz, u3;
-            int pj;
-            stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
-            const int fs = pj >> 6;
-            flag = __shfl(fs == 0 ? f0 : (fs == 1 ? f1 : (fs == 2 ? f2 : f3)), pj & 63);
             }
             const double v = flag != 0.0 ? r1 : r0;
             double *wkd = reinterpret_cast<double *>(wk);
@@ -870,7 +800,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     }
     // ---- phase 1: gate + prologue + parameter-only penalties, one row per walker
     // (the host guarantees blockDim.x >= 16 W)
-    if constexpr (!SPEC)
+    if constexpr (!FLOW)
     if (const int j = tid >> 4; j < W) {
         const bool lead = (tid & 15) == 0;                    // the lane that writes to LDS
         const int w = w0 + j;
@@ -891,22 +821,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 stretch_draw(row, L_step, L_half, L_seed, a.stretch_a, a.c_count, zz, pj, u3);
                 const double *srow = a.pos6 + (size_t)row * 6;
                 const double *crow = a.pos6 + (size_t)(src * a.nw_src + L_c_begin + pj) * 6;
-                if (PERSIST && it > 0) {
-                    // every walker of the previous half-step must have stored its row: the eight
-                    // arrival counters (one per XCD) add up to n per completed half-step.  Only
-                    // this wave reads state rows, so no workgroup barrier is needed after the poll.
-                    const unsigned target = (unsigned)it * (unsigned)a.n;
-                    const int l = tid & 63;
-                    long long spins = 0;
-                    for (;;) {
-                        unsigned v = 0;
-                        if (l < 8) v = __hip_atomic_load(a.gbar + l * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-                        if (__builtin_amdgcn_ballot_w64(l == 0 && v < target) == 0) break;
-                        if (++spins > (1ll << 22)) { atomicMax(a.errflag, 9); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                }
                 constexpr bool xchg = XCHG;
                 if (xchg) {
                     const XchgArgs &x = *a.xargs;
@@ -934,11 +848,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                 double srow5 = 0.0;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    const double cv = xchg ? ld_sys(crow + i) : (PERSIST ? ld_dev(crow + i) : crow[i]);
-                    const double sv = xchg ? ld_sys(srow + i) : (PERSIST ? ld_dev(srow + i) : srow[i]);
+                    const double cv = xchg ? ld_sys(crow + i) : crow[i];
+                    const double sv = xchg ? ld_sys(srow + i) : srow[i];
                     p[i] = stretch_q(cv, sv, zz);
                 }
-                srow5 = xchg ? ld_sys(srow + 5) : (PERSIST ? ld_dev(srow + 5) : srow[5]);
+                srow5 = xchg ? ld_sys(srow + 5) : srow[5];
                 double lo[4];
                 vlog<true>(lo, p[0], p[2], zz, u3);
                 lT = lo[0]; lL = lo[1];
@@ -1008,7 +922,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
         } else if (us.w == 2) {                               // four band leftovers, one per row
             acc = row_sum(acc);
             if ((lane & 15) == 0) {
-                const int sl = (PERSIST && first_unit) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
+                const int sl = (FLOW && first_unit) ? tail_first : a.tail_slot[4 * s + (lane >> 4)];
                 if (sl >= 0) partial[j * npart + sl] = acc;
             }
         } else {
@@ -1145,7 +1059,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             for (int b = lane; b < nb; b += 64) a.model_flux[(size_t)w * nb + b] = __builtin_nan("");
         }
         double old5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if constexpr (SPEC) {
+        if constexpr (FLOW) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) old5[i] = __shfl(own_reg, i);
         }
@@ -1156,8 +1070,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
             else if (st != ROW_OK) r = __builtin_nan("");
             else {
-                r = -0.5 * acc;
-                r += pen_u;                                    // :828
+                r = fma(-0.5, acc, pen_u);                     // :828
                 if (a.has_gprior) r += pen_g;                  // :830-831
             }
             double *lnl_out = FIRST ? lnl_first : (a.lnl ? a.lnl + w : nullptr);
@@ -1229,46 +1142,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
                     }
                     flow_accept = accept ? 1 : 0;
                     flow_r = r;
-                } else if (PERSIST) {
-                    // the row goes out write-through, the stores are waited for, then this
-                    // walker is counted on its XCD's counter: the next half-step starts from that
-                    if (accept) {
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) st_dev(srow + i, q[i]);
-                        st_dev(srow + 5, r);
-                        atomicAdd(&L_nacc[w], 1u);
-                    }
-                    if (L_chain6) {
-                        double *crow = L_chain6 + (size_t)w * 6;
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : ld_dev(srow + i);
-                        crow[5] = accept ? r : q[6];
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(a.gbar + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (SPEC) {
-                    // the row always goes to the OTHER slot of the state (the workgroups working
-                    // ahead read this one), with the flag the next launch picks candidates by
-                    double *dst = a.spec + (size_t)a.nw * 2 * kSpecRec +
-                                  ((size_t)((a.spec_cfg & 1) ^ 1) * a.nw + row) * 8;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) dst[i] = accept ? q[i] : old5[i];
-                    dst[5] = accept ? r : q[6];
-                    dst[6] = accept ? 1.0 : 0.0;
-                    a.spec[(size_t)a.nw * 2 * kSpecRec + (size_t)2 * a.nw * 8 + (size_t)((a.spec_cfg & 1) ^ 1) * a.nw + row] =
-                        accept ? 1.0 : 0.0;
-                    if (accept) {
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) srow[i] = q[i];
-                        srow[5] = r;
-                        atomicAdd(&L_nacc[w], 1u);
-                    }
-                    if (L_chain6) {
-                        double *crow = L_chain6 + (size_t)w * 6;
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) crow[i] = accept ? q[i] : old5[i];
-                        crow[5] = accept ? r : q[6];
-                    }
                 } else {
                 if (accept) {
 #pragma unroll
@@ -1323,22 +1196,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     if (wave < W) epilogue(wave, std::true_type{});
     if (W > nwave)
         for (int j = wave + nwave; j < W; j += nwave) epilogue(j, std::false_type{});
-    }   // half-steps of a persistent run
+    }   // half-steps of a one-launch run
     STAMP(6);
 #undef MBB_FLOW_SPIN_LIMIT
-}
-
-// SMODE 4: both slots of the double-buffered state from the sampler's rows, accept flags clear.
-static __global__ void k_spec_init(const double *pos6, double *spec, int nw)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw * 8) return;
-    const int row = i >> 3, e = i & 7;
-    const double v = e < 6 ? pos6[(size_t)row * 6 + e] : 0.0;
-    double *st8 = spec + (size_t)nw * 2 * kSpecRec;
-    st8[i] = v;
-    st8[(size_t)nw * 8 + i] = v;
-    if (e == 0) { st8[(size_t)nw * 16 + row] = 0.0; st8[(size_t)nw * 17 + row] = 0.0; }   // the compact accept flags
 }
 
 // SMODE 5: slot 0 of the state from the sampler's rows (accept flags clear), all words zero.
@@ -1585,7 +1445,7 @@ __global__ void k_sed_integrate(const WalkerK *wk, double numin, double numax, c
             if (!NOALPHA) kk.xmerge = (piece == 2) ? 0.0 : __builtin_inf();
             const double pw = (b - a) / npanel, half = 0.5 * pw;
             for (int pn = 0; pn < npanel; ++pn) {
-                const double mid = a + (pn + 0.5) * pw;
+                const double mid = fma(pn + 0.5, pw, a);
                 for (int i = lane; i < ngl; i += 64) {
                     const double t = fma(half, glx[i], mid);
                     const double nu = m_exp(t);

@@ -193,7 +193,7 @@ MBB_HD double m_log(double x)
     const double a4 = fma(z, 2.0 / 21.0, 2.0 / 19.0);
     const double p = fma(fma(a4, z4, fma(a3, z2, a2)), z4, fma(a1, z2, a0));
     // log m = 2s + s z p ; write 2s = f - s f  (exact identity: s = f/(2+f))
-    const double lm = f - s * (f - z * p);
+    const double lm = fma(-s, fma(-z, p, f), f);
     const double ed = (double)e;
     return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
 }

@@ -145,6 +145,7 @@ class DeviceEnsembleSampler(object):
         pos = np.empty(lead + (5,))
         lnprob = np.empty(lead)
         nacc = np.zeros(lead)
+        fallbacks = ctx.info("flow_fallbacks")
         rc = ctx.lib.mbb_sampler_run(ctx.h, h, N, self.a,
                                      _native._d(chain) if storechain else None,
                                      _native._d(lnp) if storechain else None,
@@ -152,6 +153,14 @@ class DeviceEnsembleSampler(object):
         if rc == -2:
             raise ValueError(ctx.lib.mbb_last_error().decode())
         _native._check(rc)
+        if ctx.info("flow_fallbacks") > fallbacks:
+            import warnings
+            warnings.warn("the one-launch form of the device sampler gave up waiting (a workgroup was not "
+                          "resident: another process on the GPU?) and the run was redone as a train of "
+                          "launches, about 2.5x slower; same chain.  %d such run(s) on this context so far%s"
+                          % (ctx.info("flow_fallbacks"),
+                             "; the one-launch form now rests for %d runs" % ctx.info("flow_resting")
+                             if ctx.info("flow_resting") else ""), RuntimeWarning, stacklevel=2)
         self.iterations += N
         self.naccepted = nacc
         if storechain:

@@ -1224,61 +1224,17 @@ def test_one_hop_exchange_three_processes_one_gpu():
     _run_xchg_worker(3, {"MBB_XCHG_TEST_WALKERS": "72", "MBB_XCHG_TEST_SKIP_LOST_PEER": "1"})
 
 
-def test_one_launch_sampler_run_equals_one_launch_per_half_step(mbb, g_lnl):
-    """The single-GPU device sampler can run all its half-steps in ONE launch (option
-    "persistent_sampler"; k_lnlike SMODE 3: the dependence between half-steps is a fence-free
-    hand-off inside the kernel; measured slower than a launch per half-step, so off by
-    default, but it is the same chain and a test of that hand-off on every step).  Chain,
-    lnprob, final state and acceptance counts are bitwise those of the form with one launch
-    per half-step, for every model variant, with and without a stored chain, across several
-    consecutive runs, and with more walkers than fit the one-launch form (fall-back)."""
-    bands = [str(b) for b in g_lnl["cfg2/bands"]]
-    rng = np.random.RandomState(12)
-    for name, opthin, noalpha in VARIANTS:
-        k = "cfg2/" + name
-        res = []
-        for persistent in (1, 0):
-            like = mbb.likelihood(response=True, opthin=opthin, noalpha=noalpha)
-            like.set_phot(bands, g_lnl[k + "/flux"], g_lnl[k + "/unc"])
-            like.context.set_option("persistent_sampler", persistent)
-            like.context.set_option("lookahead_sampler", 0)       # the reference form: one plain launch per half-step
-            p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(4).normal(size=(250, 5)))
-            s = mbb.DeviceEnsembleSampler(250, 5, like, seed=77)
-            a = s.run_mcmc(p0, 40)
-            b = s.run_mcmc(None, 25, storechain=False)
-            s.advance_async(30); like.context.sync()
-            c = s.run_mcmc(None, 7)
-            res.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-        for x, y in zip(res[0], res[1]):
-            assert np.array_equal(x, y), name
-        assert res[0][6].shape == (250, 47, 5) and 0.1 < res[0][8].mean() / 102 < 0.9
-    # 600 walkers: 300 per half-step, more than one per CU -> the per-half-step form takes over
-    like = mbb.likelihood(response=True)
-    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
-    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(600, 5)))
-    out = []
-    for persistent in (1, 0):
-        like.context.set_option("persistent_sampler", persistent)
-        like.context.set_option("lookahead_sampler", 0)
-        s = mbb.DeviceEnsembleSampler(600, 5, like, seed=5)
-        out.append(s.run_mcmc(p0, 6)[:2] + (s.chain.copy(),))
-    for x, y in zip(out[0], out[1]):
-        assert np.array_equal(x, y)
-
-
 def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
-            ("look-ahead launches", {"lookahead_sampler": 1, "flow_sampler": 0}),
             ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0}),
             ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     """The device sampler prepares the next half-step's proposals (draw, SED constructor,
-    penalties) ahead of time, for both outcomes of each partner's pending move -- in extra
-    workgroups of every launch (k_lnlike SMODE 4), in ONE launch per run whose half-steps hand over
-    row by row (SMODE 5), or, by default, in one launch per run where the passband quadrature of both
+    penalties) ahead of time, for both outcomes of each partner's pending move -- in ONE launch per
+    run whose half-steps hand over row by row (SMODE 5), or, by default, in one launch per run where the passband quadrature of both
     candidates runs ahead of the partner's decision as well (k_flowm, form 7: one workgroup per pair of
     walkers and candidate).  Same draws and same arithmetic, so chain,
     lnprob, final state and acceptance counts must be bitwise those of the plain train of one
@@ -1309,7 +1265,7 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(5).normal(size=(100, 5)))
     ref = None
-    for flow, rows, waves in ((0, 0, 0), (0, 1, 16), (0, 4, 4), (0, 2, 3), (1, 0, 0), (1, 2, 4), (1, 4, 16), (1, 1, 7)):
+    for flow, rows, waves in ((1, 0, 0), (1, 2, 4), (1, 4, 16), (1, 1, 7), (1, 1, 16), (1, 4, 4), (1, 2, 3)):
         ctx = like.context
         ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", flow); ctx.set_option("merged_flow_sampler", 0)
         ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
@@ -1392,7 +1348,7 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
             pos, lnp, _ = s.run_mcmc(p0, nsteps)
             pos2, lnp2, _ = s.run_mcmc(None, 3)
             out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-            assert like.context.info("last_kernel_form") == {"plain": 1, "look-ahead launches": 4, "one launch, row by row": 5,
+            assert like.context.info("last_kernel_form") == {"plain": 1, "one launch, row by row": 5,
                                                              "one launch, quadrature ahead": 7}[form]
         for form, r in zip(_sampler_forms(None)[1:], out[1:]):
             for x, y in zip(out[0], r):
@@ -1474,9 +1430,9 @@ def test_random_sampler_configurations_all_forms_equal(mbb, seed):
             assert np.array_equal(x, y, equal_nan=True), (seed, form[0], names, nw, opts)
     assert forms[0] == 1
     if nw <= 256:
-        assert forms[3] == 7, forms                         # every (pair, candidate) has a CU
+        assert forms[2] == 7, forms                         # every (pair, candidate) has a CU
     elif nw <= 500:
-        assert forms[3] == 5 and forms[2] == 5, forms
+        assert forms[2] == 5 and forms[1] == 5, forms
 
 
 def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
@@ -1487,7 +1443,7 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     ctx = like.context
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(250, 5)))
     out = []
-    for rows, waves, merged, form in ((1, 1, 0, 4), (0, 0, 0, 5), (0, 0, 1, 7)):     # 500 + 125 workgroups do not fit 256 CUs
+    for rows, waves, merged, form in ((1, 1, 0, 1), (0, 0, 0, 5), (0, 0, 1, 7)):     # 500 + 125 workgroups do not fit 256 CUs
         ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
         ctx.set_option("merged_flow_sampler", merged)
         s = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
@@ -1515,7 +1471,9 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
     """A one-launch run whose waits give up (here: a poll budget of two; in the field: a workgroup
     that is not resident because another process holds CUs) ends with an error flag, not a hang;
     mbb_sampler_run then restores the state the run started from and does the same steps as a train
-    of launches -- the caller gets the chain it would have got, and the context stays on the train."""
+    of launches -- the caller gets the chain it would have got, with a warning.  A give-up is a
+    property of the moment: the next run takes the one-launch form again; only three give-ups in a
+    row rest it, for sixteen runs."""
     for merged, form in ((1, 7), (0, 5)):
         like = _cfg2_like(mbb, g_lnl)
         ctx = like.context
@@ -1528,12 +1486,42 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         first = s1.run_mcmc(p0, 6)[:2]
         assert ctx.info("last_kernel_form") == form and ctx.info("flow_fallbacks") == 0
         ctx.set_option("flow_spin_log2", 1)                       # the second run gives up at once ...
-        second = s1.run_mcmc(None, 5)[:2]
-        assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 4      # ... and was redone
+        with pytest.warns(RuntimeWarning, match="redone as a train"):
+            second = s1.run_mcmc(None, 5)[:2]
+        assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 1      # ... and was redone
         b = first + second + (s1.chain.copy(), s1.naccepted.copy())
         for x, y in zip(a, b):
             assert np.array_equal(x, y), form
         ctx.set_option("flow_spin_log2", 0)
+        # the next run is a one-launch run again, and the same chain goes on
+        c0 = s0.run_mcmc(None, 4)[:2]
+        c1 = s1.run_mcmc(None, 4)[:2]
+        assert ctx.info("last_kernel_form") == form and ctx.info("flow_fallbacks") == 1
+        assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
+        # three give-ups in a row: the form rests (16 runs on the train, no give-ups), then comes back
+        ctx.set_option("flow_spin_log2", 1)
+        for k in range(3):
+            with pytest.warns(RuntimeWarning):
+                s1.run_mcmc(None, 2)
+        assert ctx.info("flow_fallbacks") == 4 and ctx.info("flow_resting") > 0
+        rest = ctx.info("flow_resting")
+        for k in range(rest):
+            s1.run_mcmc(None, 2)
+            assert ctx.info("last_kernel_form") == 1 and ctx.info("flow_fallbacks") == 4
+        ctx.set_option("flow_spin_log2", 0)
+        s1.run_mcmc(None, 2)
+        assert ctx.info("last_kernel_form") == form and ctx.info("flow_resting") == 0
+        s0.run_mcmc(None, 3 * 2 + rest * 2 + 2)
+        assert np.array_equal(s0.run_mcmc(None, 0)[0], s1.run_mcmc(None, 0)[0])
+        # an asynchronous advance keeps nothing to redo a run from: the give-up surfaces at the next
+        # synchronous call as an error, and the sampler wants its state set again
+        ctx.set_option("flow_spin_log2", 1)
+        s1.advance_async(5); ctx.sync()
+        with pytest.raises(Exception, match="set the sampler's state again"):
+            s1.run_mcmc(None, 1)
+        ctx.set_option("flow_spin_log2", 0)
+        s1.run_mcmc(p0, 3)
+        assert ctx.info("last_kernel_form") == form
 
 
 def test_one_launch_sampler_ignores_records_left_in_reused_memory(mbb, g_lnl):
