@@ -82,14 +82,72 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     return (chk ^ (unsigned long long)__double_as_longlong(v)) == tag;
 }
 
+// What every role needs of the launch, declared inside the role after its own argument pointer (what a
+// role does not use is dead code there): band counts, the layout of the dynamic LDS, the run's state.
+#define MBB_FM_COMMON() \
+    const int nun = a.nunit, npart = a.npart, nb = a.nb; \
+    const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1; \
+    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw); \
+    double *partial = reinterpret_cast<double *>(wk + kFmNB); \
+    double *mflux_all = partial + kFmNB * (size_t)npart; \
+    double *prop = mflux_all + 2 * nb; \
+    double *s_flux = prop + kFmNB * kFmProp; \
+    double *s_ivar = s_flux + nb; \
+    double *s_invcov = s_ivar + nb; \
+    int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
+    double *cscr = reinterpret_cast<double *>(s_band + nb + 1); \
+    int *ctl = reinterpret_cast<int *>(cscr + kFmNC * 64); \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15; \
+    double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
+    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
+    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
+    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22); \
+    const FlowMView fv = flowm_view(a.spec, a.nw); \
+    const unsigned long long serial32 = a.flow_serial << 32; \
+    unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \
+    const int niter = a.persist;
+// ... and the waits.  Hand-over words in LDS: a wave's LDS operations execute in the order it issued
+// them, so data then word (writer) and word then data (reader) need no wait in between, only the
+// compiler's order; every wait is bounded and gives up once the run's error flag is up.
+#define MBB_FM_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define MBB_FM_WAITS() \
+    auto dec_ok = [&](unsigned long long v, unsigned long long need) {   /* a decision word of this launch whose half-step + 1 is at least `need` */ \
+        return (v >> 32) == (serial32 >> 32) && ((v & 0xffffffffull) >> 1) >= need; \
+    }; \
+    auto lds_wait = [&](int *word, int need) { \
+        long long spins = 0; \
+        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) { \
+            ++spins; \
+            if (spins > spin_limit * 16 || \
+                ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { \
+                atomicMax(a.errflag, 9); \
+                break; \
+            } \
+            __builtin_amdgcn_s_sleep(1); \
+        } \
+        MBB_FM_ORDER(); \
+    }; \
+    auto lds_post = [&](int *word, int v) { \
+        MBB_FM_ORDER(); \
+        __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }; \
+    (void)dec_ok; (void)lds_wait; (void)lds_post
+// (the wave's number as a scalar: the roles are then uniform branches, not exec-masked regions)
+#ifdef MBB_WAVE_VECTOR
+#define MBB_WAVE_ID(t) ((t) >> 6)
+#else
+#define MBB_WAVE_ID(t) __builtin_amdgcn_readfirstlane((t) >> 6)
+#endif
+
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
 __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 {
+    CLikeArgs *const ka = MBB_KERNARGS();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = MBB_WAVE_ID(tid);
     const int nwave = blockDim.x >> 6, nq = nwave - kFmNC - 2;
     // Which wave does what.  The constructor is one long dependent chain and runs fastest on a SIMD it
     // does not share with the quadrature's bursts: waves 3, 7, 11 and 15 (one SIMD: a workgroup's waves
@@ -102,32 +160,6 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     const int role = spread ? ((wave & 3) == 3 ? 1 + (wave >> 2) : (wave == 14 ? 2 + kFmNC : 0))
                             : (wave < nq ? 0 : 1 + wave - nq);                    // 0 Q, 1..3 C, 4 E0, 5 E1
     const int qi = spread ? wave - (wave >> 2) : wave;                           // Q wave number (14 is not one)
-    const int nun = a.nunit, npart = a.npart, nb = a.nb;
-    const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1;
-    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);                    // [2]
-    double *partial = reinterpret_cast<double *>(wk + kFmNB);               // [kFmNB][npart]
-    double *mflux_all = partial + kFmNB * (size_t)npart;                    // [2][nb]: a scratch row per E wave
-    double *prop = mflux_all + 2 * nb;                                      // [kFmNB][kFmProp]
-    double *s_flux = prop + kFmNB * kFmProp;                                // [nb]
-    double *s_ivar = s_flux + nb;                                           // [nb]
-    double *s_invcov = s_ivar + nb;                                         // [nb*nb] when in LDS
-    int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));   // [nb]
-    double *cscr = reinterpret_cast<double *>(s_band + nb + 1);             // [kFmNC][64]
-    int *ctl = reinterpret_cast<int *>(cscr + kFmNC * 64);                  // [16]
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15;
-    double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
-    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
-    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
-    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
-    const FlowMView fv = flowm_view(a.spec, a.nw);
-    const unsigned long long serial32 = a.flow_serial << 32;
-    unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16;    // this launch's counters
-    // a decision word of this launch whose half-step + 1 is at least `need`
-    auto dec_ok = [&](unsigned long long v, unsigned long long need) {
-        return (v >> 32) == (serial32 >> 32) && ((v & 0xffffffffull) >> 1) >= need;
-    };
-    const int niter = a.persist;
-
     // ---- set-up, once per launch ---------------------------------------------------------------
     // control words clear; this pair's two rows as the sampler holds them -> slot 0 of the run's state,
     // with this launch's check words (no kernel before this one; candidate 0's workgroup does it);
@@ -135,13 +167,18 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     // quadrature and the band sums need go to LDS from the Q and E waves, behind a counter of their
     // own: the C waves start on the launch's first proposals meanwhile (a launch's fixed cost is what
     // a short run is made of: tools/probe_flowm_short.py).
-    if (tid < 16) ctl[tid] = 0;
-    if (cand == 0 && tid < 12) {
-        const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
-        fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
+    {
+        MBB_ROLE_ARGS();
+        MBB_FM_COMMON();
+        if (tid < 16) ctl[tid] = 0;
+        if (cand == 0 && tid < 12) {
+            const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
+            fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
+        }
+        if (blockIdx.x == 0 && tid < kFmRing * 16)
+            __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)done_set; (void)niter; (void)spin_limit;
     }
-    if (blockIdx.x == 0 && tid < kFmRing * 16)
-        __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     // diagnostic build: cycles a wave spends in each part of its loop, summed over the launch
     // -> stamps[(workgroup * 16 + wave) * 8 + part] (tools/probe_stamps_flowm.py)
@@ -171,29 +208,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #define FM_TOUT() do { } while (0)
 #endif
 
-    // hand-over words in LDS.  A wave's LDS operations execute in the order it issued them, so data
-    // then word (writer) and word then data (reader) need no wait in between, only the compiler's
-    // order; every wait is bounded and gives up once the run's error flag is up.
-#define MBB_FM_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-    auto lds_wait = [&](int *word, int need) {
-        long long spins = 0;
-        while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-            ++spins;
-            if (spins > spin_limit * 16 ||
-                ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                atomicMax(a.errflag, 9);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        MBB_FM_ORDER();
-    };
-    auto lds_post = [&](int *word, int v) {
-        MBB_FM_ORDER();
-        __hip_atomic_store(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
     if (role == 0 || role > kFmNC) {
+        MBB_ROLE_ARGS();
+        MBB_FM_COMMON();
+        MBB_FM_WAITS();
         // tables -> LDS: the Q and E waves' threads, numbered through
         const int ns = nq + 2, si = role == 0 ? qi : nq + (role - 1 - kFmNC);
         const int t0 = si * 64 + lane, nt = ns * 64;
@@ -226,6 +244,11 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     if (role != 0) __builtin_amdgcn_s_setprio(3);
     // =========================== Q: the passband quadrature ====================================
     if (role == 0) {
+        MBB_ROLE_ARGS();
+        MBB_FM_COMMON();
+        MBB_FM_WAITS();
+        MBB_PIN(a.unit_tab); MBB_PIN(a.tail_slot); MBB_PIN(a.errflag);
+        if (!STAGE) { MBB_PIN(a.nu); MBB_PIN(a.lnnu); MBB_PIN(a.wt); }
         auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
         auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
         auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
@@ -293,6 +316,12 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 
     // =========================== E: band sums, lnL, and the move if it is this candidate's =====
     if (role > kFmNC) {
+        MBB_ROLE_ARGS();
+        MBB_FM_COMMON();
+        MBB_FM_WAITS();
+        MBB_PIN(a.n); MBB_PIN(a.nw); MBB_PIN(a.c_count); MBB_PIN(a.step); MBB_PIN(a.seed); MBB_PIN(a.stretch_a);
+        MBB_PIN(a.has_gprior); MBB_PIN(a.invcov); MBB_PIN(a.cov_in_lds); MBB_PIN(a.pos6); MBB_PIN(a.chain6);
+        MBB_PIN(a.nacc); MBB_PIN(a.errflag);
         double *mflux = mflux_all + (size_t)(role - 1 - kFmNC) * nb;     // (the two E waves run side by side)
         for (int it = role - 1 - kFmNC; it < niter; it += 2) {
             const int b = it & (kFmNB - 1);
@@ -469,6 +498,12 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 
     // =========================== C: the proposals, worked out ahead of their decisions =========
     {
+        MBB_ROLE_ARGS();
+        MBB_FM_COMMON();
+        MBB_FM_WAITS();
+        MBB_PIN(a.c_count); MBB_PIN(a.step); MBB_PIN(a.seed); MBB_PIN(a.stretch_a); MBB_PIN(a.nw); MBB_PIN(a.errflag);
+        MBB_PIN(a.lowlim[0]); MBB_PIN(a.lowlim[1]); MBB_PIN(a.lowlim[2]); MBB_PIN(a.lowlim[3]); MBB_PIN(a.lowlim[4]);
+        MBB_PIN(a.nunorm); MBB_PIN(a.lnunorm); MBB_PIN(a.has_uplim); MBB_PIN(a.has_gprior);
         const int cb = role - 1;                                  // this wave takes the half-steps j = cb mod kFmNC
         const int vrow = lane >> 4, l16 = lane & 15, base = lane & 48;
         double *scr = cscr + (size_t)cb * 64;
@@ -668,5 +703,4 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 #undef FM_T
 #undef FM_TD
 #undef FM_TOUT
-#undef MBB_FM_ORDER
 }

@@ -1028,10 +1028,10 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     // of the ~4 us dependent chain of the constructor.  Same draws, same arithmetic: chains are
     // bitwise those of the plain launch train, which is what larger ensembles, several sources and
     // very short runs take.
-    const bool resting = c->flow_rest > 0;
-    if (resting && nsteps > 0) --c->flow_rest;
-    if (c->opt_lookahead && c->opt_flow && !resting && p.shards == 1 && !p.collective && s->nsrc == 1 &&
-        nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps) && wpb_1 == 1) {
+    bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&
+                      nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps) && wpb_1 == 1;
+    if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
+    if (one_launch) {
         const size_t R = (size_t)s->rows();
         if (!s->d_spec) {
             // zeroed: the records of a one-launch run are taken by their check words, and freshly

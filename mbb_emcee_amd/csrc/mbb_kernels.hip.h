@@ -192,6 +192,32 @@ __device__ __forceinline__ void st_dev(double *p, double v)    // device-scope: 
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------
+// Role-local view of the kernel arguments (the one-launch sampler kernels: k_lnlike SMODE 5/6, k_flowm).
+// Their workgroups or waves take roles that share one kernel and one 480-byte argument block, and the
+// compiler fetches a by-value kernel argument where the function begins: every field any role touches is
+// then live in scalar registers across the branch to the roles -- far more than the 102 there are -- and
+// the overflow comes back as v_readlane wherever the spiller puts it.  So each role reads the block
+// through a pointer to the kernel-argument segment (constant address space: scalar loads) that it
+// launders at its own top: nothing a role needs can be fetched before its block is entered and nothing
+// another role needs is live inside it.
+// A field named with MBB_PIN at the top of a role arrives with the rest of the role's batch; one that is
+// first touched inside a branch is a scalar load -- a round trip to the scalar cache -- where it is used,
+// and in these kernels that is on the chain between a decision and its publication (measured: role-local
+// arguments WITHOUT the pins cost form 7 +6 % per step, with them -2.3 %; profiles/r03/ab_role_args.txt).
+// So every field of a role's hot path is pinned (the later reads of the same address are the same value
+// to the compiler); what depends on run-time switches (priors, limits) stays a load inside its branch.
+struct LikeArgs;
+typedef const __attribute__((address_space(4))) LikeArgs CLikeArgs;
+__device__ __forceinline__ CLikeArgs *role_args(CLikeArgs *p)
+{
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define MBB_KERNARGS() ((CLikeArgs *)__builtin_amdgcn_kernarg_segment_ptr())
+#define MBB_ROLE_ARGS() CLikeArgs &a = *role_args(ka)
+#define MBB_PIN(x) asm volatile("" ::"s"(x))
+
 // Philox4x32-10 (Salmon et al. 2011), counter = (row, 2 step + half), key = seed.
 __device__ __forceinline__ void philox4x32(unsigned int c[4], unsigned int k0, unsigned int k1)
 {
@@ -254,10 +280,14 @@ __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsign
 // look-ahead as extra workgroups of every launch of a train: both measured slower than what
 // replaced them -- profiles/r02/persistent_sampler.txt, lookahead_notes.txt -- and removed in round 3.)
 template <bool OPTHIN, bool NOALPHA, int SMODE, bool STAGE>
-__global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
+__global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
 {
     static_assert(SMODE == 0 || SMODE == 1 || SMODE == 2 || SMODE == 5 || SMODE == 6, "no such sampler form");
     constexpr bool SAMPLER = SMODE != 0, XCHG = SMODE == 2, XF = SMODE == 6, FLOW = SMODE == 5 || XF;
+    // The one-launch forms have two kinds of workgroups (movers, and those that work ahead) in one kernel:
+    // they read the argument block through role-local views (see MBB_ROLE_ARGS); the others take it by value.
+    CLikeArgs *const ka = MBB_KERNARGS();
+    auto &a = *[&]() { if constexpr (FLOW) return role_args(ka); else return &a_val; }();
     // SMODE 6, the one-launch run of a sharded ensemble: this rank's copy of the run's state and
     // its peers'; words and rows that cross GPUs are read and written at system scope
     const FlowX *const fx = XF ? reinterpret_cast<const FlowX *>(a.spec) : nullptr;
@@ -308,18 +338,17 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // scalar-cache round trip (~200 cycles) each; on the latency path that is a
     // dozen of them.  Ask for the hot ones here so that they arrive in one batch.
 #define PIN(x) asm volatile("" ::"s"(x))
+#define MBB_LNLIKE_PINS() do { \
+    PIN(a.n); PIN(a.pars); PIN(a.nunorm); PIN(a.lnunorm); PIN(a.has_uplim); PIN(a.has_gprior); \
+    PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]); \
+    PIN(a.unit_tab); PIN(a.lnl); PIN(a.status); PIN(a.model_flux); PIN(a.invcov); PIN(a.nsrc); \
+    PIN(a.debug); PIN(a.flux); PIN(a.ivar); PIN(a.rows_per_src); } while (0)
+    if constexpr (!FLOW) {
     PIN(a.n); PIN(a.pars); PIN(a.nunorm); PIN(a.lnunorm); PIN(a.has_uplim); PIN(a.has_gprior);
     PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]);
     PIN(a.unit_tab); PIN(a.lnl); PIN(a.status); PIN(a.model_flux); PIN(a.invcov); PIN(a.nsrc);
     PIN(a.debug); PIN(a.flux); PIN(a.ivar); PIN(a.rows_per_src);
-    if constexpr (FLOW) {
-        // a mover starts from loads, not from arithmetic: everything its first instructions need
-        PIN(a.spec); PIN(a.n_ahead); PIN(a.spec_cfg); PIN(a.s_begin); PIN(a.c_begin); PIN(a.c_count);
-        PIN(a.step); PIN(a.half); PIN(a.seed); PIN(a.stretch_a); PIN(a.nw); PIN(a.poly_b); PIN(a.poly_c);
-        PIN(a.nu); PIN(a.lnnu); PIN(a.wt); PIN(a.nchunk); PIN(a.band_rng); PIN(a.nb); PIN(a.wpb);
-        PIN(a.nunit); PIN(a.npart); PIN(a.pos6); PIN(a.nacc); PIN(a.chain6); PIN(a.errflag);
     }
-#undef PIN
 #ifdef MBB_STAMPS
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();   // before the kernarg arrives
 #define STAMP(i) do { if (tid == 0 && a.stamps && blockIdx.x < 65536) a.stamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -336,114 +365,6 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
 #endif
     STAMP(0);
 
-    // A walker's prologue runs on one row of 16 lanes (mbb_device.hip.h, "rows"), so
-    // the first ceil(16 W / 64) waves are prologue waves.  The other waves meanwhile
-    // stage what the later phases need in LDS and pull their first segment's samples
-    // and the index table into this CU's L1, so that nothing after the barrier waits
-    // on L2; without spare waves every wave stages first.
-    const int pwaves = min(nwave, (16 * W + 63) >> 6);
-    if ((!FLOW || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
-        const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
-        const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
-        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
-        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
-        const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
-        const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
-        const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
-        double2 *lb = reinterpret_cast<double2 *>(s_pb);
-        double2 *lc = reinterpret_cast<double2 *>(s_pc);
-        double2 *l0 = reinterpret_cast<double2 *>(s_nu);
-        double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
-        double2 *l2 = reinterpret_cast<double2 *>(s_wt);
-        constexpr int nB = kPolyBDoubles / 2, nC = OPTHIN ? 0 : kPolyCDoubles / 2;
-        const int n2 = STAGE ? a.nchunk * 32 : 0;              // double2 elements per passband array
-        if constexpr (!FLOW) {
-            // table by table, a sweep at a time: the copy trickles along beside the constructor
-            // (asked for all at once it fills the CU's load queue and the constructor wave's own
-            // few loads wait behind it: +15 % on the 125-walker launch)
-            for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
-            for (int i = t0; i < nB; i += nt) lb[i] = gb[i];
-            for (int i = t0; i < nC; i += nt) lc[i] = gc[i];
-            for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
-            for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
-            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-        } else {
-            // A mover of a look-ahead run has no constructor to hide the copy behind (other
-            // workgroups run it), so every table is asked for before the first one is stored: one
-            // exposed round trip for the lot (~3500 cycles at the start of a launch, when nothing
-            // is in L2 yet) instead of one per table and sweep.  Up to three sweeps per table go
-            // through registers; what is left (few staging threads, long tables) follows in
-            // plain loops.  The loads are pinned in front of the stores: left alone the compiler
-            // sinks each load into the branch of its store and waits for it there.
-#define MBB_PIN2(v) asm volatile("" : "+v"(v.x), "+v"(v.y))
-            // (After that first round trip the copy is bound by the rate at which the CU's address
-            // unit takes loads -- 64 bytes a cycle, 16 cycles per full wave -- so lanes past the
-            // end of a table ask for nothing.)
-            const int i0 = t0, i1 = t0 + nt, i2 = t0 + 2 * nt;
-            const double2 z2 = make_double2(0.0, 0.0);
-            double2 ve = z2, vb0 = z2, vb1 = z2, vb2 = z2, vc0 = z2, vc1 = z2;
-            double2 p00 = z2, p01 = z2, p10 = z2, p11 = z2, p20 = z2, p21 = z2, fiv = z2;
-            int2 brv = make_int2(0, 0);
-            if (STAGE) {
-                if (i0 < n2) { p00 = g0[i0]; p10 = g1[i0]; p20 = g2[i0]; }
-                if (i1 < n2) { p01 = g0[i1]; p11 = g1[i1]; p21 = g2[i1]; }
-            }
-            if (i0 < kExp2N) ve = reinterpret_cast<const double2 *>(kExp2Tab)[i0];
-            if (i0 < nB) vb0 = gb[i0];
-            if (i1 < nB) vb1 = gb[i1];
-            if (i2 < nB) vb2 = gb[i2];
-            if (!OPTHIN) {
-                if (i0 < nC) vc0 = gc[i0];
-                if (i1 < nC) vc1 = gc[i1];
-            }
-            if (t0 < nb) { fiv = make_double2(a.flux[t0], a.ivar[t0]); brv = a.band_rng[t0]; }
-            if (STAGE) { MBB_PIN2(p00); MBB_PIN2(p10); MBB_PIN2(p20); MBB_PIN2(p01); MBB_PIN2(p11); MBB_PIN2(p21); }
-            MBB_PIN2(ve); MBB_PIN2(vb0); MBB_PIN2(vb1); MBB_PIN2(vb2);
-            if (!OPTHIN) { MBB_PIN2(vc0); MBB_PIN2(vc1); }
-            MBB_PIN2(fiv);
-#undef MBB_PIN2
-            if (STAGE) {
-                if (i0 < n2) { l0[i0] = p00; l1[i0] = p10; l2[i0] = p20; }
-                if (i1 < n2) { l0[i1] = p01; l1[i1] = p11; l2[i1] = p21; }
-            }
-            if (i0 < kExp2N) reinterpret_cast<double2 *>(s_tab)[i0] = ve;
-            if (i0 < nB) lb[i0] = vb0;
-            if (i1 < nB) lb[i1] = vb1;
-            if (i2 < nB) lb[i2] = vb2;
-            if (!OPTHIN) {
-                if (i0 < nC) lc[i0] = vc0;
-                if (i1 < nC) lc[i1] = vc1;
-            }
-            if (t0 < nb) { s_flux[t0] = fiv.x; s_ivar[t0] = fiv.y; s_band[t0] = brv; }
-            for (int i = t0 + nt; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
-            for (int i = t0 + 3 * nt; i < nB; i += nt) lb[i] = gb[i];
-            for (int i = t0 + 2 * nt; i < nC; i += nt) lc[i] = gc[i];
-            for (int i = t0 + 2 * nt; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
-            for (int b = t0 + nt; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
-        }
-        if (a.cov_in_lds)
-            for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
-        if (!STAGE && wave >= pwaves) {
-            const int u = wave;
-            if (u < W * nun) {
-                const int4 us = a.unit_tab[u % nun];
-                double t = 0.0;
-                for (int c = us.y; c < us.z; ++c) {
-                    const int i = c * 64 + lane;
-                    t += a.nu[i] + a.lnnu[i] + a.wt[i];
-                }
-                asm volatile("" ::"v"(t));
-            }
-        }
-    }
-
-    // this wave's first quadrature unit: asked for now, it is here when phase 2 begins
-    const int nunit = W * nun;
-    int4 us_first = make_int4(0, 0, 0, 0);
-    if (wave < nunit) us_first = a.unit_tab[wave % nun];
-    int tail_first = -1;                  // ... and (a one-launch run) should it be a tail chunk, the slot of this lane's row
-    if (FLOW && wave < nunit && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
-
     // ---- the workgroups that work ahead --------------------------------------------------
     // Row (16 lanes) `pair` = (walker, candidate): the walker's proposal for its next half-step,
     // its SED constants and penalties, under the assumption that its partner -- moving in the
@@ -452,6 +373,11 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     // the mover's own record holds).
     if constexpr (FLOW) {
         if ((int)blockIdx.x < a.n_ahead) {
+            MBB_ROLE_ARGS();
+            PIN(a.spec_cfg); PIN(a.m_count); PIN(a.persist); PIN(a.c_count); PIN(a.s_begin); PIN(a.step); PIN(a.seed);
+            PIN(a.stretch_a); PIN(a.nw); PIN(a.flow_serial); PIN(a.errflag); PIN(a.nunorm); PIN(a.lnunorm);
+            PIN(a.has_uplim); PIN(a.has_gprior);
+            PIN(a.lowlim[0]); PIN(a.lowlim[1]); PIN(a.lowlim[2]); PIN(a.lowlim[3]); PIN(a.lowlim[4]);
             const int rpw = (a.spec_cfg >> 8) & 0xff, aw = (a.spec_cfg >> 16) & 0xff;
             const int pair = ((int)blockIdx.x * aw + wave) * rpw + (lane >> 4);
             // a row of lanes keeps to one half of the ensemble, every other half-step (a proposal
@@ -668,6 +594,124 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
             return;
         }
     }
+
+    if constexpr (FLOW) {
+        // a mover starts from loads, not from arithmetic: everything its first instructions need (the
+        // workgroups that work ahead have left above: these loads are the movers' alone)
+        MBB_LNLIKE_PINS();
+        PIN(a.spec); PIN(a.n_ahead); PIN(a.spec_cfg); PIN(a.s_begin); PIN(a.c_begin); PIN(a.c_count);
+        PIN(a.step); PIN(a.half); PIN(a.seed); PIN(a.stretch_a); PIN(a.nw); PIN(a.poly_b); PIN(a.poly_c);
+        PIN(a.nu); PIN(a.lnnu); PIN(a.wt); PIN(a.nchunk); PIN(a.band_rng); PIN(a.nb); PIN(a.wpb);
+        PIN(a.nunit); PIN(a.npart); PIN(a.pos6); PIN(a.nacc); PIN(a.chain6); PIN(a.errflag); PIN(a.tail_slot);
+    }
+
+    // A walker's prologue runs on one row of 16 lanes (mbb_device.hip.h, "rows"), so
+    // the first ceil(16 W / 64) waves are prologue waves.  The other waves meanwhile
+    // stage what the later phases need in LDS and pull their first segment's samples
+    // and the index table into this CU's L1, so that nothing after the barrier waits
+    // on L2; without spare waves every wave stages first.
+    const int pwaves = min(nwave, (16 * W + 63) >> 6);
+    if ((!FLOW || (int)blockIdx.x >= a.n_ahead) && (wave >= pwaves || pwaves == nwave)) {
+        const int t0 = (pwaves == nwave) ? tid : tid - 64 * pwaves;
+        const int nt = (pwaves == nwave) ? (int)blockDim.x : (int)blockDim.x - 64 * pwaves;
+        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+        const double2 *g0 = reinterpret_cast<const double2 *>(a.nu);
+        const double2 *g1 = reinterpret_cast<const double2 *>(a.lnnu);
+        const double2 *g2 = reinterpret_cast<const double2 *>(a.wt);
+        double2 *lb = reinterpret_cast<double2 *>(s_pb);
+        double2 *lc = reinterpret_cast<double2 *>(s_pc);
+        double2 *l0 = reinterpret_cast<double2 *>(s_nu);
+        double2 *l1 = reinterpret_cast<double2 *>(s_lnnu);
+        double2 *l2 = reinterpret_cast<double2 *>(s_wt);
+        constexpr int nB = kPolyBDoubles / 2, nC = OPTHIN ? 0 : kPolyCDoubles / 2;
+        const int n2 = STAGE ? a.nchunk * 32 : 0;              // double2 elements per passband array
+        if constexpr (!FLOW) {
+            // table by table, a sweep at a time: the copy trickles along beside the constructor
+            // (asked for all at once it fills the CU's load queue and the constructor wave's own
+            // few loads wait behind it: +15 % on the 125-walker launch)
+            for (int i = t0; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+            for (int i = t0; i < nB; i += nt) lb[i] = gb[i];
+            for (int i = t0; i < nC; i += nt) lc[i] = gc[i];
+            for (int b = t0; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; }
+            for (int b = t0; b < nb; b += nt) s_band[b] = a.band_rng[b];
+            for (int i = t0; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        } else {
+            // A mover of a look-ahead run has no constructor to hide the copy behind (other
+            // workgroups run it), so every table is asked for before the first one is stored: one
+            // exposed round trip for the lot (~3500 cycles at the start of a launch, when nothing
+            // is in L2 yet) instead of one per table and sweep.  Up to three sweeps per table go
+            // through registers; what is left (few staging threads, long tables) follows in
+            // plain loops.  The loads are pinned in front of the stores: left alone the compiler
+            // sinks each load into the branch of its store and waits for it there.
+#define MBB_PIN2(v) asm volatile("" : "+v"(v.x), "+v"(v.y))
+            // (After that first round trip the copy is bound by the rate at which the CU's address
+            // unit takes loads -- 64 bytes a cycle, 16 cycles per full wave -- so lanes past the
+            // end of a table ask for nothing.)
+            const int i0 = t0, i1 = t0 + nt, i2 = t0 + 2 * nt;
+            const double2 z2 = make_double2(0.0, 0.0);
+            double2 ve = z2, vb0 = z2, vb1 = z2, vb2 = z2, vc0 = z2, vc1 = z2;
+            double2 p00 = z2, p01 = z2, p10 = z2, p11 = z2, p20 = z2, p21 = z2, fiv = z2;
+            int2 brv = make_int2(0, 0);
+            if (STAGE) {
+                if (i0 < n2) { p00 = g0[i0]; p10 = g1[i0]; p20 = g2[i0]; }
+                if (i1 < n2) { p01 = g0[i1]; p11 = g1[i1]; p21 = g2[i1]; }
+            }
+            if (i0 < kExp2N) ve = reinterpret_cast<const double2 *>(kExp2Tab)[i0];
+            if (i0 < nB) vb0 = gb[i0];
+            if (i1 < nB) vb1 = gb[i1];
+            if (i2 < nB) vb2 = gb[i2];
+            if (!OPTHIN) {
+                if (i0 < nC) vc0 = gc[i0];
+                if (i1 < nC) vc1 = gc[i1];
+            }
+            if (t0 < nb) { fiv = make_double2(a.flux[t0], a.ivar[t0]); brv = a.band_rng[t0]; }
+            if (STAGE) { MBB_PIN2(p00); MBB_PIN2(p10); MBB_PIN2(p20); MBB_PIN2(p01); MBB_PIN2(p11); MBB_PIN2(p21); }
+            MBB_PIN2(ve); MBB_PIN2(vb0); MBB_PIN2(vb1); MBB_PIN2(vb2);
+            if (!OPTHIN) { MBB_PIN2(vc0); MBB_PIN2(vc1); }
+            MBB_PIN2(fiv);
+#undef MBB_PIN2
+            if (STAGE) {
+                if (i0 < n2) { l0[i0] = p00; l1[i0] = p10; l2[i0] = p20; }
+                if (i1 < n2) { l0[i1] = p01; l1[i1] = p11; l2[i1] = p21; }
+            }
+            if (i0 < kExp2N) reinterpret_cast<double2 *>(s_tab)[i0] = ve;
+            if (i0 < nB) lb[i0] = vb0;
+            if (i1 < nB) lb[i1] = vb1;
+            if (i2 < nB) lb[i2] = vb2;
+            if (!OPTHIN) {
+                if (i0 < nC) lc[i0] = vc0;
+                if (i1 < nC) lc[i1] = vc1;
+            }
+            if (t0 < nb) { s_flux[t0] = fiv.x; s_ivar[t0] = fiv.y; s_band[t0] = brv; }
+            for (int i = t0 + nt; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+            for (int i = t0 + 3 * nt; i < nB; i += nt) lb[i] = gb[i];
+            for (int i = t0 + 2 * nt; i < nC; i += nt) lc[i] = gc[i];
+            for (int i = t0 + 2 * nt; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+            for (int b = t0 + nt; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
+        }
+        if (a.cov_in_lds)
+            for (int i = t0; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
+        if (!STAGE && wave >= pwaves) {
+            const int u = wave;
+            if (u < W * nun) {
+                const int4 us = a.unit_tab[u % nun];
+                double t = 0.0;
+                for (int c = us.y; c < us.z; ++c) {
+                    const int i = c * 64 + lane;
+                    t += a.nu[i] + a.lnnu[i] + a.wt[i];
+                }
+                asm volatile("" ::"v"(t));
+            }
+        }
+    }
+
+    // this wave's first quadrature unit: asked for now, it is here when phase 2 begins
+    const int nunit = W * nun;
+    int4 us_first = make_int4(0, 0, 0, 0);
+    if (wave < nunit) us_first = a.unit_tab[wave % nun];
+    int tail_first = -1;                  // ... and (a one-launch run) should it be a tail chunk, the slot of this lane's row
+    if (FLOW && wave < nunit && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
 
     // FLOW: a.persist half-steps in this launch; otherwise one pass with the launch's values
     const int niter = FLOW ? a.persist : 1;
@@ -1199,6 +1243,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a)
     }   // half-steps of a one-launch run
     STAMP(6);
 #undef MBB_FLOW_SPIN_LIMIT
+#undef PIN
 }
 
 // SMODE 5: slot 0 of the state from the sampler's rows (accept flags clear), all words zero.

@@ -1493,26 +1493,38 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         for x, y in zip(a, b):
             assert np.array_equal(x, y), form
         ctx.set_option("flow_spin_log2", 0)
+        # (the reference sampler makes the same runs as a launch train: a run's length is part of its
+        # random stream)
+        def ref_run(n):
+            ctx.set_option("lookahead_sampler", 0)
+            out = s0.run_mcmc(None, n)[:2]
+            ctx.set_option("lookahead_sampler", 1)
+            return out
         # the next run is a one-launch run again, and the same chain goes on
-        c0 = s0.run_mcmc(None, 4)[:2]
         c1 = s1.run_mcmc(None, 4)[:2]
         assert ctx.info("last_kernel_form") == form and ctx.info("flow_fallbacks") == 1
+        c0 = ref_run(4)
         assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         # three give-ups in a row: the form rests (16 runs on the train, no give-ups), then comes back
         ctx.set_option("flow_spin_log2", 1)
         for k in range(3):
             with pytest.warns(RuntimeWarning):
-                s1.run_mcmc(None, 2)
+                c1 = s1.run_mcmc(None, 2)[:2]
+            ctx.set_option("flow_spin_log2", 0)
+            c0 = ref_run(2)                                       # (a train: neither a give-up nor a rest)
+            ctx.set_option("flow_spin_log2", 1)
+            assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         assert ctx.info("flow_fallbacks") == 4 and ctx.info("flow_resting") > 0
-        rest = ctx.info("flow_resting")
-        for k in range(rest):
-            s1.run_mcmc(None, 2)
+        while ctx.info("flow_resting") > 0:
+            c1 = s1.run_mcmc(None, 2)[:2]
             assert ctx.info("last_kernel_form") == 1 and ctx.info("flow_fallbacks") == 4
+            c0 = ref_run(2)
+            assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         ctx.set_option("flow_spin_log2", 0)
-        s1.run_mcmc(None, 2)
+        c1 = s1.run_mcmc(None, 2)[:2]
         assert ctx.info("last_kernel_form") == form and ctx.info("flow_resting") == 0
-        s0.run_mcmc(None, 3 * 2 + rest * 2 + 2)
-        assert np.array_equal(s0.run_mcmc(None, 0)[0], s1.run_mcmc(None, 0)[0])
+        c0 = ref_run(2)
+        assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         # an asynchronous advance keeps nothing to redo a run from: the give-up surfaces at the next
         # synchronous call as an error, and the sampler wants its state set again
         ctx.set_option("flow_spin_log2", 1)
