@@ -193,6 +193,95 @@ def valu_roofline(pm, pm_src, kernel_s, label):
             "kernel_us": kernel_s * 1e6, "counters_source": pm_src}
 
 
+def user_runs(like, pos):
+    import mbb_emcee_amd as mbb
+    from tools.bench_configs import CFG1_WAVE
+    ctx = like._sync_device()
+    out = {}
+    # M2 with the chain stored: enqueue + D2H + re-ordering on the host, wall clock
+    smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
+    smp.run_mcmc(pos, 60, storechain=False)
+    stored = {}
+    for k in (250, 2000):
+        smp.run_mcmc(None, k)                                  # (warm: the chain buffer of this length exists)
+        smp.reset()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); smp.run_mcmc(None, k); ts.append(time.perf_counter() - t0)
+            smp.reset()
+        t = float(np.median(ts))
+        ctx.sync()
+        e0, e1 = ctx.event(), ctx.event()
+        ctx.record(e0); smp.advance_async(k); ctx.record(e1); ctx.sync()
+        stored["steps_%d" % k] = {"wall_us_per_step": t * 1e6 / k, "evals_per_s": NW_PER_GPU * k / t,
+                                  "unstored_stream_us_per_step": ctx.elapsed_ms(e0, e1) * 1e3 / k,
+                                  "chain_bytes": NW_PER_GPU * k * 48}
+    stored["note"] = ("DeviceEnsembleSampler.run_mcmc(None, K) with storechain=True: launch, 48 B per walker per "
+                      "step back over PCIe, re-ordering into chain[walker, step, 5] + lnprobability[walker, step]; "
+                      "median of 5 by the wall clock")
+    out["sampler_M2_stored_chain"] = stored
+    del smp
+    # whole fits
+    fits = {}
+    for cfg in ("cfg1", "cfg2"):
+        for sampler in ("device", "native"):
+            if cfg == "cfg1":
+                fit = mbb.mbb_fitter(nwalkers=50, opthin=True, seed=3, sampler=sampler)
+                one = mbb.likelihood(opthin=True)
+                one.set_phot(CFG1_WAVE, np.ones(5), np.ones(5))
+                f = one.model_flux(TRUTH)[0]
+                fit.set_data(CFG1_WAVE, f, 0.1 * f + 1.0)
+            else:
+                fit = mbb.mbb_fitter(nwalkers=NW_PER_GPU, response=True, seed=3, sampler=sampler)
+                fit.set_data(BANDS, like._flux, like._flux_unc)
+            p0 = fit.generate_initial_values(np.array([10.0, 2.0, 600.0, 4.0, 40.0]), np.array([2.0, 0.2, 100.0, 0.3, 5.0]))
+            t0 = time.perf_counter(); fit.run(50, 250, p0); first = time.perf_counter() - t0
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); fit.run(50, 250, p0); ts.append(time.perf_counter() - t0)
+            ch = fit.sampler.chain
+            fits["%s_%s" % (cfg, sampler)] = {"fit_wall_s": float(np.median(ts)), "first_fit_wall_s": first,
+                                              "chain_shape": list(ch.shape),
+                                              "acceptance_fraction": float(np.mean(fit.sampler.acceptance_fraction)),
+                                              "median_T": float(np.median(ch[:, :, 0]))}
+    fits["note"] = ("mbb_fitter(...).run(nburn=50, nsteps=250, p0) end to end: validation, burn-in, reset, main chain, chain "
+                    "on the host; first = including the context, the tables' upload and the first launches.  cfg1: 50 "
+                    "walkers, 5 delta bands, thin; cfg2: 250 walkers, 8 passbands, thick+alpha.  `device` is the default "
+                    "sampler of mbb_fitter, `native` the host stretch move over likelihood.__call__ (one launch per "
+                    "half-step: the boundary an external sampler sees)")
+    out["fit"] = fits
+    return out
+
+
+def config_roofline(name, plain_us, half_step_us, form, half, ctx):
+    """fp64 roofline objects of a config's plain launch and of its sampler half-step, from the committed
+    counter passes of `tools/bench_configs.py <name> --profile` (profiles/rNN/pmc_valu_<name>.json)."""
+    f = newest_profile("pmc_valu_%s.json" % name)
+    if not f:
+        return {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "note": "no committed PMC summary for this config"}
+    d = json.load(open(f))
+    src = os.path.relpath(f, ROOT)
+    plain = next((v for k, v in d["kernels"].items() if "k_lnlike<" in k and ", 0, " in k), None)
+    roof = valu_roofline(plain, src, plain_us * 1e-6,
+                         "k_lnlike<plain> n=%d (%d workgroups x %d threads)" % (half, ctx.info("last_grid"), ctx.info("last_threads"))) \
+        if plain else {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None}
+    smp = next((v for k, v in d["kernels"].items() if ("k_flowm<" in k or ", 5, " in k) and "counters_per_half_step" in v), None)
+    if smp and form in (5, 7):
+        sm = dict(smp)
+        sm["counters_per_launch"] = smp["counters_per_half_step"]
+        r2 = valu_roofline(sm, src, half_step_us * 1e-6, "sampler form %d, per half-step" % form)
+        roof["sampler_half_step"] = {"executed_tflops": r2["achieved"], "executed_frac": r2["frac"],
+                                     "valu_issue_frac": r2["valu_issue_frac"], "half_step_us": half_step_us,
+                                     "valu_wave_instructions_per_half_step": r2["valu_wave_instructions_per_launch"]}
+        if plain:
+            # algorithmic work of a half-step = the plain launch's count (it computes nothing twice)
+            useful = plain["fp64_flops_per_launch"]
+            roof["sampler_half_step"]["achieved_tflops"] = useful / (half_step_us * 1e-6) / 1e12
+            roof["sampler_half_step"]["frac"] = roof["sampler_half_step"]["achieved_tflops"] / FP64_VALU_PEAK_TFLOPS
+    return roof
+
+
 def ensemble_crc(pos, lnp):
     import zlib
     return zlib.crc32(np.ascontiguousarray(pos).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp).tobytes())
@@ -959,6 +1048,21 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
         if pm5:
             cfg5["valu_wave_instructions_per_walker"] = pm5["counters_per_launch"].get("SQ_INSTS_VALU", 0) / n5
         out["cfg5"] = cfg5
+
+    # ---- what a user runs (outside `value`): the sampler WITH its chain stored and brought back in
+    # emcee's [walker, step, dim] layout (reference mbb_fit.py:542 -> results.py:153-154), by the wall
+    # clock; and whole fits, mbb_fitter.run(50, 250, p0) (run_mbb_emcee.py:73-74, :137-142 defaults), with
+    # the device-resident sampler (the default) and with the host stretch move that calls
+    # likelihood.__call__ once per half-step (what an external sampler such as emcee does)
+    if not args.no_fit:
+        out["user_runs"] = user_runs(like, pos)
+
+    # ---- the other single-GPU configurations of BASELINE.json (configs[0], configs[3]): M1, M2, the
+    # plain launch, its fp64 roofline from the committed PMC pass of that launch, the CPU oracle on
+    # the same rows (tools/bench_configs.py)
+    if not args.no_configs:
+        from tools.bench_configs import measure as cfg_measure
+        out["configs"] = {c: cfg_measure(c, roofline_fn=config_roofline, cpu=not args.no_cpu) for c in ("cfg1", "cfg4")}
 
     if not args.no_cpu:
         cb, ref = cpu_baseline(like, flux, pos)

@@ -342,10 +342,22 @@ class likelihood(object):
         return lnl
 
     def map(self, func, rows):
-        """pool-style adaptor: ``sampler.pool = like`` makes an emcee-2 style
-        sampler evaluate a whole half-step in one launch.  func is ignored when
-        it is this object's own __call__ wrapper."""
-        return list(self(np.asarray(list(rows), dtype=np.float64)))
+        """pool-style adaptor: ``EnsembleSampler(..., pool=like)`` makes an emcee-2 style sampler
+        hand a whole half-step over at once.  When ``func`` is this object -- bare, as a bound
+        ``__call__``, or inside emcee's function wrapper (attribute ``f``) without extra
+        arguments -- the rows are evaluated in ONE launch.  Any other function (a lambda that adds
+        a prior, a wrapper carrying ``args=``) is what the caller wants evaluated: it is applied row
+        by row, as ``map`` would."""
+        rows = list(rows)
+        target = getattr(func, "f", func)
+        extra = bool(getattr(func, "args", None)) or bool(getattr(func, "kwargs", None))
+        own = target is self or (getattr(target, "__self__", None) is self and
+                                 getattr(target, "__name__", "") == "__call__")
+        if own and not extra:
+            if not rows:
+                return []
+            return list(self(np.asarray(rows, dtype=np.float64)))
+        return [func(r) for r in rows]
 
     # ---- pickling: the device context is rebuilt on demand ---------------------
     def __getstate__(self):

@@ -61,8 +61,36 @@ def parity_record(kind, observed, bound):
     k["checks"] += 1
 
 
+KERNEL_SOURCE_GLOBS = ("mbb_emcee_amd/csrc/*.hip", "mbb_emcee_amd/csrc/*.h", "mbb_emcee_amd/csrc/*.inc",
+                       "mbb_emcee_amd/csrc/*.cpp", "include/*.h", "mbb_emcee_amd/build.py")
+
+
+def kernel_sources_sha16():
+    """Hash of everything the device library is built from: a parity report says which sources it
+    was measured on (the GPU box has no .git), and tests/test_host_cpu.py holds the committed
+    report to the sources of the tree it is committed in."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for pat in KERNEL_SOURCE_GLOBS:
+        for f in sorted(glob.glob(os.path.join(ROOT, pat))):
+            h.update(os.path.relpath(f, ROOT).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pytest_deselected(items):
+    if items:
+        cfg = items[0].config
+        cfg._mbb_deselected = getattr(cfg, "_mbb_deselected", 0) + len(items)
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _PARITY:
+        return
+    # the report is the GPU suite's (`-m gpu`); a CPU session checks the oracle against the golden
+    # vectors with the same helpers and must not overwrite it
+    if session.config.getoption("markexpr", "").strip() != "gpu" and "MBB_PARITY_REPORT" not in os.environ:
         return
     import json
     path = os.environ.get("MBB_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.json"))
@@ -73,9 +101,19 @@ def pytest_sessionfinish(session, exitstatus):
             w = worst.setdefault(kind, {"observed_max": 0.0, "test": None})
             if v["observed_max"] >= w["observed_max"]:
                 w.update(observed_max=v["observed_max"], test=t, bound=v["bound"])
+    head = None
+    try:
+        import subprocess
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                              timeout=10).stdout.decode().strip() or None
+    except Exception:
+        pass
     json.dump({"tolerances": "SURVEY.md 8(c): band flux / f_nu rtol 1e-12, xmerge atol 1e-10, "
                              "lnL |d| <= 1e-10 max(1, |lnL|), diagonal and covariance likelihoods alike",
-               "exitstatus": int(exitstatus), "worst_per_kind": worst, "tests": _PARITY},
+               "exitstatus": int(exitstatus), "kernel_sources_sha16": kernel_sources_sha16(), "git_head": head,
+               "tests_run": int(session.testscollected), "tests_deselected": int(getattr(session.config, "_mbb_deselected", 0)),
+               "tests_failed": int(session.testsfailed), "tests_with_tolerance_checks": len(_PARITY),
+               "worst_per_kind": worst, "tests": _PARITY},
               open(path, "w"), indent=1, sort_keys=True)
 
 

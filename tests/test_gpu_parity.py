@@ -953,6 +953,16 @@ def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
     monkeypatch.setattr(like.context, "lnlike_batch", lambda p, **k: calls.append(len(p) // 5 if p.ndim == 1 else p.shape[0]) or orig(p, **k))
     mbb.EnsembleSampler(20, 5, Wrapper(like), seed=3, vectorize=False, pool=like).run_mcmc(p0, 2)
     assert calls == [20, 10, 10, 10, 10]
+    # ... but only when the function IS the likelihood: a posterior of the caller's own (a lambda that
+    # adds a prior; emcee's wrapper carrying args=) is applied row by row, and its value is what counts
+    del calls[:]
+    extra_prior = lambda x: like(x) - 0.5 * ((x[0] - 12.0) / 0.5) ** 2
+    rows = [p0[i] for i in range(6)]
+    got = like.map(extra_prior, rows)
+    assert calls == [1] * 6
+    assert got == [extra_prior(r) for r in rows] and got != list(like(np.asarray(rows)))
+    del calls[:]
+    assert like.map(like.__call__, rows) == list(like(np.asarray(rows))) and calls[0] == 6      # the bound method: one launch
     monkeypatch.undo()
 
     # mbb_fitter(sampler="emcee") with emcee-2 and emcee-3 shaped stand-ins

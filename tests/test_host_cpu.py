@@ -193,6 +193,26 @@ def test_likelihood_response_mode_and_files(tmp_path):
     assert like4._ctx is None and like4.ndata == 3
 
 
+def test_map_applies_a_foreign_function_row_by_row():
+    """likelihood.map is a pool adaptor: only this object's own call (bare, bound, or inside an
+    emcee-style wrapper without extra arguments) may be turned into one launch; any other function
+    is the caller's posterior and is applied to every row (no GPU needed for that)."""
+    like = _like()
+    like.set_phot([250.0, 350.0], [30.0, 40.0], [3.0, 4.0])
+    rows = [np.array([10.0 + i, 2.0, 600.0, 3.0, 40.0]) for i in range(4)]
+    assert like.map(lambda r: -0.5 * r[0], rows) == [-5.0, -5.5, -6.0, -6.5]
+
+    class Wrapper(object):                      # emcee 2's _function_wrapper with args=
+        def __init__(self, f, args):
+            self.f, self.args, self.kwargs = f, args, {}
+        def __call__(self, x):
+            return self.f(x, *self.args)
+    calls = []
+    w = Wrapper(lambda x, offset: calls.append(1) or x[0] + offset, (100.0,))
+    assert like.map(w, rows) == [110.0, 111.0, 112.0, 113.0] and len(calls) == 4
+    assert like.map(like, []) == []
+
+
 def test_no_gpu_fails_loudly():
     """There is no CPU fallback: without a device the call raises."""
     from mbb_emcee_amd import _native
@@ -238,6 +258,24 @@ def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
                                            "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert rc == 2 and len(out) == 1
     assert "WORLD_SIZE=2" in json.loads(out[0])["error"]
+
+
+def test_committed_parity_report_is_of_these_sources():
+    """profiles/rNN/parity_report.json (the observed maxima DESIGN.md section 2 quotes) must have been
+    measured on the kernel sources of the tree it is committed in: the report carries a hash of
+    everything the device library is built from, and a change to any of it without a fresh GPU run
+    of the suite (copy gpurun_out/parity_report.json over it) fails here."""
+    import glob
+    import json
+    from conftest import kernel_sources_sha16
+    reports = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "parity_report.json")))
+    assert reports, "no committed parity report"
+    rep = json.load(open(reports[-1]))
+    assert rep.get("exitstatus") == 0 and rep.get("tests_failed", 0) == 0, reports[-1]
+    assert rep.get("kernel_sources_sha16") == kernel_sources_sha16(), \
+        "%s was measured on other kernel sources than this tree's: rerun `pytest -m gpu` on the GPU box and " \
+        "commit its gpurun_out/parity_report.json" % os.path.relpath(reports[-1], ROOT)
+    assert rep.get("tests_run", 0) >= 140 and rep.get("tests_with_tolerance_checks", 0) >= 50
 
 
 def test_c_abi_exports_every_declared_symbol():
