@@ -508,18 +508,25 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
 // `rows` of them per wave, `aw` such waves per
 // workgroup.  A constructor is one dependent chain and a wave alone on its SIMD runs it fastest,
 // so the candidates are spread as thinly as the CUs the movers leave free allow.
-static void lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, int &rows, int &aw, int &n_ahead)
+// Returns false when only the densest packing (64 candidates per workgroup) would fit: measured, the
+// one-launch run is then slower than the launch train (480 walkers: 17.7 against 15.8 us per step;
+// 450 walkers, 32 per workgroup: 15.0 against 15.8 -- profiles/r03/walker_sweep.txt), so the host takes
+// the train from there (ensembles above ~454 walkers on 256 CUs).
+static bool lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, int &rows, int &aw, int &n_ahead)
 {
     const int pairs = 4 * half, free_cus = c->cu_count - movers;
     static const int plan[5][2] = {{1, 4}, {2, 4}, {4, 4}, {4, 8}, {4, 16}};
     rows = 1; aw = 4;
+    int chosen = 4;
     for (int i = 0; i < 5; ++i) {
         rows = plan[i][0]; aw = std::min(plan[i][1], threads / 64);
-        if ((pairs + rows * aw - 1) / (rows * aw) <= free_cus) break;
+        if ((pairs + rows * aw - 1) / (rows * aw) <= free_cus) { chosen = i; break; }
     }
-    if (c->opt_la_rows > 0) rows = (int)(c->opt_la_rows == 4 ? 4 : (c->opt_la_rows == 2 ? 2 : 1));
-    if (c->opt_la_waves > 0) aw = (int)std::min<long>(c->opt_la_waves, threads / 64);
+    bool worth = chosen < 4;
+    if (c->opt_la_rows > 0) { rows = (int)(c->opt_la_rows == 4 ? 4 : (c->opt_la_rows == 2 ? 2 : 1)); worth = true; }
+    if (c->opt_la_waves > 0) { aw = (int)std::min<long>(c->opt_la_waves, threads / 64); worth = true; }
     n_ahead = (pairs + rows * aw - 1) / (rows * aw);
+    return worth;
 }
 
 constexpr long kFlowStrikes = 3, kFlowRest = 16;
@@ -822,6 +829,9 @@ struct mbb_sampler_state {
     int spec_form = 0;                   // the sampler form whose state d_spec holds (0: none / not to be trusted)
     int flowm_parity = 0;                // form 7: the set of completion counters the next launch uses
     double *d_chain6 = nullptr;          // [shards][nsteps][2][nsrc*per][6]
+    double *d_chain_out = nullptr;       // the same chain in the caller's layout: [rows][nsteps][5] then [rows][nsteps]
+    double *h_chain = nullptr;           // ... and its pinned landing place on the host (a D2H into the caller's pageable,
+                                         // often untouched, arrays ran at ~1 GB/s: 18.8 us per step for 2000 stored steps)
     size_t chain_cap = 0;
     unsigned long long seed = 0, steps_done = 0;
     int rows() const { return nw * nsrc; }
@@ -863,7 +873,8 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     HIPCHK(hipStreamSynchronize(c->stream));
     if (s->pos6_owned) free_dev(s->d_pos6);
     else if (c->x.users > 0) --c->x.users;
-    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_spec);
+    free_dev(s->d_nacc); free_dev(s->d_err); free_dev(s->d_chain6); free_dev(s->d_chain_out); free_dev(s->d_spec);
+    if (s->h_chain) (void)hipHostFree(s->h_chain);
     free_dev(s->d_bak);
     delete s;
     return MBB_OK;
@@ -1040,10 +1051,11 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             HIPCHK(hipMemsetAsync(s->d_spec, 0, spec_words(R) * sizeof(double), c->stream));
         }
         int la_rows, la_aw, la_ahead;
-        lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead);
-        // form 7 where every (pair, candidate) gets a CU of its own; else form 5
+        const bool la_worth = lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead);
+        // form 7 where every (pair, candidate) gets a CU of its own; else form 5 while the workgroups
+        // that work ahead can be spread thinly enough to beat the launch train
         const bool merged = c->opt_flowm && 2 * (int)nl <= c->cu_count;
-        if (merged || la_ahead + (int)nl <= c->cu_count) {
+        if (merged || (la_worth && la_ahead + (int)nl <= c->cu_count)) {
             // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
@@ -1150,7 +1162,11 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     if (store && (size_t)nsteps * R * 6 > s->chain_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         free_dev(s->d_chain6); s->d_chain6 = nullptr; s->chain_cap = 0;
+        free_dev(s->d_chain_out); s->d_chain_out = nullptr;
+        if (s->h_chain) { (void)hipHostFree(s->h_chain); s->h_chain = nullptr; }
         HIPCHK(hipMalloc((void **)&s->d_chain6, (size_t)nsteps * R * 6 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&s->d_chain_out, (size_t)nsteps * R * 6 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&s->h_chain, (size_t)nsteps * R * 6 * sizeof(double), hipHostMallocDefault));
         s->chain_cap = (size_t)nsteps * R * 6;
     }
     if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, store))) return rc;
@@ -1160,8 +1176,29 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     HIPCHK(hipMemcpyAsync(rows.data(), s->d_pos6, rows.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(nacc.data(), s->d_nacc, nacc.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // The chain comes back in the caller's layout: re-ordered on the device, copied straight into the
+    // caller's arrays.  (A rank of a run sharded with the one-hop exchange holds its own walkers' part
+    // only: there the old way, through a staging vector, fills just those rows.)
+    const bool direct = store && !p.xchg;
+    bool via_pinned = false;
     std::vector<double> ch;
-    if (store) {
+    if (direct) {
+        const long long cells = (long long)R * nsteps;
+        hipLaunchKernelGGL(k_chain_reorder, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, c->stream,
+                           (const double *)s->d_chain6, s->d_chain_out, nsteps, nw, half, p.per, s->nsrc, p.shards);
+        HIPCHK(hipGetLastError());
+        // small chains go straight into the caller's arrays (the runtime stages them through its own pinned
+        // buffers); big ones land in ours first -- a D2H into megabytes of pageable, untouched memory runs at
+        // ~1 GB/s (measured: 3 MB direct 0.43 ms against 1.35 ms staged; 24 MB direct 25 ms against 6 ms staged)
+        via_pinned = (size_t)cells * 6 * sizeof(double) > ((size_t)8 << 20);
+        if (via_pinned) {
+            HIPCHK(hipMemcpyAsync(s->h_chain, s->d_chain_out, (size_t)cells * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        } else {
+            if (chain) HIPCHK(hipMemcpyAsync(chain, s->d_chain_out, (size_t)cells * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            if (lnprob) HIPCHK(hipMemcpyAsync(lnprob, s->d_chain_out + (size_t)cells * 5, (size_t)cells * sizeof(double),
+                                              hipMemcpyDeviceToHost, c->stream));
+        }
+    } else if (store) {
         ch.resize((size_t)nsteps * R * 6);
         HIPCHK(hipMemcpyAsync(ch.data(), s->d_chain6, ch.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
@@ -1197,6 +1234,11 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         return MBB_ERR_ARG;
     }
     if (s->flow_used) c->flow_strikes = 0;                  // a one-launch run that went through
+    if (direct && via_pinned) {
+        const size_t cells = (size_t)R * nsteps;
+        if (chain) memcpy(chain, s->h_chain, cells * 5 * sizeof(double));
+        if (lnprob) memcpy(lnprob, s->h_chain + cells * 5, cells * sizeof(double));
+    }
     for (int i = 0; i < R; ++i) {
         if (pos_out) for (int k = 0; k < 5; ++k) pos_out[(size_t)i * 5 + k] = rows[(size_t)i * 6 + k];
         if (lnprob_out) lnprob_out[i] = rows[(size_t)i * 6 + 5];
@@ -1209,7 +1251,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
                 const int src = (int)(w / p.per), loc = (int)(w - (size_t)src * p.per);
                 const int row = src * nw + (h ? half : 0) + r * p.per + loc;
                 if (naccepted) naccepted[row] = (double)nacc[((size_t)r * 2 + h) * nl + w];
-                if (!store) continue;
+                if (!store || direct) continue;
                 for (int t = 0; t < nsteps; ++t) {
                     const double *q = &ch[((((size_t)r * nsteps + t) * 2 + h) * nl + w) * 6];
                     if (chain) for (int k = 0; k < 5; ++k) chain[((size_t)row * nsteps + t) * 5 + k] = q[k];

@@ -1271,6 +1271,31 @@ static __global__ void k_flow_finish(double *pos6, double *spec, int nw, int nha
     pos6[i] = __hip_atomic_load(fv.st + ((size_t)slot * nw + row) * 8 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The chain of a run, from the order the launches wrote it in -- [shard][step][half][launch index][6] --
+// to the layout the caller gets (emcee's, results.py:153-154): chain [row][step][5] and lnprob
+// [row][step], behind one another in `out`.  One thread per (row, step).  Doing this on the device and
+// copying straight into the caller's arrays replaced a D2H into a staging vector plus three nested host
+// loops: 3.8 -> see profiles/r03 us per step of overhead for a stored run of 250 walkers.
+static __global__ void k_chain_reorder(const double *chain6, double *out, int nsteps, int nw, int half, int per,
+                                       int nsrc, int shards)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long R = (long long)nsrc * nw;
+    if (i >= R * nsteps) return;
+    const int row = (int)(i / nsteps), t = (int)(i - (long long)row * nsteps);
+    const int src = row / nw, rin = row - src * nw;
+    const int h = rin >= half ? 1 : 0, rh = rin - h * half;
+    const int r = rh / per, loc = rh - r * per;
+    const size_t nl = (size_t)nsrc * per;
+    const size_t w = (size_t)src * per + loc;
+    const double *q = chain6 + ((((size_t)r * nsteps + t) * 2 + h) * nl + w) * 6;
+    double *c = out + (size_t)i * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c[k] = q[k];
+    out[(size_t)R * nsteps * 5 + i] = q[5];
+    (void)shards;
+}
+
 // ---- sampler form 7 (k_flowm, mbb_flowm.hip.h): the state of a run, its set-up and its end
 struct FlowMView {
     double *prop, *row;

@@ -139,9 +139,10 @@ class DeviceEnsembleSampler(object):
                 barrier()
         N = int(N)
         lead = (self.nsources, self.k) if self.nsources > 1 else (self.k,)
-        # (zeros: sharded with the one-hop exchange only this rank's walkers are filled in)
-        chain = np.zeros(lead + (N, 5)) if storechain else None
-        lnp = np.zeros(lead + (N,)) if storechain else None
+        # (zeros where a run is sharded with the one-hop exchange: only this rank's walkers are filled in)
+        alloc = np.zeros if barrier else np.empty
+        chain = alloc(lead + (N, 5)) if storechain else None
+        lnp = alloc(lead + (N,)) if storechain else None
         pos = np.empty(lead + (5,))
         lnprob = np.empty(lead)
         nacc = np.zeros(lead)
@@ -165,8 +166,11 @@ class DeviceEnsembleSampler(object):
         self.naccepted = nacc
         if storechain:
             ax = len(lead)
-            self._chain = np.concatenate((self._chain, chain), axis=ax)
-            self._lnprob = np.concatenate((self._lnprob, lnp), axis=ax)
+            if self._chain.shape[ax] == 0:            # the usual case (after reset): no second copy of the chain
+                self._chain, self._lnprob = chain, lnp
+            else:
+                self._chain = np.concatenate((self._chain, chain), axis=ax)
+                self._lnprob = np.concatenate((self._lnprob, lnp), axis=ax)
         self._last = (pos, lnprob)
         return pos, lnprob, self.seed
 
