@@ -59,6 +59,10 @@ BANDS = ["PACS_70um", "PACS_100um", "PACS_160um", "SPIRE_250um",
          "SPIRE_350um", "SPIRE_500um", "SCUBA2_850um", "Bolocam_1.1mm"]
 TRUTH = np.array([12.0, 1.8, 600.0, 3.0, 40.0])
 NW_PER_GPU = 250
+# (rehearsals of the N > 1 machinery on one GPU only: a smaller ensemble per rank lets the ranks' one-launch
+# kernels all be resident on the shared device; the line is then marked invalid)
+if os.environ.get("MBB_BENCH_WALKERS_PER_GPU"):
+    NW_PER_GPU = int(os.environ["MBB_BENCH_WALKERS_PER_GPU"])
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
 N_SIMD = 1024                  # 256 CUs x 4
@@ -747,6 +751,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
         base["config"]["rehearsal"] = run["rehearsal"]
     if tried:
         base["config"]["collective_fallback_from"] = tried
+    if os.environ.get("MBB_BENCH_WALKERS_PER_GPU"):
+        base["valid_for_scaling"] = False
+        base["invalid"] = "MBB_BENCH_WALKERS_PER_GPU=%d: not BASELINE.json's ensemble, a rehearsal" % NW_PER_GPU
     if world > ndev:
         base["valid_for_scaling"] = False
         base["config"]["note"] = "%d ranks share %d device(s): a rehearsal of the exchange, not a scaling point" % (world, ndev)
@@ -970,6 +977,12 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
             roof["achieved"] = useful / (k_us * 1e-6) / 1e12
             roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
             roof["useful_counters_source"] = plain_src
+            # the same split for the issue bound: `valu_issue_frac` prices every instruction the launch
+            # executes (speculative work and polling included); this one only those of the form that
+            # computes nothing twice
+            pu = valu_roofline(plain, plain_src, k_us * 1e-6, "")
+            roof["valu_issue_frac_useful"] = pu["valu_issue_frac"]
+            roof["useful_valu_wave_instructions_per_half_step"] = pu["valu_wave_instructions_per_launch"]
         else:
             roof["note"] += "; no summary of the plain launch found: `achieved` is the executed count"
     alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb

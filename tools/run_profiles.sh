@@ -16,7 +16,10 @@ SHORT="--steps 300 --warmup 50 --no-extras"
 HS=$((2 * (60 + 50 + 300)))      # half-steps of the sampler in such a run: rehearsal 60 steps, warm-up, timed
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py > $O/stats.log 2>&1 || exit 2
+# kernel trace + stats of the timed region alone (default K and W): the dominant kernel's three launches
+# (rehearsal, warm-up, timed), tools/summarize_stats.py holds the timed one against the line's HIP events
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-extras > $O/stats_line.json 2> $O/stats.log || exit 2
+python3 tools/summarize_stats.py $O/stats $O/stats_line.json $O/kernel_time.json > /dev/null || exit 2
 echo "stats done"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py $SHORT > $O/fetch.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py $SHORT > $O/write.log 2>&1 || exit 4

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extras [--steps K --warmup W]` -> the dominant
+kernel's duration per half-step, launch by launch, next to the live HIP-event figure of the same run.
+
+    python tools/summarize_stats.py <rocprof output dir> <bench line json> <out.json>
+
+The one-launch sampler kernel covers a different number of half-steps in each of its launches (the 60-step
+rehearsal, the warm-up, the timed region), so "average duration per launch" means nothing for it: the
+summary gives every launch's duration divided by the half-steps it covered, and the timed one beside the
+line's `half_step_us` (HIP events over the timed region)."""
+import csv
+import glob
+import json
+import sys
+
+
+def main(run_dir, bench_json, out):
+    line = json.load(open(bench_json))
+    steps, warm = line["steps"], line["warmup"]
+    trace = glob.glob(run_dir + "/*/*_kernel_trace.csv")[0]
+    rows = [r for r in csv.DictReader(open(trace)) if "k_flowm<" in r["Kernel_Name"] or ", 5, " in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    covered = [60, warm, steps]                       # bench.py: rehearsal, warm-up, timed region (steps)
+    launches = []
+    for r, st in zip(rows, covered):
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        launches.append({"kernel": r["Kernel_Name"], "steps": st, "duration_us": dur, "us_per_half_step": dur / (2 * st),
+                         "workgroups": int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]),
+                         "vgprs": int(r["VGPR_Count"]), "sgprs": int(r["SGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]),
+                         "scratch_bytes": int(r["Scratch_Size"])})
+    res = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-extras --steps %d --warmup %d" % (steps, warm),
+           "launches_of_the_dominant_kernel": launches, "launches_seen": len(rows),
+           "timed_launch_us_per_half_step_rocprof": launches[-1]["us_per_half_step"] if len(launches) == 3 else None,
+           "half_step_us_hip_events_same_run": line.get("half_step_us"),
+           "value_same_run": line.get("value")}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
