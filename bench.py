@@ -394,18 +394,24 @@ def supervise(args):
         th = threading.Thread(target=collect, args=(procs[0].stdout,), daemon=True)
         th.start()
     deadline = time.time() + float(os.environ.get("MBB_BENCH_DEADLINE_S", "1500"))
-    timed_out = False
-    for r, pr in procs.items():
-        try:
-            pr.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
+    timed_out, orphaned_since = False, None
+    while any(pr.poll() is None for pr in procs.values()):
+        now = time.time()
+        if now > deadline:
             timed_out = True
-    if timed_out:
-        for pr in procs.values():
-            if pr.poll() is None:
-                pr.kill()                  # exactly the processes started above
-        for pr in procs.values():
-            pr.wait()
+            break
+        # a rank that has ended badly leaves the others waiting in a rendezvous or an exchange: they get
+        # half a minute to notice by themselves (bounded polls, gloo's own errors), then they are ended
+        if any(pr.poll() not in (None, 0) for pr in procs.values()):
+            orphaned_since = orphaned_since or now
+            if now - orphaned_since > 30.0:
+                break
+        time.sleep(0.05)
+    for pr in procs.values():
+        if pr.poll() is None:
+            pr.kill()                      # exactly the processes started above
+    for pr in procs.values():
+        pr.wait()
     if th is not None:
         th.join(timeout=10.0)
     rcs = {r: pr.returncode for r, pr in procs.items()}
