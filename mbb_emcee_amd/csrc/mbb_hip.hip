@@ -474,9 +474,19 @@ static size_t static_lds(const mbb_ctx *c)
 }
 static size_t dynamic_lds_limit(const mbb_ctx *c) { return 160 * 1024 - static_lds(c) - 2048; }
 
-// Walkers per workgroup and workgroup size.
-static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
+// Dynamic LDS of a k_lnlike workgroup of `wpb` walkers, without the staged passband tables and without
+// the inverse covariance.
+static size_t lnlike_lds_base(const mbb_ctx *c, int wpb)
 {
+    return (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->npart + 8 * (size_t)c->nb + 16) +
+           16 * (size_t)c->nb + 8 * ((size_t)c->nb + 2) + 64 * (size_t)wpb;
+}
+
+// Walkers per workgroup and workgroup size.  mid_staged: the launch is of the middle regime below and
+// wants its passband tables in LDS.
+static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads, bool *mid_staged = nullptr)
+{
+    if (mid_staged) *mid_staged = false;
     // Small batches (an emcee half-step) are latency bound: one walker per
     // workgroup with about one segment per wave, so the chip sees n workgroups.
     // The static tables (36-57 KB) allow two workgroups per CU, so beyond one walker
@@ -492,6 +502,17 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads)
         w = (n + cus * 2 - 1) / (cus * 2);
         if (w > 32) w = 32;
         t = 512;
+        // The middle regime, more than one walker per CU but at most 256 (round 3, tools/sweep_geometry.py,
+        // profiles/r03/geometry_sweep.txt): ONE workgroup of 1024 threads per CU with the passband tables
+        // staged in LDS once for all its walkers beats two narrower workgroups reading them through L2 by
+        // 13-17 % from 500 to 8192 rows, 7 % at 32768, 3 % at 65536; at 250 000 rows it is 3 % behind.
+        const long wm = std::min<long>(64, (n + cus - 1) / cus);
+        const size_t tables = (size_t)c->nchunk * 64 * 3 * sizeof(double);
+        if (n <= 256 * cus && c->opt_wpb <= 0 && c->opt_threads <= 0 && c->opt_stage != 0 &&
+            lnlike_lds_base(c, (int)wm) + (c->has_cov ? 8 * (size_t)c->nb * c->nb : 0) + tables + 16 <= dynamic_lds_limit(c)) {
+            w = wm; t = 1024;
+            if (mid_staged) *mid_staged = true;
+        }
     }
     if (c->opt_wpb > 0) w = c->opt_wpb > 64 ? 64 : c->opt_wpb;
     wpb = (int)w;
@@ -569,7 +590,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
     a.pars = d_pars; a.n = n; a.lnl = d_lnl; a.status = d_status; a.model_flux = d_mflux;
     int wpb, threads;
-    pick_geometry(c, n, wpb, threads);
+    bool mid_staged = false;
+    pick_geometry(c, n, wpb, threads, &mid_staged);
     a.wpb = wpb;
     a.debug = (int)c->opt_debug;
 #ifdef MBB_STAMPS
@@ -577,8 +599,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
 #endif
     int grid = (n + wpb - 1) / wpb;
     const size_t cov_bytes = c->has_cov ? 8 * (size_t)c->nb * c->nb : 0;
-    const size_t smem_base = (size_t)wpb * (sizeof(WalkerK) + 8 * (size_t)c->npart + 8 * (size_t)c->nb + 16) +
-                             16 * (size_t)c->nb + 8 * ((size_t)c->nb + 2) + 64 * (size_t)wpb;
+    const size_t smem_base = lnlike_lds_base(c, wpb);
     // the inverse covariance goes to LDS when it fits beside everything else
     const size_t dyn_limit = dynamic_lds_limit(c);
     a.cov_in_lds = (c->has_cov && smem_base + cov_bytes <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
@@ -599,7 +620,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     // workgroup it is 4-5 % slower than reading the tables through L2, because
     // 60 KB of LDS per workgroup caps residency at two workgroups per CU.
     const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);
-    bool stage = wpb == 1 && n <= c->cu_count && smem + table_bytes + 16 <= dyn_limit;
+    bool stage = ((wpb == 1 && n <= c->cu_count) || mid_staged) && smem + table_bytes + 16 <= dyn_limit;
     if (c->opt_stage == 0) stage = false;
     if (c->opt_stage == 1) stage = smem + table_bytes + 16 <= dyn_limit;
     const size_t smem_total = smem + (stage ? table_bytes + 16 : 0);

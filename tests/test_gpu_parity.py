@@ -669,8 +669,15 @@ def test_lds_staged_tables_identical(mbb, g_lnl):
     ctx.set_option("stage_tables", -1); ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0)
     like(pars[:100])
     assert ctx.info("last_stage") == 1           # auto: staged in the latency regime
-    like(np.tile(pars, (8, 1)))
-    assert ctx.info("last_stage") == 0           # auto: L2 path for big batches
+    mid = np.tile(pars, (8, 1))
+    got = like(mid)
+    # auto, up to 256 walkers per CU: one workgroup of 1024 threads per CU, tables staged once for all its walkers
+    assert ctx.info("last_stage") == 1 and ctx.info("last_threads") == 1024 and ctx.info("last_grid") <= 256
+    assert np.array_equal(got, np.tile(ref, 8), equal_nan=True)
+    big = np.tile(pars, (1 + 70000 // pars.shape[0], 1))
+    got = like(big)
+    assert ctx.info("last_stage") == 0 and ctx.info("last_threads") == 512      # auto: L2 path for big batches
+    assert np.array_equal(got, np.tile(ref, big.shape[0] // pars.shape[0]), equal_nan=True)
 
 
 # ------------------------------------------------------ shapes beyond the configs

@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import make_likelihood, TRUTH
 
 
+WPBS = (1, 2, 3, 4, 6, 8, 16, 24, 32, 48, 64)
+
+
 def main():
     ns = [int(a) for a in sys.argv[1:]] or [256, 500, 1000, 2048, 4096]
     like, flux = make_likelihood(0)
@@ -21,7 +24,7 @@ def main():
         dp = ctx.alloc(p.nbytes); dp.upload(p)
         dl, ds = ctx.alloc(n * 8), ctx.alloc(n * 4)
         best = None
-        for wpb, thr, stage in [(0, 0, -1)] + [(w, t, s) for w in (1, 2, 3, 4, 6, 8, 16) for t in (256, 512, 768, 1024) for s in (0, 1)]:
+        for wpb, thr, stage in [(0, 0, -1)] + [(w, t, s) for w in WPBS for t in (256, 512, 768, 1024) for s in (0, 1)]:
             ctx.set_option("walkers_per_group", wpb); ctx.set_option("block_threads", thr); ctx.set_option("stage_tables", stage)
             try:
                 ctx.lnlike_repeat_device(dp, n, dl, ds, 30); ctx.sync()
@@ -36,6 +39,8 @@ def main():
                 print("n=%5d  %-14s wpb %2d thr %4d stage %d grid %4d : %8.2f us  %.3g evals/s" % (n, tag, row[1], row[2], row[3], row[4], us, n / us * 1e6), flush=True)
             if best is None or us < best[0]:
                 best = row
+            if os.environ.get("SWEEP_ALL") and wpb:
+                print("        wpb %2d thr %4d stage %d grid %5d : %8.2f us" % (row[1], row[2], row[3], row[4], us), flush=True)
         print("n=%5d  %-14s wpb %2d thr %4d stage %d grid %4d : %8.2f us  %.3g evals/s" % (n, "best of sweep", best[1], best[2], best[3], best[4], best[0], n / best[0] * 1e6), flush=True)
         ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0); ctx.set_option("stage_tables", -1)
 
