@@ -1452,6 +1452,36 @@ def test_random_sampler_configurations_all_forms_equal(mbb, seed):
         assert forms[2] == 5 and forms[1] == 5, forms
 
 
+def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
+    """A stored run's chain is re-ordered on the device (k_chain_reorder) and comes back either straight
+    into the caller's arrays (under 8 MB) or through a pinned landing buffer (above): chain[walker, step]
+    must be the walker's position after that step and lnprobability[walker, step] its lnprob -- the last
+    step equals the returned state, every entry's lnprob is the likelihood of its position, and a step
+    where a walker did not move repeats the entry before (250 walkers x 40 steps: 0.5 MB; x 800: 9.6 MB;
+    the launch train and the one-launch form)."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(3).normal(size=(250, 5)))
+    rng = np.random.RandomState(4)
+    for look, nsteps in ((1, 40), (1, 800), (0, 40), (0, 800)):
+        ctx.set_option("lookahead_sampler", look)
+        s = mbb.DeviceEnsembleSampler(250, 5, like, seed=21)
+        pos, lnp, _ = s.run_mcmc(p0, nsteps)
+        ch, lp = s.chain, s.lnprobability
+        assert ch.shape == (250, nsteps, 5) and lp.shape == (250, nsteps)
+        assert np.array_equal(ch[:, -1, :], pos) and np.array_equal(lp[:, -1], lnp)
+        w, t = rng.randint(250, size=400), rng.randint(nsteps, size=400)
+        assert np.array_equal(like(ch[w, t]), lp[w, t])
+        moved = np.any(ch[:, 1:, :] != ch[:, :-1, :], axis=2)
+        assert np.array_equal(lp[:, 1:][~moved], lp[:, :-1][~moved])
+        assert abs(moved.mean() - s.acceptance_fraction.mean()) < 0.02 and 0.2 < moved.mean() < 0.7
+        if nsteps == 800 and look == 1:
+            big = (ch.copy(), lp.copy())
+        elif nsteps == 800:
+            assert np.array_equal(big[0], ch) and np.array_equal(big[1], lp)      # same chain whichever form stored it
+    ctx.set_option("lookahead_sampler", 1)
+
+
 def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     """The one-launch run needs every workgroup on the GPU at once.  A shape of the working-ahead
     workgroups that does not fit (forced through the options here; too many walkers elsewhere) is
