@@ -695,6 +695,11 @@ def worker_body(args, rank, world, local_rank, base, fail):
         def timed():
             smp.advance_async(warmup)
             ctx.sync(); barrier()
+            if dist is None:
+                # one GPU: clock, event, enqueue, event, stream wait, clock -- inside one native call
+                # (mbb_sampler_advance_timed), so that the harness around a 20-step region is not four
+                # Python-to-C round trips; the stream is idle before (sync above) and after (the wait inside)
+                return smp.advance_timed(steps)
             e0, e1 = ctx.event(), ctx.event()
             t0 = time.perf_counter()
             ctx.record(e0)

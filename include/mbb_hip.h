@@ -137,6 +137,13 @@ int mbb_sampler_set_state(mbb_ctx *ctx, void *sampler, const double *pos, const 
 int mbb_sampler_run(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a, double *chain,
                     double *lnprob, double *pos_out, double *lnprob_out, double *naccepted);
 int mbb_sampler_advance_async(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a);
+/* Measurement helper (bench.py's timed region on one GPU): nsteps steps as mbb_sampler_advance_async
+ * enqueues them, bracketed inside ONE call by the host clock and by two events on the context's stream:
+ * clock; event; enqueue; event; stream wait; clock.  The stream must be idle on entry (mbb_sync before).
+ * wall_s = host seconds from before the first event to after the wait; stream_ms = between the events.
+ * No reference counterpart. */
+int mbb_sampler_advance_timed(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a, double *wall_s,
+                              float *stream_ms);
 
 /* ---- SED-level entry points (parity + the modified_blackbody class) ----- */
 /* Replaces: modified_blackbody.__init__ (modified_blackbody.py:168-337) and

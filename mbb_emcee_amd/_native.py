@@ -40,6 +40,7 @@ SIGNATURES = {
     "mbb_sampler_set_state": (C.c_int, [_vp, _vp, _dp, _dp]),
     "mbb_sampler_run": (C.c_int, [_vp, _vp, C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]),
     "mbb_sampler_advance_async": (C.c_int, [_vp, _vp, C.c_int, C.c_double]),
+    "mbb_sampler_advance_timed": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "mbb_sed_prologue_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double,
                                          C.c_int, _dp, _ip]),
     "mbb_sed_eval_batch": (C.c_int, [_vp, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp,

@@ -179,6 +179,14 @@ class DeviceEnsembleSampler(object):
         ctx, h = self._handle()
         _native._check(ctx.lib.mbb_sampler_advance_async(ctx.h, h, int(N), self.a))
 
+    def advance_timed(self, N):
+        """N steps as advance_async enqueues them, timed inside one native call: (wall seconds from an
+        idle stream to an idle stream, stream milliseconds between two events).  Benchmarks."""
+        ctx, h = self._handle()
+        wall, ms = C.c_double(), C.c_float()
+        _native._check(ctx.lib.mbb_sampler_advance_timed(ctx.h, h, int(N), self.a, C.byref(wall), C.byref(ms)))
+        return wall.value, ms.value
+
     def __del__(self):
         try:
             if self._h is not None and self._ctx is not None and self._ctx.h:
