@@ -400,9 +400,10 @@ def supervise(args):
         if now > deadline:
             timed_out = True
             break
-        # a rank that has ended badly leaves the others waiting in a rendezvous or an exchange: they get
-        # half a minute to notice by themselves (bounded polls, gloo's own errors), then they are ended
-        if any(pr.poll() not in (None, 0) for pr in procs.values()):
+        # a rank that has ended -- badly, or after a wedged exchange made it leave at once -- leaves the
+        # others waiting in a rendezvous or an exchange: they get half a minute to notice by themselves
+        # (bounded polls, gloo's own errors) or to finish their own tear-down, then they are ended
+        if any(pr.poll() is not None for pr in procs.values()):
             orphaned_since = orphaned_since or now
             if now - orphaned_since > 30.0:
                 break
@@ -439,8 +440,12 @@ def supervise(args):
     main_line.update(parts)
     bad = {str(r): rc for r, rc in rcs.items() if rc != 0}
     if bad and main_line.get("value") is not None:
-        # the measured line stands; what died afterwards is said beside it
+        # the measured line stands; what died afterwards (while the other exchanges were being rehearsed)
+        # is said beside it, and does not turn a valid measurement into a failed run when rank 0 itself
+        # left in good order
         main_line["ranks_ended_badly"] = bad
+        if rcs.get(0) == 0:
+            worst = 0
     if timed_out:
         main_line["supervisor_timeout"] = True
     emit(main_line)
