@@ -405,7 +405,7 @@ def supervise(args):
         # (bounded polls, gloo's own errors) or to finish their own tear-down, then they are ended
         if any(pr.poll() is not None for pr in procs.values()):
             orphaned_since = orphaned_since or now
-            if now - orphaned_since > 30.0:
+            if now - orphaned_since > float(os.environ.get("MBB_BENCH_GRACE_S", "30")):
                 break
         time.sleep(0.05)
     for pr in procs.values():
@@ -452,8 +452,27 @@ def supervise(args):
     return worst
 
 
+def fake_worker(args, how):
+    """Test hook (tests/test_host_cpu.py; MBB_BENCH_FAKE_WORKER): a rank that touches nothing and behaves as
+    told, so that the supervisor's collecting, merging, waiting and ending of ranks can be tested without a GPU."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0 and "noline" not in how:
+        emit(dict(base_line(args, world), value=1.0e6 * world, ms_per_step=1.0))
+    if rank == 0 and "part" in how:
+        emit({"_part": "exchange_validation", "data": {"rccl": {"ok": True, "us_per_step": 20.0}}})
+    if rank == 1 and "crash1" in how:
+        os._exit(7)
+    if rank == 1 and "hang1" in how:
+        time.sleep(600)
+    if rank == 0 and "fail0" in how:
+        os._exit(3)
+    return 0
+
+
 def main():
     args = parse_args()
+    if os.environ.get("MBB_BENCH_FAKE_WORKER") and os.environ.get("MBB_BENCH_WORKER") == "1":
+        sys.exit(fake_worker(args, os.environ["MBB_BENCH_FAKE_WORKER"]))
     if os.environ.get("MBB_BENCH_WORKER") == "1" or (args.gpus == 1 and "WORLD_SIZE" not in os.environ):
         return worker(args)
     sys.exit(supervise(args))

@@ -252,6 +252,26 @@ def test_bench_starts_its_own_ranks_and_always_prints_one_line(argv):
     assert line["metric"].startswith("walker-likelihood")
 
 
+@pytest.mark.parametrize("how,rc_want,checks", [
+    ("part", 0, lambda d: d["value"] == 2.0e6 and d["exchange_validation"]["rccl"]["ok"] is True and "ranks_ended_badly" not in d),
+    ("part,crash1", 0, lambda d: d["value"] == 2.0e6 and d["ranks_ended_badly"] == {"1": 7}),
+    ("hang1", 0, lambda d: d["value"] == 2.0e6 and d["ranks_ended_badly"] == {"1": -9}),
+    ("noline,fail0", 3, lambda d: d["value"] is None and "without a line" in d["error"]),
+])
+def test_bench_supervisor_collects_merges_and_ends_ranks(how, rc_want, checks):
+    """The process the driver starts for --gpus N supervises its ranks (no GPU touched; fake ranks here): rank
+    0's measured line and the parts printed after it are merged into ONE line; a rank that crashes or hangs after
+    the measurement is named beside the line and ended, and does not turn the measurement into a failure; a
+    rank 0 that leaves without a line gives an error line and its status."""
+    import json
+    rc, out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         {"MBB_BENCH_FAKE_WORKER": how, "MBB_BENCH_GRACE_S": "1"})
+    assert len(out) == 1, out
+    line = json.loads(out[0])
+    assert rc == rc_want and checks(line), (rc, line)
+    assert line["n_gpus"] == 2
+
+
 def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
     import json
     rc, out = _run_bench(["--gpus", "3"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
