@@ -1043,6 +1043,15 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
     if roof is None:
         roof = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": None, "note": "no committed PMC summary found"}
+    # the same half-step priced with the survey's nominal weights instead of counted
+    # instructions -- per quadrature sample of the thick+alpha model 3 exp-class operations at 24 flop, one
+    # division at 10, four FMAs at 2 = 90 flop, x NQ samples x 125 walkers.  The polynomial tables removed
+    # every division and two of the three exp-class operations from the sample loop, so the counted figure
+    # (`achieved`) is the smaller one.
+    nominal = 90.0 * nq * half
+    roof["survey_weights"] = {"flop_per_sample": 90.0, "flop_per_half_step": nominal,
+                              "achieved": nominal / (k_us * 1e-6) / 1e12,
+                              "frac": nominal / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS}
     roof["traffic"] = traffic
     roof["kernel_avg_us"] = k_us
     roof["sample_arithmetic"] = arith
