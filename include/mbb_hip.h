@@ -207,6 +207,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * walker can end up making, and the SED constructor for every outcome still open, run ahead of the
  * decisions they depend on -- one workgroup per pair of walkers and candidate, ensembles up to two
  * walkers per CU ("form 7"); 0: only the proposals are prepared ahead ("form 5")),
+ * "merged_flow_pairs" (pairs of walkers a form-7 workgroup serves: 0 = the host's choice -- one while every
+ * pair and candidate has a CU of its own, two for the ensembles beyond, up to four walkers per CU; 1 or 2 force it),
  * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
  * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),

@@ -20,9 +20,11 @@ MBB_FLOW_INST(true, true)
 #undef MBB_FLOW_INST
 
 #include "mbb_flowm.hip.h"
-#define MBB_FLOWM_INST(OT, NA)                                         \
-    template __global__ void k_flowm<OT, NA, false>(const LikeArgs); \
-    template __global__ void k_flowm<OT, NA, true>(const LikeArgs);
+#define MBB_FLOWM_INST(OT, NA)                                            \
+    template __global__ void k_flowm<OT, NA, false, 1>(const LikeArgs); \
+    template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);  \
+    template __global__ void k_flowm<OT, NA, false, 2>(const LikeArgs); \
+    template __global__ void k_flowm<OT, NA, true, 2>(const LikeArgs);
 MBB_FLOWM_INST(false, false)
 MBB_FLOWM_INST(false, true)
 MBB_FLOWM_INST(true, false)

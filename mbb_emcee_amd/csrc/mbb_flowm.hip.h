@@ -61,10 +61,11 @@ constexpr int kFmStaged = 12;  //        Q and E waves that have copied their sh
 constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: proposal 0..4, (dim-1) ln z,
                                // ln u, the two penalties, the walker's row as it is (9..13)
 // dynamic LDS of a k_flowm launch besides the staged passband tables (bytes)
-__host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds)
+// (np = pairs of walkers a workgroup serves: the hand-over records and their control words are per pair)
+__host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)
 {
-    return kFmNB * sizeof(WalkerK) + 8 * (kFmNB * npart + 2 * nb + kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (kFmNC * 64) + 64 + 32;
+    return np * kFmNB * sizeof(WalkerK) + 8 * (np * kFmNB * npart + 2 * nb + np * kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (kFmNC * 64) + 64 * np + 32;
 }
 
 // an element and its check word
@@ -86,18 +87,18 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
 // role does not use is dead code there): band counts, the layout of the dynamic LDS, the run's state.
 #define MBB_FM_COMMON() \
     const int nun = a.nunit, npart = a.npart, nb = a.nb; \
-    const int w = (int)blockIdx.x >> 1, cand = (int)blockIdx.x & 1; \
-    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw); \
-    double *partial = reinterpret_cast<double *>(wk + kFmNB); \
-    double *mflux_all = partial + kFmNB * (size_t)npart; \
-    double *prop = mflux_all + 2 * nb; \
-    double *s_flux = prop + kFmNB * kFmProp; \
+    const int wbase = ((int)blockIdx.x >> 1) * NP, cand = (int)blockIdx.x & 1; \
+    WalkerK *wk0 = reinterpret_cast<WalkerK *>(smem_raw); \
+    double *partial0 = reinterpret_cast<double *>(wk0 + NP * kFmNB); \
+    double *mflux_all = partial0 + NP * kFmNB * (size_t)npart; \
+    double *prop0 = mflux_all + 2 * nb; \
+    double *s_flux = prop0 + NP * kFmNB * kFmProp; \
     double *s_ivar = s_flux + nb; \
     double *s_invcov = s_ivar + nb; \
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
     double *cscr = reinterpret_cast<double *>(s_band + nb + 1); \
-    int *ctl = reinterpret_cast<int *>(cscr + kFmNC * 64); \
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15; \
+    int *ctl0 = reinterpret_cast<int *>(cscr + kFmNC * 64); \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl0 + 16 * NP) - smem_raw) + 15) & ~(size_t)15; \
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
@@ -106,6 +107,18 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     const unsigned long long serial32 = a.flow_serial << 32; \
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \
     const int niter = a.persist;
+// One workgroup serves NP pairs of walkers (NP = 1 up to two walkers per CU; NP = 2 for the ensembles
+// beyond, up to four per CU): the roles take the pairs one after another in every half-step, each pair with
+// hand-over records and control words of its own.  Inside `for (vp ...)` these names are that pair's.
+#define MBB_FM_PAIRS_LOOP _Pragma("clang loop unroll(disable)")      /* (one body for both pairs, not two copies) */
+#define MBB_FM_PAIR(vp) \
+    const int w = wbase + (vp); \
+    if constexpr (NP > 1) { if (w >= a.n) continue; }      /* (an odd number of pairs: the last workgroup's second is not there) */ \
+    WalkerK *const wk = wk0 + (vp) * kFmNB; \
+    double *const partial = partial0 + (size_t)(vp) * kFmNB * npart; \
+    double *const prop = prop0 + (vp) * kFmNB * kFmProp; \
+    int *const ctl = ctl0 + 16 * (vp); \
+    (void)wk; (void)partial; (void)prop; (void)ctl
 // ... and the waits.  Hand-over words in LDS: a wave's LDS operations execute in the order it issued
 // them, so data then word (writer) and word then data (reader) need no wait in between, only the
 // compiler's order; every wait is bounded and gives up once the run's error flag is up.
@@ -139,7 +152,7 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
 #define MBB_WAVE_ID(t) __builtin_amdgcn_readfirstlane((t) >> 6)
 #endif
 
-template <bool OPTHIN, bool NOALPHA, bool STAGE>
+template <bool OPTHIN, bool NOALPHA, bool STAGE, int NP>
 __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 {
     CLikeArgs *const ka = MBB_KERNARGS();
@@ -170,9 +183,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     {
         MBB_ROLE_ARGS();
         MBB_FM_COMMON();
-        if (tid < 16) ctl[tid] = 0;
-        if (cand == 0 && tid < 12) {
-            const int r = (tid < 6 ? 0 : a.c_count) + w, e = tid < 6 ? tid : tid - 6;
+        if (tid < 16 * NP) ctl0[tid] = 0;
+        if (cand == 0 && tid < 12 * NP && wbase + tid / 12 < a.n) {
+            const int t12 = tid % 12;
+            const int r = (t12 < 6 ? 0 : a.c_count) + wbase + tid / 12, e = t12 < 6 ? t12 : t12 - 6;
             fm_put(fv.row + (size_t)r * kFmWords + 2 * e, a.pos6[(size_t)r * 6 + e], serial32);
         }
         if (blockIdx.x == 0 && tid < kFmRing * 16)
@@ -237,8 +251,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         // every share is in LDS before any of these waves reads a table
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         MBB_FM_ORDER();
-        if (lane == 0) __hip_atomic_fetch_add(ctl + kFmStaged, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        lds_wait(ctl + kFmStaged, ns);
+        if (lane == 0) __hip_atomic_fetch_add(ctl0 + kFmStaged, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_wait(ctl0 + kFmStaged, ns);
     }
     // (the chains of C and E are what a half-step waits for: ahead of the Q wave they share a SIMD with)
     if (role != 0) __builtin_amdgcn_s_setprio(3);
@@ -257,7 +271,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         if (qi < nun) us_first = a.unit_tab[qi];
         int tail_first = -1;
         if (qi < nun && us_first.w == 2) tail_first = a.tail_slot[4 * us_first.x + (lane >> 4)];
-        for (int it = 0; it < niter; ++it) {
+        for (int it = 0; it < niter; ++it)
+        MBB_FM_PAIRS_LOOP
+        for (int vp = 0; vp < NP; ++vp) {
+            MBB_FM_PAIR(vp);
             const int b = it & (kFmNB - 1);
             lds_wait(ctl + kFmReady + b, it + 1);
             FM_T(0);
@@ -323,7 +340,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
         MBB_PIN(a.has_gprior); MBB_PIN(a.invcov); MBB_PIN(a.cov_in_lds); MBB_PIN(a.pos6); MBB_PIN(a.chain6);
         MBB_PIN(a.nacc); MBB_PIN(a.errflag);
         double *mflux = mflux_all + (size_t)(role - 1 - kFmNC) * nb;     // (the two E waves run side by side)
-        for (int it = role - 1 - kFmNC; it < niter; it += 2) {
+        for (int it = role - 1 - kFmNC; it < niter; it += 2)
+        MBB_FM_PAIRS_LOOP
+        for (int vp = 0; vp < NP; ++vp) {
+            MBB_FM_PAIR(vp);
             const int b = it & (kFmNB - 1);
             const int L_step = a.step + (it >> 1), L_half = it & 1;
             const unsigned long long L_seed = a.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(it >> 1);
@@ -524,7 +544,10 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             }
             return v;
         };
-        for (int j = cb; j < niter; j += kFmNC) {
+        for (int j = cb; j < niter; j += kFmNC)
+        MBB_FM_PAIRS_LOOP
+        for (int vp = 0; vp < NP; ++vp) {
+            MBB_FM_PAIR(vp);
             const int hj = j & 1;
             const int sb = hj ? a.c_count : 0, ob = hj ? 0 : a.c_count;    // the half that moves in j / the other
             const int tn = a.step + (j >> 1);

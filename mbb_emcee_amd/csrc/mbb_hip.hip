@@ -40,21 +40,23 @@ MBB_FLOW_EXT(true, false)
 MBB_FLOW_EXT(true, true)
 #undef MBB_FLOW_EXT
 // ... and so is k_flowm, sampler form 7 (mbb_flowm.hip.h; only its LDS plan is needed here)
-template <bool OPTHIN, bool NOALPHA, bool STAGE>
+template <bool OPTHIN, bool NOALPHA, bool STAGE, int NP>
 __global__ void k_flowm(const LikeArgs a);
-#define MBB_FLOWM_EXT(OT, NA)                                         \
-    extern template __global__ void k_flowm<OT, NA, false>(const LikeArgs); \
-    extern template __global__ void k_flowm<OT, NA, true>(const LikeArgs);
+#define MBB_FLOWM_EXT(OT, NA)                                                   \
+    extern template __global__ void k_flowm<OT, NA, false, 1>(const LikeArgs); \
+    extern template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);  \
+    extern template __global__ void k_flowm<OT, NA, false, 2>(const LikeArgs); \
+    extern template __global__ void k_flowm<OT, NA, true, 2>(const LikeArgs);
 MBB_FLOWM_EXT(false, false)
 MBB_FLOWM_EXT(false, true)
 MBB_FLOWM_EXT(true, false)
 MBB_FLOWM_EXT(true, true)
 #undef MBB_FLOWM_EXT
 constexpr int kFmPropHost = 16;
-static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)   // = flowm_lds() of mbb_flowm.hip.h
+static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)   // = flowm_lds() of mbb_flowm.hip.h
 {
-    return 4 * sizeof(WalkerK) + 8 * (4 * npart + 2 * nb + 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (3 * 64) + 64 + 32;
+    return np * 4 * sizeof(WalkerK) + 8 * (np * 4 * npart + 2 * nb + np * 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
+           8 * (nb + 2) + 8 * (3 * 64) + 64 * np + 32;
 }
 #include "mbb_host_tables.h"
 
@@ -181,9 +183,11 @@ struct mbb_ctx {
     long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
+    long opt_flowm_pairs = 0; // pairs of walkers per form-7 workgroup: 0 = one while every (pair, candidate) has a CU, two beyond
+                              // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[64] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[80] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -537,7 +541,8 @@ static void pick_geometry(const mbb_ctx *c, int n, int &wpb, int &threads, bool 
 // one-launch run is then slower than the launch train (480 walkers: 17.7 against 15.8 us per step;
 // 450 walkers, 32 per workgroup: 15.0 against 15.8 -- profiles/r03/walker_sweep.txt), so the host takes
 // the train from there (ensembles above ~454 walkers on 256 CUs).
-static bool lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, int &rows, int &aw, int &n_ahead)
+static bool lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, int &rows, int &aw, int &n_ahead,
+                           bool *sparse = nullptr)
 {
     const int pairs = 4 * half, free_cus = c->cu_count - movers;
     static const int plan[5][2] = {{1, 4}, {2, 4}, {4, 4}, {4, 8}, {4, 16}};
@@ -548,6 +553,7 @@ static bool lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, 
         if ((pairs + rows * aw - 1) / (rows * aw) <= free_cus) { chosen = i; break; }
     }
     bool worth = chosen < 4;
+    if (sparse) *sparse = chosen <= 1;        // at most 8 candidates per working-ahead workgroup
     if (c->opt_la_rows > 0) { rows = (int)(c->opt_la_rows == 4 ? 4 : (c->opt_la_rows == 2 ? 2 : 1)); worth = true; }
     if (c->opt_la_waves > 0) { aw = (int)std::min<long>(c->opt_la_waves, threads / 64); worth = true; }
     n_ahead = (pairs + rows * aw - 1) / (rows * aw);
@@ -646,20 +652,26 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.n_ahead = 0;
         const int nq = std::min(threads / 64, 11);
         const int thr = (nq + 5) * 64;
-        a.cov_in_lds = (c->has_cov && flowm_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
-        const size_t sm = flowm_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
+        // pairs of walkers per workgroup: one where every (pair, candidate) gets a CU of its own, else two --
+        // the roles then take the two pairs one after the other in every half-step (mbb_flowm.hip.h)
+        const int np = c->opt_flowm_pairs == 1 ? 1 : (c->opt_flowm_pairs == 2 ? 2 : (2 * n <= c->cu_count ? 1 : 2));
+        const int wgs = 2 * ((n + np - 1) / np);
+        a.cov_in_lds = (c->has_cov && flowm_lds_bytes(c->nb, c->npart, true, np) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
+        const size_t sm = flowm_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0, np);
         const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
         const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
         if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
-        if (2 * n > c->cu_count)
+        if (wgs > c->cu_count)
             return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
-        static void (*const mtable[8])(const LikeArgs) = {
-            k_flowm<false, false, false>, k_flowm<false, false, true>, k_flowm<false, true, false>,
-            k_flowm<false, true, true>,   k_flowm<true, false, false>, k_flowm<true, false, true>,
-            k_flowm<true, true, false>,   k_flowm<true, true, true>};
-        const int mi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+#define MBB_FM_TABLE(NP)                                                                                        \
+    k_flowm<false, false, false, NP>, k_flowm<false, false, true, NP>, k_flowm<false, true, false, NP>,       \
+        k_flowm<false, true, true, NP>, k_flowm<true, false, false, NP>, k_flowm<true, false, true, NP>,      \
+        k_flowm<true, true, false, NP>, k_flowm<true, true, true, NP>
+        static void (*const mtable[16])(const LikeArgs) = {MBB_FM_TABLE(1), MBB_FM_TABLE(2)};
+#undef MBB_FM_TABLE
+        const int mi = (np - 1) * 8 + ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
         kern = mtable[mi];
-        c->last_wpb = 1; c->last_threads = thr; c->last_grid = 2 * n; c->last_smem = (long)sm_total;
+        c->last_wpb = np; c->last_threads = thr; c->last_grid = wgs; c->last_smem = (long)sm_total;
         c->last_stage = stg ? 1 : 0; c->last_smode = 7; c->last_ahead = 0;
         if (static_lds(c) + sm_total > 60 * 1024) {
             size_t &g = c->lds_granted[56 + mi];
@@ -670,7 +682,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                 g = want;
             }
         }
-        hipLaunchKernelGGL(kern, dim3(2 * n), dim3(thr), sm_total, c->stream, a);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(thr), sm_total, c->stream, a);
         HIPCHK(hipGetLastError());
         return MBB_OK;
     }
@@ -1076,11 +1088,17 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             HIPCHK(hipMemsetAsync(s->d_spec, 0, spec_words(R) * sizeof(double), c->stream));
         }
         int la_rows, la_aw, la_ahead;
-        const bool la_worth = lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead);
-        // form 7 where every (pair, candidate) gets a CU of its own; else form 5 while the workgroups
-        // that work ahead can be spread thinly enough to beat the launch train
-        const bool merged = c->opt_flowm && 2 * (int)nl <= c->cu_count;
-        if (merged || (la_worth && la_ahead + (int)nl <= c->cu_count)) {
+        bool la_sparse = false;
+        const bool la_worth = lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead, &la_sparse);
+        // Which one-launch form (profiles/r03/walker_sweep.txt, us per step): form 7 with a workgroup per (pair,
+        // candidate) while each has a CU of its own (6.1, up to 256 walkers); beyond, form 5 while its working-ahead
+        // workgroups hold at most 8 candidates each (9.6-10.2, up to ~340 walkers); then form 7 with two pairs per
+        // workgroup (11.1, flat up to 512 walkers; form 5 is at 13.6-15 there and the launch train at 15.7)
+        const bool form5 = la_worth && la_ahead + (int)nl <= c->cu_count;
+        const bool merged1 = c->opt_flowm && c->opt_flowm_pairs != 2 && 2 * (int)nl <= c->cu_count;
+        const bool merged2 = c->opt_flowm && c->opt_flowm_pairs != 1 && 2 * (((int)nl + 1) / 2) <= c->cu_count;
+        const bool merged = merged1 || (merged2 && (c->opt_flowm_pairs == 2 || !(form5 && la_sparse)));
+        if (merged || form5) {
             // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
@@ -1635,6 +1653,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
+    else if (!strcmp(name, "merged_flow_pairs")) c->opt_flowm_pairs = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "flow_min_steps")) c->opt_flow_min_steps = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;

@@ -1245,7 +1245,10 @@ def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
             ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0}),
-            ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1})]
+            ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1,
+                                              "merged_flow_pairs": 0}),
+            ("one launch, quadrature ahead, two pairs of walkers per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "merged_flow_pairs": 2})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
@@ -1366,6 +1369,7 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
             pos2, lnp2, _ = s.run_mcmc(None, 3)
             out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
             assert like.context.info("last_kernel_form") == {"plain": 1, "one launch, row by row": 5,
+                                                             "one launch, quadrature ahead, two pairs of walkers per workgroup": 7,
                                                              "one launch, quadrature ahead": 7}[form]
         for form, r in zip(_sampler_forms(None)[1:], out[1:]):
             for x, y in zip(out[0], r):
@@ -1447,9 +1451,10 @@ def test_random_sampler_configurations_all_forms_equal(mbb, seed):
             assert np.array_equal(x, y, equal_nan=True), (seed, form[0], names, nw, opts)
     assert forms[0] == 1
     if nw <= 256:
-        assert forms[2] == 7, forms                         # every (pair, candidate) has a CU
+        assert forms[2] == 7 and forms[3] == 7, forms       # every (pair, candidate) has a CU / two pairs share one
     elif nw <= 500:
-        assert forms[2] == 5 and forms[1] == 5, forms
+        # form 5 while its working-ahead workgroups stay sparse, form 7 with two pairs per workgroup beyond
+        assert forms[1] in (5, 1) and forms[2] in (5, 7) and forms[3] == 7, forms
 
 
 def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
