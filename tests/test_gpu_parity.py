@@ -647,6 +647,29 @@ def test_multi_source_device_sampler(mbb, g_lnl):
         rec_allclose(s2.chain[g, :, 0, :], hp, rtol=1e-13, kind="sampler vs host emulation")
 
 
+def test_multi_source_sampler_in_the_middle_regime(mbb, g_lnl):
+    """Many sources: a half-step's launch covers nsrc x nw/2 rows, more than one per CU -- the middle regime's
+    geometry (one 1024-thread workgroup per CU, several walkers each, passband tables staged in LDS, per-source
+    data read from global memory).  The chain must not depend on it: bitwise that of the same run forced to one
+    walker per 256-thread workgroup with the tables read through L2."""
+    ns, nw = 24, 40
+    bands, truths, flux, unc, multi = _multi_setup(mbb, g_lnl, ns, seed=7)
+    p0 = truths[:, None, :] * (1.0 + 0.02 * np.random.RandomState(3).normal(size=(ns, nw, 5)))
+    ctx = multi.context
+    out = []
+    for opts in ((0, 0, -1), (1, 256, 0)):
+        ctx.set_option("walkers_per_group", opts[0]); ctx.set_option("block_threads", opts[1]); ctx.set_option("stage_tables", opts[2])
+        s = mbb.DeviceEnsembleSampler(nw, 5, multi, seed=31)
+        pos, lnp, _ = s.run_mcmc(p0, 25)
+        out.append((pos, lnp, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy(),
+                    ctx.info("last_wpb"), ctx.info("last_threads"), ctx.info("last_stage")))
+    ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0); ctx.set_option("stage_tables", -1)
+    assert out[0][5:] == (2, 1024, 1) and out[1][5:] == (1, 256, 0), (out[0][5:], out[1][5:])
+    for x, y in zip(out[0][:5], out[1][:5]):
+        assert np.array_equal(x, y)
+    lnl_close(multi(out[0][2][:, :, -1, :]), out[0][3][:, :, -1])
+
+
 def test_lds_staged_tables_identical(mbb, g_lnl):
     """The LDS-staged variant of the kernel gives bitwise the same lnL as the
     variant that reads the passband tables through L2, at every geometry."""
