@@ -22,6 +22,7 @@
 #include <type_traits>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mbb_hip.h"
@@ -231,6 +232,15 @@ extern "C" int mbb_device_count(void)
     return n;
 }
 
+struct DeviceStatics {
+    bool ready = false;
+    int cu_count = 0;
+    double *d_poly_b = nullptr, *d_poly_c = nullptr;
+    std::vector<hipStream_t> idle_streams;
+};
+static std::mutex g_dev_mutex;
+static DeviceStatics g_dev[64];
+
 extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
 {
     if (!out) return fail(MBB_ERR_ARG, "out is null");
@@ -239,19 +249,42 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
     HIPCHK(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(MBB_ERR_ARG, "no such HIP device");
     HIPCHK(hipSetDevice(device));
+    // What is the same for every context of a device is made once per process and shared: the device's CU
+    // count and the two polynomial tables of the sample loop (read-only; never freed).  A catalogue loop makes
+    // a context per source: this took a new one from 6.2 ms to the stream and a few allocations
+    // (tools/probe_first_fit.py).
+    if (device >= 64) return fail(MBB_ERR_ARG, "device number out of range");
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        DeviceStatics &d = g_dev[device];
+        if (!d.ready) {
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, device));
+            d.cu_count = prop.multiProcessorCount;
+            std::vector<double> pb, pc;
+            mbbh::build_poly_tables(pb, pc);
+            HIPCHK(hipMalloc((void **)&d.d_poly_b, pb.size() * sizeof(double)));
+            HIPCHK(hipMalloc((void **)&d.d_poly_c, pc.size() * sizeof(double)));
+            HIPCHK(hipMemcpy(d.d_poly_b, pb.data(), pb.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(d.d_poly_c, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
+            d.ready = true;
+        }
+    }
     mbb_ctx *c = new mbb_ctx();
     c->device = device;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    c->cu_count = prop.multiProcessorCount;
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->cu_count = g_dev[device].cu_count;
+    c->d_poly_b = g_dev[device].d_poly_b;
+    c->d_poly_c = g_dev[device].d_poly_c;
+    // A stream costs ~5 ms to create (a hardware queue): the streams of contexts that have gone are kept, idle,
+    // for the contexts to come.
     {
-        std::vector<double> pb, pc;
-        mbbh::build_poly_tables(pb, pc);
-        HIPCHK(hipMalloc((void **)&c->d_poly_b, pb.size() * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&c->d_poly_c, pc.size() * sizeof(double)));
-        HIPCHK(hipMemcpy(c->d_poly_b, pb.data(), pb.size() * sizeof(double), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(c->d_poly_c, pc.data(), pc.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        std::vector<hipStream_t> &pool = g_dev[device].idle_streams;
+        if (!pool.empty()) { c->stream = pool.back(); pool.pop_back(); }
+    }
+    if (!c->stream) {
+        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (es != hipSuccess) { delete c; return fail(MBB_ERR_HIP, "hipStreamCreateWithFlags", es); }
     }
     *out = c;
     return MBB_OK;
@@ -269,7 +302,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->x.base) (void)xchg_free(c);
     free_dev(c->d_nu); free_dev(c->d_lnnu); free_dev(c->d_wt);
-    free_dev(c->d_poly_b); free_dev(c->d_poly_c);
+    // (d_poly_b / d_poly_c belong to the device, not to the context: mbb_ctx_create)
     free_dev(c->d_unit_tab); free_dev(c->d_band_rng); free_dev(c->d_tail_slot);
     free_dev(c->d_flux); free_dev(c->d_ivar); free_dev(c->d_invcov);
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
@@ -279,7 +312,14 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->d_sed_wk);
     for (int i = 0; i < 2; ++i)
         if (c->ev_timed[i]) (void)hipEventDestroy(c->ev_timed[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) {
+        // idle (synchronised above): kept for the next context of this device, up to a handful
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (c->device >= 0 && c->device < 64 && g_dev[c->device].idle_streams.size() < 8)
+            g_dev[c->device].idle_streams.push_back(c->stream);
+        else
+            (void)hipStreamDestroy(c->stream);
+    }
     delete c;
 }
 
@@ -853,6 +893,7 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
 }
 
 // ---- device-resident ensemble sampler ----------------------------------------
+constexpr size_t kChainDirectBytes = (size_t)8 << 20;   // stored chains up to this size go straight into the caller's arrays
 struct mbb_sampler_state {
     int nw = 0;            // walkers per source
     int nsrc = 1;          // independent ensembles advanced together
@@ -1209,7 +1250,14 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         if (s->h_chain) { (void)hipHostFree(s->h_chain); s->h_chain = nullptr; }
         HIPCHK(hipMalloc((void **)&s->d_chain6, (size_t)nsteps * R * 6 * sizeof(double)));
         HIPCHK(hipMalloc((void **)&s->d_chain_out, (size_t)nsteps * R * 6 * sizeof(double)));
-        HIPCHK(hipHostMalloc((void **)&s->h_chain, (size_t)nsteps * R * 6 * sizeof(double), hipHostMallocDefault));
+        // (a landing buffer the host refuses to pin -- a limit on locked memory -- is done without: the chain
+        // then goes straight into the caller's arrays, slower for big chains, never wrong)
+        // (only chains big enough to go through it get one: pinning costs a few hundred microseconds)
+        if ((size_t)nsteps * R * 6 * sizeof(double) > kChainDirectBytes &&
+            hipHostMalloc((void **)&s->h_chain, (size_t)nsteps * R * 6 * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            s->h_chain = nullptr;
+        }
         s->chain_cap = (size_t)nsteps * R * 6;
     }
     if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, store))) return rc;
@@ -1233,7 +1281,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         // small chains go straight into the caller's arrays (the runtime stages them through its own pinned
         // buffers); big ones land in ours first -- a D2H into megabytes of pageable, untouched memory runs at
         // ~1 GB/s (measured: 3 MB direct 0.43 ms against 1.35 ms staged; 24 MB direct 25 ms against 6 ms staged)
-        via_pinned = (size_t)cells * 6 * sizeof(double) > ((size_t)8 << 20);
+        via_pinned = s->h_chain != nullptr && (size_t)cells * 6 * sizeof(double) > kChainDirectBytes;
         if (via_pinned) {
             HIPCHK(hipMemcpyAsync(s->h_chain, s->d_chain_out, (size_t)cells * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         } else {

@@ -14,6 +14,7 @@ run on current numpy or that is internally inconsistent:
       once instead of being re-interpreted.
 """
 import math
+import copy
 import os
 import re
 
@@ -374,6 +375,9 @@ class response(object):
         return "{0:s} lambda_eff: {1:0.1f} [um]".format(self._name, self._effective_wave)
 
 
+_BUILTIN_WHEEL = {}
+
+
 class response_set(object):
     """A named set of passbands -- the filter wheel (response.py:642-840)."""
 
@@ -397,10 +401,18 @@ class response_set(object):
             if len(rows) == 0:
                 raise IOError("No data read from {:s}".format(inputfile))
         self._responses.clear()
+        if inputfile is None and _BUILTIN_WHEEL:
+            # the built-in wheel is set up once per process (18 curves: 3 ms) and handed out as shallow copies --
+            # setup() replaces a passband's arrays, it never writes into them
+            for name, resp in _BUILTIN_WHEEL.items():
+                self._responses[name] = copy.copy(resp)
+            return
         for r in rows:
             self.add(str(r[0]), str(r[1]), str(r[2]).lower(), str(r[3]).lower(),
                      str(r[4]).lower(), str(r[5]).lower(), float(r[6]), float(r[7]),
                      dir=indir)
+        if inputfile is None:
+            _BUILTIN_WHEEL.update((name, copy.copy(resp)) for name, resp in self._responses.items())
 
     def add(self, name, spec, xtype, xunits, senstype, normtype, xnorm, normparam, dir=None):
         resp = response(name)
