@@ -47,6 +47,23 @@ def test_add_special_kat():
     assert "ZSpec_box_1050um_100" not in wheel
 
 
+def test_builtin_wheel_is_cached_not_shared():
+    """The built-in wheel is set up once per process and handed out as copies: what one wheel adds, deletes or
+    sets up again never shows in another."""
+    from mbb_emcee_amd import response_set
+    a = response_set()
+    before = (a["SPIRE_350um"].effective_wavelength, a["SPIRE_350um"]._nresp)
+    a.add_special("ZSpec_box_1050um_100")
+    del a["SPIRE_250um"]
+    a["SPIRE_350um"].setup("box_300_20", xtype="freq", xunits="ghz", senstype="energy", normtype="flat", xnorm=300.0, normparam=0.0)
+    b = response_set()
+    assert "SPIRE_250um" in b and "ZSpec_box_1050um_100" not in b and len(b) == 18
+    assert (b["SPIRE_350um"].effective_wavelength, b["SPIRE_350um"]._nresp) == before
+    assert a["SPIRE_350um"]._nresp != b["SPIRE_350um"]._nresp
+    assert b["SPIRE_500um"] is not response_set()["SPIRE_500um"]
+    np.testing.assert_allclose(b["SPIRE_250um"].normfac, 3.0796e-3, atol=1e-4)
+
+
 def test_passband_tables_match_reference(g_pb):
     """G1: wave, freq, response, trapezoid weights, normalisation and effective
     wavelength of every wheel band and every special type, as the reference
