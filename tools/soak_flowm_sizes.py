@@ -8,7 +8,9 @@ import mbb_emcee_amd as mbb
 from bench import make_likelihood, TRUTH
 
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-for nw in (256, 254, 130, 64, 18, -250):
+# (further arguments: ensemble sizes; beyond 256 walkers form 7 serves two pairs of walkers per workgroup)
+sizes = [int(a) for a in sys.argv[2:]] or [256, 254, 130, 64, 18, -250]
+for nw in sizes:
     like, flux = make_likelihood(0)
     if nw < 0:
         # a covariance matrix: the two accept-test waves of a workgroup each need a scratch row of their own
