@@ -1510,6 +1510,25 @@ def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
     ctx.set_option("lookahead_sampler", 1)
 
 
+def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
+    """mbb_sampler_advance_timed (bench.py's timed region on one GPU) enqueues exactly what advance_async does --
+    the same chain afterwards, whatever form the run takes (form 7, form 7 with two pairs per workgroup, form 5,
+    the launch train) -- and returns a wall time that covers the stream time."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    for nw, form in ((60, 7), (300, 5), (400, 7), (600, 1)):
+        p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
+        a = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
+        b = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
+        a.run_mcmc(p0, 5, storechain=False); b.run_mcmc(p0, 5, storechain=False)
+        a.advance_async(40); ctx.sync()
+        wall, ms = b.advance_timed(40)
+        assert ctx.info("last_kernel_form") == form
+        assert 0.0 < ms * 1e-3 <= wall < 1.0
+        ra, rb = a.run_mcmc(None, 3), b.run_mcmc(None, 3)
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])
+
+
 def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     """The one-launch run needs every workgroup on the GPU at once.  A shape of the working-ahead
     workgroups that does not fit (forced through the options here; too many walkers elsewhere) is
