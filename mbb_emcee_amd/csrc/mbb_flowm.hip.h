@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     // diagnostic build: cycles a wave spends in each part of its loop, summed over the launch
     // -> stamps[(workgroup * 16 + wave) * 8 + part] (tools/probe_stamps_flowm.py)
 #ifdef MBB_STAMPS
+    // (when this workgroup got past its set-up, on the clock all CUs share: tools/probe_flowm_start.py)
+    if (tid == 0 && a.stamps) a.stamps[(1u << 20) + 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #define FM_T(kk) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[kk] += t_now - t_last; t_last = t_now; } while (0)
