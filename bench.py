@@ -134,43 +134,69 @@ def cpu_baseline(like, flux, pars):
             "single_thread_value": rate1}, ref[:250]
 
 
+def profile_files(pattern):
+    """Committed summaries matching `pattern`, newest round (then newest name) first."""
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)), reverse=True)
+
+
 def newest_profile(pattern):
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pattern)))
-    return files[-1] if files else None
+    files = profile_files(pattern)
+    return files[0] if files else None
 
 
-def measured_traffic(kernel_substr):
-    """HBM-side bytes per launch of the dominant kernel from the newest committed
-    rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of this same
-    command; tools/summarize_pmc.py).  bench.py cannot run the profiler on itself."""
-    f = newest_profile("pmc_traffic*.json")
-    if not f:
-        return None, None
-    try:
-        d = json.load(open(f))
-        for k, v in d["kernels"].items():
-            if kernel_substr in k:
-                return v["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
-    except Exception:
-        pass
-    return None, None
+def lookup_kernel(pattern, kernel_substr, prefer=None):
+    """(entry, source file, error): the kernel's entry in the newest committed summary matching `pattern`
+    that holds it.  A newer summary that lacks the kernel is named in the error text even when an older
+    one answers, so a renamed instantiation cannot hide behind stale counters."""
+    files = profile_files(pattern)
+    if not files:
+        return None, None, "no profiles/r*/%s committed" % pattern
+    missed = []
+    for f in files:
+        src = os.path.relpath(f, ROOT)
+        try:
+            d = json.load(open(f))
+            ks = d.get("kernels", {d.get("kernel", ""): d})
+        except Exception as e:      # noqa
+            missed.append("%s: %r" % (src, e))
+            continue
+        k, v = find_kernel(ks, kernel_substr, prefer)
+        if v is not None:
+            return v, src, ("older summary used; " + "; ".join(missed)) if missed else None
+        missed.append("%s holds no kernel matching %r (it has: %s)" % (src, kernel_substr, "; ".join(sorted(ks))))
+    return None, os.path.relpath(files[0], ROOT), "; ".join(missed[:2])
 
 
-def measured_valu(pattern, kernel_substr):
-    """VALU / fp64 instruction counts per launch from the newest committed PMC summary
-    (tools/summarize_valu.py)."""
-    f = newest_profile(pattern)
-    if not f:
-        return None, None
-    try:
-        d = json.load(open(f))
-        ks = d.get("kernels", {d.get("kernel", ""): d})
-        for k, v in ks.items():
-            if kernel_substr in k:
-                return v, os.path.relpath(f, ROOT)
-    except Exception:
-        pass
-    return None, None
+def kernel_key(form, opthin=False, noalpha=False, staged=True, pairs=None):
+    """The substring that names a kernel instantiation in rocprofv3's output, from what was launched
+    (`last_kernel_form`) -- never a literal copied from an old summary: round 3 lost its headline roofline
+    to a template parameter added after the literal was written.  k_flowm's trailing parameter (pairs of
+    walkers per workgroup) is left open unless `pairs` is given."""
+    b = ("false", "true")
+    if form == 7:
+        key = "k_flowm<%s, %s, %s," % (b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
+        return key + (" %d>" % pairs if pairs else "")
+    return "k_lnlike<%s, %s, %d, %s>" % (b[bool(opthin)], b[bool(noalpha)], form, b[bool(staged)])
+
+
+def find_kernel(kernels, key, prefer=None):
+    """The entry of a summary's `kernels` whose name contains `key` (`prefer`: a second substring that
+    decides between several hits).  Returns (name, entry) or (None, None)."""
+    hits = [(k, v) for k, v in kernels.items() if key in k]
+    if prefer:
+        hits = [h for h in hits if prefer in h[0]] or hits
+    return hits[0] if hits else (None, None)
+
+
+def measured_traffic(kernel_substr, prefer=None):
+    """HBM-side bytes of the dominant kernel from the committed rocprofv3 PMC summaries (separate FETCH_SIZE /
+    WRITE_SIZE passes of this same command; tools/summarize_pmc.py).  bench.py cannot run the profiler on itself."""
+    return lookup_kernel("pmc_traffic*.json", kernel_substr, prefer)
+
+
+def measured_valu(pattern, kernel_substr, prefer=None):
+    """VALU / fp64 instruction counts per launch from the committed PMC summaries (tools/summarize_valu.py)."""
+    return lookup_kernel(pattern, kernel_substr, prefer)
 
 
 def valu_roofline(pm, pm_src, kernel_s, label):
@@ -195,6 +221,123 @@ def valu_roofline(pm, pm_src, kernel_s, label):
             "issue_cost_model": "fp64 %.1f / other %.1f cycles per wave instruction per SIMD, %d SIMDs at "
                                 "%.1f GHz (profiles/r02/issue_cost_v2.txt)" % (CYC_FP64, CYC_OTHER, N_SIMD, CLOCK_HZ / 1e9),
             "kernel_us": kernel_s * 1e6, "counters_source": pm_src}
+
+
+def dominant_kernel_roofline(form, pairs, staged, k_us, steps, kern_label, nq, nb, half):
+    """`roofline` and `roofline_hbm` of the dominant kernel from the half-step time measured in this run and
+    the newest committed counter summaries (profiles/rNN/pmc_valu_cfg2*, pmc_valu_plain*, pmc_traffic*).
+    Touches no GPU: tests/test_host_cpu.py calls it for every sampler form.
+
+    `achieved` / `frac` are SURVEY.md 8(d)(ii)'s ALGORITHMIC flops -- 90 flop per quadrature sample of the
+    thick+alpha model (3 exp-class operations at 24, one division at 10, four FMAs at 2; fnu.pyx:82-108) x NQ
+    samples (response.py:572-576) x the walkers a half-step moves -- over the measured half-step, against the
+    fp64 vector peak; they need no committed file and are never null.  `counted` prices the same half-step
+    with the fp64 instructions the profiler counted (fewer than the nominal weights: the polynomial tables
+    removed the division and two of the three exp-class operations per sample), `executed_*` with everything
+    the launch ran, work for outcomes that did not happen included.  A summary that lacks the kernel is said
+    in `error`, never passed over."""
+    # ---- rooflines of the dominant kernel.  The one-launch run's launches cover different
+    # numbers of half-steps, so its counters are taken per half-step (all launches of the
+    # profiled run / the half-steps they cover: tools/summarize_valu.py) and priced against
+    # the half-step time measured above; a launch of the timed region is 2 K of those.
+    kname = kernel_key(form, staged=staged, pairs=pairs if form == 7 else None)
+    roof_errors = []
+    pm, pm_src, err = measured_valu("pmc_valu_cfg2*.json", kname)
+    if err:
+        roof_errors.append(err)
+    per_launch = 1.0
+    if pm and form in (5, 7) and "counters_per_half_step" in pm:
+        pm = dict(pm)
+        pm["counters_per_launch"] = pm["counters_per_half_step"]
+        per_launch = 2.0 * min(steps, 4096)
+    elif pm and form in (5, 7):
+        roof_errors.append("%s: the entry of %s has no counters_per_half_step" % (pm_src, kname))
+        pm = None
+    roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
+    if roof and form in (5, 7):
+        roof["unit_of_counts"] = ("one half-step (125 walkers moved; the quadrature of 250 candidates and the constructor of up to "
+                                  "1000 variants run for them)" if form == 7 else
+                                  "one half-step (125 walkers moved, 250 proposals prepared ahead)")
+        roof["half_steps_per_launch"] = per_launch
+        roof["fp64_flops_per_launch"] = roof["fp64_flops_per_launch"] * per_launch
+        roof["fp64_flops_per_half_step"] = roof["fp64_flops_per_launch"] / per_launch
+        roof["valu_wave_instructions_per_half_step"] = roof.pop("valu_wave_instructions_per_launch")
+        roof["fp64_wave_instructions_per_half_step"] = roof.pop("fp64_wave_instructions_per_launch")
+        roof["kernel_us"] = k_us * per_launch
+        roof["half_step_us"] = k_us
+        roof["note"] = (("the counts include the work for outcomes that did not happen -- half of the quadrature, up to three "
+                         "quarters of the constructor -- and the instructions spent polling; `useful_fp64_flops_per_half_step` "
+                         "is the same chain's count in the form that computes nothing twice (the plain launch train)")
+                        if form == 7 else
+                        ("the counts include the proposals prepared for the outcome that did not happen (half of the "
+                         "constructor work) and the instructions spent polling"))
+    if roof and form == 7:
+        # `achieved` is algorithmic work over time: the fp64 flops of a half-step in the form that computes
+        # nothing twice (the plain launch of 125 walkers, counted in its own profiler pass); what the launch
+        # executes, outcomes that did not happen included, is kept beside it
+        plain, plain_src, err = measured_valu("pmc_valu_plain*.json", kernel_key(1, staged=staged))
+        if err:
+            roof_errors.append(err)
+        roof["executed_tflops"] = roof["achieved"]
+        roof["executed_fp64_flops_per_half_step"] = roof["fp64_flops_per_half_step"]
+        if plain:
+            useful = plain["fp64_flops_per_launch"]
+            roof["useful_fp64_flops_per_half_step"] = useful
+            roof["achieved"] = useful / (k_us * 1e-6) / 1e12
+            roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
+            roof["useful_counters_source"] = plain_src
+            # the same split for the issue bound: `valu_issue_frac` prices every instruction the launch
+            # executes (speculative work and polling included); this one only those of the form that
+            # computes nothing twice
+            pu = valu_roofline(plain, plain_src, k_us * 1e-6, "")
+            roof["valu_issue_frac_useful"] = pu["valu_issue_frac"]
+            roof["useful_valu_wave_instructions_per_half_step"] = pu["valu_wave_instructions_per_launch"]
+        else:
+            roof["note"] += "; no summary of the plain launch found: `achieved` is the executed count"
+    alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb      # SURVEY.md 8(d)
+    tr, traffic_src, err = measured_traffic(kname)
+    if err:
+        roof_errors.append(err)
+    traffic = None
+    if tr:
+        traffic = tr.get("traffic_bytes_per_half_step" if form in (5, 7) else "traffic_bytes_per_launch")
+        if traffic is None:
+            roof_errors.append("%s: the entry of %s has no per-half-step traffic" % (traffic_src, kname))
+    hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+           "traffic_ratio": (traffic / alg_bytes) if traffic else None, "traffic_source": traffic_src,
+           "algorithmic_bytes_per_launch": alg_bytes * per_launch, "algorithmic_bytes_per_half_step": alg_bytes,
+           "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per half-step.  "
+                   + ("Per half-step; the tables are staged once per launch, what crosses the fabric every half-step "
+                      "is the hand-over between workgroups (records, rows, the words they poll)" if form in (5, 7) else
+                      "The traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
+                      "kernel code reaching each of the 8 XCD L2s once per launch")}
+    if roof is None:
+        roof = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": None}
+    # SURVEY.md 8(d)(ii): the same half-step priced with the survey's nominal weights instead of counted
+    # instructions -- per quadrature sample of the thick+alpha model 3 exp-class operations at 24 flop, one
+    # division at 10, four FMAs at 2 = 90 flop, x NQ samples x 125 walkers.  The polynomial tables removed
+    # every division and two of the three exp-class operations from the sample loop, so the counted figure
+    # (`achieved`) is the smaller one.
+    nominal = 90.0 * nq * half
+    roof["survey_weights"] = {"flop_per_sample": 90.0, "flop_per_half_step": nominal,
+                              "achieved": nominal / (k_us * 1e-6) / 1e12,
+                              "frac": nominal / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+    roof["traffic"] = traffic
+    if roof_errors:
+        # never a silent null: say which committed summary lacks which kernel
+        roof["error"] = "; ".join(roof_errors)
+    # the headline pair is the algorithmic one (see the docstring); the profiler-counted figure stays beside it
+    roof["counted"] = {"achieved": roof.get("achieved"), "frac": roof.get("frac"), "unit": "TFLOP/s",
+                       "what": "fp64 flops the profiler counted for a half-step of the form that computes nothing "
+                               "twice (useful_fp64_flops_per_half_step) over the same time" if form == 7 else
+                               "fp64 flops the profiler counted for this launch over the same time"}
+    roof["achieved"] = roof["survey_weights"]["achieved"]
+    roof["frac"] = roof["survey_weights"]["frac"]
+    roof["algorithmic_flops_per_half_step"] = nominal
+    roof["definition"] = "achieved = 90 flop x NQ x walkers moved per half-step / measured half-step (SURVEY.md 8d ii)"
+    return roof, hbm
 
 
 def user_runs(like, pos):
@@ -760,7 +903,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             teardown()
             return res
         res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, form=ctx.info("last_kernel_form"),
-                   us_per_step=1e6 * elapsed / steps)
+                   us_per_step=1e6 * elapsed / steps,
+                   # which instantiation that was (form 7: last_wpb = pairs of walkers per workgroup)
+                   pairs=ctx.info("last_wpb"), staged=bool(ctx.info("last_stage")))
         return res
 
     tried, validation, run = [], dict(skipped), None
@@ -826,7 +971,8 @@ def worker_body(args, rank, world, local_rank, base, fail):
             out["kernel_avg_us"] = k_us
         out["half_step_us"] = k_us
         if world == 1 and not args.no_extras:
-            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form))
+            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form,
+                              pairs=run["pairs"], staged=run["staged"]))
         elif world > 1:
             alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
             out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None,
@@ -881,7 +1027,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
         dist.destroy_process_group()
 
 
-def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
+def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True):
     """Everything on the line besides the timed region (rank 0, one GPU)."""
     import mbb_emcee_amd as mbb
     out = {}
@@ -968,91 +1114,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
                       "constants -- the exp + two degree-7 polynomials per sample and nothing else" % nchunk,
              "probe_seconds": sec, "probe_shader_clock_mhz": roof_mhz, "samples_per_launch": half * nq, "lane_slots_per_launch": slots_per_launch}
 
-    # ---- rooflines of the dominant kernel.  The one-launch run's launches cover different
-    # numbers of half-steps, so its counters are taken per half-step (all launches of the
-    # profiled run / the half-steps they cover: tools/summarize_valu.py) and priced against
-    # the half-step time measured above; a launch of the timed region is 2 K of those.
-    kname = "k_flowm<false, false, true>" if form == 7 else "k_lnlike<false, false, %d, true>" % form
-    pm, pm_src = measured_valu("pmc_valu_cfg2*.json", kname)
-    per_launch = 1.0
-    if pm and form in (5, 7) and "counters_per_half_step" in pm:
-        pm = dict(pm)
-        pm["counters_per_launch"] = pm["counters_per_half_step"]
-        per_launch = 2.0 * min(args.steps, 4096)
-    elif form in (5, 7):
-        pm = None
-    roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
-    if roof and form in (5, 7):
-        roof["unit_of_counts"] = ("one half-step (125 walkers moved; the quadrature of 250 candidates and the constructor of up to "
-                                  "1000 variants run for them)" if form == 7 else
-                                  "one half-step (125 walkers moved, 250 proposals prepared ahead)")
-        roof["half_steps_per_launch"] = per_launch
-        roof["fp64_flops_per_launch"] = roof["fp64_flops_per_launch"] * per_launch
-        roof["fp64_flops_per_half_step"] = roof["fp64_flops_per_launch"] / per_launch
-        roof["valu_wave_instructions_per_half_step"] = roof.pop("valu_wave_instructions_per_launch")
-        roof["fp64_wave_instructions_per_half_step"] = roof.pop("fp64_wave_instructions_per_launch")
-        roof["kernel_us"] = k_us * per_launch
-        roof["half_step_us"] = k_us
-        roof["note"] = (("the counts include the work for outcomes that did not happen -- half of the quadrature, up to three "
-                         "quarters of the constructor -- and the instructions spent polling; `useful_fp64_flops_per_half_step` "
-                         "is the same chain's count in the form that computes nothing twice (the plain launch train)")
-                        if form == 7 else
-                        ("the counts include the proposals prepared for the outcome that did not happen (half of the "
-                         "constructor work) and the instructions spent polling"))
-    if roof and form == 7:
-        # `achieved` is algorithmic work over time: the fp64 flops of a half-step in the form that computes
-        # nothing twice (the plain launch of 125 walkers, counted in its own profiler pass); what the launch
-        # executes, outcomes that did not happen included, is kept beside it
-        plain, plain_src = measured_valu("pmc_valu_plain*.json", "k_lnlike<false, false, 1, true>")
-        roof["executed_tflops"] = roof["achieved"]
-        roof["executed_fp64_flops_per_half_step"] = roof["fp64_flops_per_half_step"]
-        if plain:
-            useful = plain["fp64_flops_per_launch"]
-            roof["useful_fp64_flops_per_half_step"] = useful
-            roof["achieved"] = useful / (k_us * 1e-6) / 1e12
-            roof["frac"] = roof["achieved"] / FP64_VALU_PEAK_TFLOPS
-            roof["useful_counters_source"] = plain_src
-            # the same split for the issue bound: `valu_issue_frac` prices every instruction the launch
-            # executes (speculative work and polling included); this one only those of the form that
-            # computes nothing twice
-            pu = valu_roofline(plain, plain_src, k_us * 1e-6, "")
-            roof["valu_issue_frac_useful"] = pu["valu_issue_frac"]
-            roof["useful_valu_wave_instructions_per_half_step"] = pu["valu_wave_instructions_per_launch"]
-        else:
-            roof["note"] += "; no summary of the plain launch found: `achieved` is the executed count"
-    alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-    traffic, traffic_src = measured_traffic(kname)
-    if form in (5, 7):
-        f = newest_profile("pmc_traffic*.json")
-        traffic = None
-        try:
-            for k, v in json.load(open(f))["kernels"].items():
-                if kname in k:
-                    traffic, traffic_src = v.get("traffic_bytes_per_half_step"), os.path.relpath(f, ROOT)
-        except Exception:
-            pass
-    hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": alg_bytes / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-           "traffic_ratio": (traffic / alg_bytes) if traffic else None, "traffic_source": traffic_src,
-           "algorithmic_bytes_per_launch": alg_bytes * per_launch, "algorithmic_bytes_per_half_step": alg_bytes,
-           "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per half-step.  "
-                   + ("Per half-step; the tables are staged once per launch, what crosses the fabric every half-step "
-                      "is the hand-over between workgroups (records, rows, the words they poll)" if form in (5, 7) else
-                      "The traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
-                      "kernel code reaching each of the 8 XCD L2s once per launch")}
-    if roof is None:
-        roof = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": None, "note": "no committed PMC summary found"}
-    # the same half-step priced with the survey's nominal weights instead of counted
-    # instructions -- per quadrature sample of the thick+alpha model 3 exp-class operations at 24 flop, one
-    # division at 10, four FMAs at 2 = 90 flop, x NQ samples x 125 walkers.  The polynomial tables removed
-    # every division and two of the three exp-class operations from the sample loop, so the counted figure
-    # (`achieved`) is the smaller one.
-    nominal = 90.0 * nq * half
-    roof["survey_weights"] = {"flop_per_sample": 90.0, "flop_per_half_step": nominal,
-                              "achieved": nominal / (k_us * 1e-6) / 1e12,
-                              "frac": nominal / (k_us * 1e-6) / 1e12 / FP64_VALU_PEAK_TFLOPS}
-    roof["traffic"] = traffic
+    roof, hbm = dominant_kernel_roofline(form, pairs, staged, k_us, args.steps, kern_label, nq, nb, half)
     roof["kernel_avg_us"] = k_us
     roof["sample_arithmetic"] = arith
     roof["why_far_below"] = ("a half-step of 125 walkers is a chain of latencies, not a stream: constructor (one dependent chain of "
@@ -1085,7 +1147,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1):
         smp5.advance_async(20); c5.sync()
         t5 = (time.perf_counter() - t5) / 20
         sec5, slots5, mhz5 = c5.roof_probe(TRUTH, reps=200)
-        pm5, pm5_src = measured_valu("pmc_valu_cfg5*.json", "k_lnlike<false, false, 0, false>")
+        pm5, pm5_src, err5 = measured_valu("pmc_valu_cfg5*.json", kernel_key(0, staged=False))
         r5 = valu_roofline(pm5, pm5_src, ms5 * 1e-3, "k_lnlike<thick,alpha,plain> n=250000")
         if r5 and mhz5 > 0:
             # the chip does not hold 2.4 GHz under this load (tools/probe_clock.py): the same

@@ -297,6 +297,47 @@ def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
     assert "WORLD_SIZE=2" in json.loads(out[0])["error"]
 
 
+def test_bench_roofline_lookups_name_kernels_the_library_has_and_the_committed_summaries_hold():
+    """Round 3's driver line carried `roofline.frac = null`: a template parameter added to k_flowm after bench.py's
+    literal kernel name was written.  For every kernel bench.py looks up in a committed counter summary: the name
+    it derives is an instantiation the built library really has (nm), the newest committed summaries hold it
+    where the default bench command needs them (form 7, the plain launch, cfg5, cfg1, cfg4), and the roofline
+    objects come out finite; where a summary lacks a kernel the object says so in `error`."""
+    import bench
+    lib = os.path.join(ROOT, "mbb_emcee_amd", "libmbb_hip.so")
+    syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
+    have = set(re.findall(r"\bvoid (k_(?:lnlike|flowm)<[^>]*>)\(LikeArgs\)", syms))
+    assert len(have) >= 50
+    keys = [bench.kernel_key(7, pairs=1), bench.kernel_key(7, pairs=2), bench.kernel_key(5), bench.kernel_key(1),
+            bench.kernel_key(0), bench.kernel_key(0, staged=False), bench.kernel_key(7, opthin=True, pairs=1),
+            bench.kernel_key(0, opthin=True)]
+    for key in keys:
+        assert any(key in h for h in have), "bench.py would look for %r, the library has no such kernel" % key
+    # the default command's headline: form 7, one pair per workgroup, staged tables -- nothing may be missing
+    roof, hbm = bench.dominant_kernel_roofline(7, 1, True, 3.2, 20, "label", 2209, 8, 125)
+    assert roof.get("error") is None, roof.get("error")
+    for v in (roof["frac"], roof["achieved"], roof["counted"]["frac"], roof["traffic"], roof["valu_issue_frac"],
+              roof["valu_issue_frac_useful"], hbm["traffic_ratio"]):
+        assert v is not None and np.isfinite(v) and v > 0
+    assert 0.02 < roof["counted"]["frac"] < roof["frac"] < 0.5
+    assert os.path.exists(os.path.join(ROOT, roof["counters_source"]))
+    assert os.path.exists(os.path.join(ROOT, hbm["traffic_source"]))
+    # the other sampler forms: the algorithmic figure is always there; a missing summary is said, not hidden
+    for form in (5, 1):
+        r, h = bench.dominant_kernel_roofline(form, 1, True, 5.0, 20, "label", 2209, 8, 125)
+        assert np.isfinite(r["frac"]) and r["frac"] > 0
+        assert (r["counted"]["frac"] is not None) or r.get("error")
+    r, h = bench.dominant_kernel_roofline(7, 3, True, 5.0, 20, "label", 2209, 8, 125)      # no such instantiation
+    assert np.isfinite(r["frac"]) and r["traffic"] is None and "no kernel matching" in r["error"]
+    # cfg5, cfg1, cfg4
+    pm5, src5, err5 = bench.measured_valu("pmc_valu_cfg5*.json", bench.kernel_key(0, staged=False))
+    assert pm5 and not err5 and bench.valu_roofline(pm5, src5, 1.3e-3, "cfg5")["frac"] > 0
+    for cfg, thin in (("cfg1", True), ("cfg4", False)):
+        for key in (bench.kernel_key(0, opthin=thin), bench.kernel_key(7, opthin=thin, pairs=1)):
+            pm, src, err = bench.measured_valu("pmc_valu_%s.json" % cfg, key)
+            assert pm and not err, (cfg, key, err)
+
+
 def test_committed_parity_report_is_of_these_sources():
     """profiles/rNN/parity_report.json (the observed maxima DESIGN.md section 2 quotes) must have been
     measured on the kernel sources of the tree it is committed in: the report carries a hash of
