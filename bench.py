@@ -66,6 +66,9 @@ if os.environ.get("MBB_BENCH_WALKERS_PER_GPU"):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
 N_SIMD = 1024                  # 256 CUs x 4
+# N > 1: what the supervisor allows the whole run, what a rank allows any one step that may wedge (communicator
+# set-up, a rehearsal, a timed run), and the age of the run beyond which nothing optional is started any more
+SUPERVISOR_DEADLINE_S, GUARD_S, OPTIONAL_UNTIL_S = 480.0, 45.0, 240.0
 CLOCK_HZ = 2.4e9
 # tools/issue_cost.hip, profiles/r02/issue_cost_v1.txt: cycles one wave64 VALU
 # instruction holds its SIMD, four waves per SIMD
@@ -458,6 +461,8 @@ def parse_args(argv=None):
                          "timed, the others are rehearsed afterwards and reported in `exchange_validation`")
     ap.add_argument("--no-validate", action="store_true",
                     help="N > 1: do not rehearse the exchanges the timed run did not use")
+    ap.add_argument("--no-sharded-boundary", action="store_true",
+                    help="N > 1: do not time likelihood.__call__ sharded over the ranks with one ncclAllGather per call")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than devices (rehearsal of the N > 1 path on one GPU; "
                          "needs --exchange ipc; the line is marked invalid for scaling)")
@@ -511,12 +516,19 @@ def supervise(args):
         emit(dict(base, error="--gpus %d: not a rank count" % args.gpus))
         return 2
     ranks = [my_rank] if launched else list(range(world))
+    # The whole run -- ranks started, exchanges tried, line printed -- has to fit the driver's limit for one
+    # bench command (600 s in round 3's record): 480 s here, every step inside a rank bounded well below that
+    # (SUPERVISOR_DEADLINE_S, GUARD_S), and when the deadline comes the ranks are ended and the line is printed
+    # from whatever rank 0 has handed over by then: the measured value if there is one, an error otherwise.
+    t_start = time.time()
+    budget = float(os.environ.get("MBB_BENCH_DEADLINE_S", SUPERVISOR_DEADLINE_S))
     port = os.environ.get("MASTER_PORT") or str(free_port())
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs, lines = {}, []
     for r in ranks:
         env = dict(os.environ, MBB_BENCH_WORKER="1", WORLD_SIZE=str(world), RANK=str(r),
-                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port)
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   MBB_BENCH_T0=repr(t_start), MBB_BENCH_DEADLINE_S=repr(budget))
         if not launched:
             env["LOCAL_RANK"] = str(r)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -536,7 +548,7 @@ def supervise(args):
     if 0 in procs:
         th = threading.Thread(target=collect, args=(procs[0].stdout,), daemon=True)
         th.start()
-    deadline = time.time() + float(os.environ.get("MBB_BENCH_DEADLINE_S", "1500"))
+    deadline = t_start + budget
     timed_out, orphaned_since = False, None
     while any(pr.poll() is None for pr in procs.values()):
         now = time.time()
@@ -551,9 +563,11 @@ def supervise(args):
             if now - orphaned_since > float(os.environ.get("MBB_BENCH_GRACE_S", "30")):
                 break
         time.sleep(0.05)
-    for pr in procs.values():
+    ended_here = set()
+    for r, pr in procs.items():
         if pr.poll() is None:
             pr.kill()                      # exactly the processes started above
+            ended_here.add(r)
     for pr in procs.values():
         pr.wait()
     if th is not None:
@@ -578,7 +592,9 @@ def supervise(args):
         elif "metric" in obj and main_line is None:
             main_line = obj
     if main_line is None:
-        main_line = dict(base, error="rank 0 ended with status %s without a line" % rcs.get(0))
+        main_line = dict(base, error=("the ranks were ended at the supervisor's deadline of %.0f s before rank 0 had a line"
+                                      % budget) if timed_out else
+                         "rank 0 ended with status %s without a line" % rcs.get(0))
         worst = worst or 1
     main_line.update(parts)
     bad = {str(r): rc for r, rc in rcs.items() if rc != 0}
@@ -587,10 +603,14 @@ def supervise(args):
         # is said beside it, and does not turn a valid measurement into a failed run when rank 0 itself
         # left in good order
         main_line["ranks_ended_badly"] = bad
-        if rcs.get(0) == 0:
+        if rcs.get(0) == 0 or 0 in ended_here:
+            # (rank 0 ended by the supervisor itself: it was wedged in something optional after the line)
             worst = 0
     if timed_out:
         main_line["supervisor_timeout"] = True
+        main_line["supervisor_deadline_s"] = budget
+        if main_line.get("value") is None and "error" not in main_line:
+            main_line["error"] = "the ranks were ended at the supervisor's deadline of %.0f s before a run was validated" % budget
     emit(main_line)
     return worst
 
@@ -606,6 +626,9 @@ def fake_worker(args, how):
     if rank == 1 and "crash1" in how:
         os._exit(7)
     if rank == 1 and "hang1" in how:
+        time.sleep(600)
+    if rank == 0 and "hang0" in how:
+        sys.stdout.flush()
         time.sleep(600)
     if rank == 0 and "fail0" in how:
         os._exit(3)
@@ -623,6 +646,10 @@ def main():
 
 class Watchdog(Exception):
     pass
+
+
+class Hung(Exception):
+    """A step that may wedge (a collective, a launch that waits for peers) did not return within its guard."""
 
 
 def guarded(fn, seconds):
@@ -693,8 +720,10 @@ def worker_body(args, rank, world, local_rank, base, fail):
         os.dup2(2, 1)
         try:
             import datetime
+            # (a collective of the side channel that a lost peer never joins ends by itself well inside the
+            # supervisor's deadline)
             dist.init_process_group(backend="gloo", rank=rank, world_size=world,
-                                    timeout=datetime.timedelta(seconds=600))
+                                    timeout=datetime.timedelta(seconds=120))
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -782,9 +811,6 @@ def worker_body(args, rank, world, local_rank, base, fail):
             del sref, like_ref
         return ref_crc["crc"]
 
-    class Hung(Exception):
-        pass
-
     def run_mode(mode, steps, warmup):
         """Set the exchange up, rehearse it, time `steps` dependent MCMC steps.  Returns a dict with `ok`;
         when ok the sampler is still alive in it (the caller tears it down)."""
@@ -810,9 +836,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             elif mode == "rccl":
                 uid = [ctx.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
-                guarded(lambda: ctx.comm_init(world, rank, uid[0]), 120.0)
+                guarded(lambda: ctx.comm_init(world, rank, uid[0]), GUARD_S)
         except Watchdog:
-            raise Hung("%s: ncclCommInitRank did not return within 120 s" % mode)
+            raise Hung("%s: ncclCommInitRank did not return within %.0f s" % (mode, GUARD_S))
         except Exception as e:
             ok, why = False, "set-up: " + repr(e)
         if not all_ok(ok):
@@ -832,9 +858,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             except Exception as e:           # noqa
                 state["err"] = repr(e)
         try:
-            guarded(rehearse, 120.0)
+            guarded(rehearse, GUARD_S)
         except Watchdog:
-            raise Hung("%s: the rehearsal did not return within 120 s" % mode)
+            raise Hung("%s: the rehearsal did not return within %.0f s" % (mode, GUARD_S))
         if not all_ok(state["ok"]):
             res["why"] = "rehearsal: %s" % (state["err"] or "failed on another rank")
             teardown()
@@ -875,9 +901,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             ctx.sync(); barrier()
             return time.perf_counter() - t0, ctx.elapsed_ms(e0, e1)
         try:
-            elapsed, stream_ms = guarded(timed, 300.0)
+            elapsed, stream_ms = guarded(timed, GUARD_S)
         except Watchdog:
-            raise Hung("%s: the timed run did not return within 300 s" % mode)
+            raise Hung("%s: the timed run did not return within %.0f s" % (mode, GUARD_S))
         except Exception as e:               # noqa
             elapsed, stream_ms, state["err"] = None, None, repr(e)
         if not all_ok(elapsed is not None):
@@ -987,6 +1013,33 @@ def worker_body(args, rank, world, local_rank, base, fail):
     run["smp"] = None
     if world > 1:
         run["teardown"]()
+        t0_run = float(os.environ.get("MBB_BENCH_T0", "0")) or time.time()
+
+        def still_time():
+            """Is the run young enough to start something optional?  Decided together: a collective that only
+            some ranks enter is a hang of its own."""
+            return all_ok(time.time() - t0_run < OPTIONAL_UNTIL_S)
+
+        # ---- M1 of the sharded run: north_star's own split.  Every rank holds the proposed rows of the
+        # moving half (every rank runs the same sampler with the same random stream), evaluates its block in
+        # the fused kernel and ONE ncclAllGather of the blocks' log-probabilities gives every rank the whole
+        # vector: literally emcee's pool (mbb_fit.py:80-81) replaced.  Host arrays in and out, never `value`.
+        hung = None
+        if world <= ndev and not args.no_sharded_boundary:
+            if still_time():
+                try:
+                    sb = sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok)
+                except Hung as e:
+                    sb, hung = {"ok": False, "why": str(e), "hung": True}, "boundary_sharded"
+                except Exception as e:           # noqa
+                    sb = {"ok": False, "why": repr(e)}
+            else:
+                sb = {"ok": None, "why": "skipped: the run was already %.0f s old" % (time.time() - t0_run)}
+            if rank == 0:
+                emit({"_part": "boundary_sharded", "data": sb})
+            if hung is not None:
+                sys.stdout.flush()
+                os._exit(0)             # the measured run was valid; a wedged stream would hang teardown
         # ---- the exchanges the timed run did not use: the same rehearsal and a short timed run each,
         # outside `value`.  The measured line is already with the supervisor; whatever happens here
         # only adds to it.
@@ -995,6 +1048,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             hung = None
             for m in all_modes:
                 if m in validation:
+                    continue
+                if not still_time():
+                    validation[m] = {"ok": None, "why": "skipped: the run was already more than %.0f s old" % OPTIONAL_UNTIL_S}
                     continue
                 if m not in modes and args.exchange != "auto":
                     validation[m] = {"ok": None, "why": "not asked for (--exchange %s)" % args.exchange}
@@ -1025,6 +1081,68 @@ def worker_body(args, rank, world, local_rank, base, fail):
             emit({"_part": "exchange_validation", "data": validation})
         barrier()
         dist.destroy_process_group()
+
+
+def sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok):
+    """SURVEY.md 8d M1 at N > 1 (see the call site): parallel.ShardedLikelihood over parallel.RcclComm.  Every
+    rank makes the same calls in the same order (a collective inside each); times are this rank's wall clock
+    around a call, the figure reported is the slowest rank's median."""
+    import torch
+    from mbb_emcee_amd import parallel
+    res = {"ok": False,
+           "what": "likelihood.__call__ of the moving half-ensemble sharded over %d ranks: this rank's block through the "
+                   "fused kernel, one in-place ncclAllGather of the blocks' lnprob (RCCL), the gathered vector back on "
+                   "the host; host arrays in and out, median of 200 synchronous calls, slowest rank" % world}
+    uid = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, src=0)
+    comm, why = None, ""
+    try:
+        comm = guarded(lambda: parallel.RcclComm(ctx, rank, world, uid[0]), GUARD_S)
+    except Watchdog:
+        raise Hung("boundary_sharded: ncclCommInitRank did not return within %.0f s" % GUARD_S)
+    except Exception as e:           # noqa
+        why = repr(e)
+    if not all_ok(comm is not None):
+        res["why"] = "set-up: " + (why or "failed on another rank")
+        if comm is not None:
+            comm.close()
+        return res
+    sl = parallel.ShardedLikelihood(like, comm)
+    try:
+        for n in (nwt // 2, nwt):
+            p = np.ascontiguousarray(allw[:n])
+
+            def loop():
+                for _ in range(20):
+                    out = sl(p)
+                barrier()
+                ts = []
+                for _ in range(200):
+                    t0 = time.perf_counter(); out = sl(p); ts.append(time.perf_counter() - t0)
+                return ts, out
+            try:
+                ts, out = guarded(loop, GUARD_S)
+            except Watchdog:
+                raise Hung("boundary_sharded: %d sharded calls of %d rows did not return within %.0f s" % (220, n, GUARD_S))
+            # the gathered vector is the unsharded evaluation, bit for bit (a walker's lnL does not depend on the
+            # launch or the GPU that evaluates it), and the same on every rank
+            same = bool(np.array_equal(out, like(p), equal_nan=True))
+            if not all_ok(same):
+                res["why"] = "the gathered lnprob of %d rows differs from the unsharded evaluation on some rank" % n
+                return res
+            t = torch.tensor([float(np.median(ts)), float(np.percentile(ts, 90))], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["rows_%d" % n] = {"rows_per_rank": -(-n // world), "median_us": float(t[0]) * 1e6, "p90_us": float(t[1]) * 1e6,
+                                  "evals_per_s": n / float(t[0]), "calls": len(ts),
+                                  "equals_unsharded_bitwise": True}
+        res["ok"] = True
+    finally:
+        try:
+            ctx.sync()
+            comm.close()
+        except Exception:           # noqa
+            pass
+    return res
 
 
 def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True):

@@ -235,6 +235,13 @@ int mbb_allgather_f64(mbb_ctx *ctx, const double *d_send, double *d_recv, int co
  * of their lnprob into d_all [nranks*n]; asynchronous on the context's stream */
 int mbb_lnlike_allgather_device(mbb_ctx *ctx, const double *d_pars, int n, double *d_lnl,
                                 int32_t *d_status, double *d_all);
+/* the same half-step as one synchronous call on host arrays -- literally what emcee's pool does per
+ * half-step (mbb_fit.py:80-81): pars [n x 5] are this rank's rows, all [nranks*n] receives every rank's
+ * lnprob (rank-major), status [n] (may be NULL) this rank's row status.  No copy command for the
+ * parameters or the status (BAR / pinned memory as in mbb_lnlike_batch), one in-place ncclAllGather,
+ * one copy of the gathered vector into a pinned landing buffer, one stream wait.  Without a communicator
+ * (one rank) it is mbb_lnlike_batch through the same buffers. */
+int mbb_lnlike_allgather(mbb_ctx *ctx, const double *pars, int n, double *all, int32_t *status);
 
 /* ---- multi-GPU, device-resident sampler: one-hop exchange of the moved walkers ----- */
 /* Replaces: emcee's multiprocessing pool (mbb_fit.py:80-81) for the device-resident

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mbb_comm_destroy": (C.c_int, [_vp]),
     "mbb_allgather_f64": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "mbb_lnlike_allgather_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "mbb_lnlike_allgather": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
 }
 
 
@@ -347,6 +348,16 @@ class Context(object):
         _check(self.lib.mbb_lnlike_allgather_device(
             self.h, d_pars.ptr, int(n), d_lnl.ptr,
             d_status.ptr if d_status is not None else None, d_all.ptr))
+
+    def lnlike_allgather(self, pars, world):
+        """This rank's rows (host, [n, 5]) -> (every rank's lnprob [world * n] rank-major, this rank's row
+        status [n]): kernel + one ncclAllGather + one stream wait inside one native call."""
+        p = pars if (type(pars) is np.ndarray and pars.dtype == np.float64 and pars.flags.c_contiguous) else _f64(pars)
+        n = p.size // 5
+        full = np.empty(int(world) * n)
+        st = np.empty(n, dtype=np.int32)
+        _check(self.lib.mbb_lnlike_allgather(self.h, _d(p), n, _d(full), _i(st)))
+        return full, st
 
     def allgather_f64(self, d_send, d_recv, count):
         _check(self.lib.mbb_allgather_f64(

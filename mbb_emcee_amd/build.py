@@ -42,12 +42,24 @@ def hipcc():
     raise RuntimeError("hipcc not found; cannot build the MI355X likelihood library")
 
 
-def needs_build(lib=None):
+def flags_tag(extra_flags=()):
+    """What a library was built with, as written beside it (`<lib>.flags`)."""
+    return " ".join(DEVICE_FLAGS + ["|"] + FLOW_FLAGS + ["|"] + list(extra_flags))
+
+
+def needs_build(lib=None, extra_flags=()):
+    """Missing, older than a source, or built with other flags than asked for now (an A/B or -DMBB_STAMPS
+    library left by an earlier run is not handed back as up to date)."""
     lib = lib or LIB
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    if any(os.path.getmtime(d) > t for d in DEPS):
+        return True
+    try:
+        return open(lib + ".flags").read() != flags_tag(extra_flags)
+    except OSError:
+        return bool(extra_flags)         # (a library without the note is taken as a default build)
 
 
 def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
@@ -57,13 +69,14 @@ def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
     the old one in one rename, so nobody ever maps a half-written file."""
     import fcntl
     target = out or LIB
-    if not force and not needs_build(target):
+    if not force and not needs_build(target, extra_flags):
         return target
     objdir = os.path.join(HERE, "csrc", "_obj" + obj_tag)
     os.makedirs(objdir, exist_ok=True)
-    with open(os.path.join(objdir, ".lock"), "w") as lock:
+    # the lock belongs to the target: two builds of one library exclude each other whatever their object tags
+    with open(target + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and not needs_build(target):       # another process built it while we waited
+        if not force and not needs_build(target, extra_flags):       # another process built it while we waited
             return target
         # three objects (the two device translation units in parallel), then one link
         common = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + DEVICE_FLAGS + list(extra_flags)
@@ -84,6 +97,9 @@ def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
         tmp = "%s.tmp.%d" % (target, os.getpid())
         subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] +
                               [obj for _, obj, _ in jobs] + ["-ldl"])
+        with open(target + ".flags.tmp.%d" % os.getpid(), "w") as f:
+            f.write(flags_tag(extra_flags))
+        os.replace(f.name, target + ".flags")
         os.replace(tmp, target)
     return target
 

@@ -151,6 +151,8 @@ struct mbb_ctx {
     int32_t *d_status = nullptr;
     double *h_pars = nullptr, *h_lnl = nullptr, *h_mflux = nullptr;   // pinned
     double *w_pars = nullptr;    // device memory the host writes through the PCIe BAR (fine-grained), or null
+    double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
+    size_t gather_cap = 0;
     int large_bar = -1;
     int32_t *h_status = nullptr;
     // scratch for SED-level calls
@@ -308,6 +310,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
     free_dev(c->w_pars);
+    free_dev(c->d_gather); free_host(c->h_gather);
     free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
     free_dev(c->d_sed_wk);
     for (int i = 0; i < 2; ++i)
@@ -903,6 +906,8 @@ struct mbb_sampler_state {
     int *d_err = nullptr;
     double *d_bak = nullptr;             // one-launch run: the rows and counts it started from (R x 6 doubles, R counts)
     bool flow_used = false;              // the last enqueue took the one-launch form
+    bool unchecked = false;              // an asynchronous advance was enqueued and its error flag not looked at yet
+    bool lost = false;                   // such an advance gave up: the rows are no state of the chain until set again
     double *d_spec = nullptr;            // one-launch run: its device state (FlowView or FlowMView, spec_words(rows))
     int spec_form = 0;                   // the sampler form whose state d_spec holds (0: none / not to be trusted)
     int flowm_parity = 0;                // form 7: the set of completion counters the next launch uses
@@ -958,12 +963,15 @@ extern "C" int mbb_sampler_destroy(mbb_ctx *c, void *sp)
     return MBB_OK;
 }
 
+static int sampler_check_pending(mbb_ctx *c, mbb_sampler_state *s);
+
 extern "C" int mbb_sampler_reset(mbb_ctx *c, void *sp)
 {
     int rc = use(c);
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s) return fail(MBB_ERR_ARG, "null sampler");
+    (void)sampler_check_pending(c, s);       // (a give-up of an asynchronous advance is remembered, not wiped with the flag)
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemset(s->d_nacc, 0, (size_t)s->rows() * sizeof(unsigned int)));
     HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
@@ -998,6 +1006,35 @@ extern "C" int mbb_sampler_set_state(mbb_ctx *c, void *sp, const double *pos, co
     HIPCHK(hipMemcpyAsync(s->d_pos6, rows.data(), rows.size() * sizeof(double),
                           hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (s->lost || s->unchecked) {
+        // whatever an asynchronous advance left in the flag belongs to the state just replaced
+        HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+        s->lost = s->unchecked = false;
+        s->spec_form = 0;
+    }
+    return MBB_OK;
+}
+
+// What an asynchronous advance left behind, looked at once before anything is built on it: a one-launch
+// run that gave up (flag 9) kept no copy to be redone from, so the rows are not a state of the chain.  Without
+// this look the next run would back those rows up and, finding the stale 9 after its own launch, "redo" it from
+// them and return MBB_OK (round 3's advisor finding).  Other flags stay for the run's own check.
+static int sampler_check_pending(mbb_ctx *c, mbb_sampler_state *s)
+{
+    if (s->unchecked) {
+        int err = 0;
+        HIPCHK(hipMemcpyAsync(&err, s->d_err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        s->unchecked = false;
+        if (err == 9) {
+            HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
+            s->lost = true;
+            s->spec_form = 0;
+        }
+    }
+    if (s->lost)
+        return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step; the ensemble it "
+                                   "left behind is not a state of the chain: set the sampler's state again");
     return MBB_OK;
 }
 
@@ -1243,6 +1280,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
     const int R = s->rows(), nw = s->nw, half = nw / 2;
     const size_t nl = (size_t)s->nsrc * p.per;
     const bool store = (chain || lnprob) && nsteps > 0;
+    if ((rc = sampler_check_pending(c, s))) return rc;
     if (store && (size_t)nsteps * R * 6 > s->chain_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         free_dev(s->d_chain6); s->d_chain6 = nullptr; s->chain_cap = 0;
@@ -1315,8 +1353,9 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
             return rc;
         }
         if (err == 9) {
-            // (an asynchronous advance, or a sharded run: nothing was kept to redo it from)
+            // (a sharded run: nothing was kept to redo it from)
             s->spec_form = 0;
+            s->lost = true;
             return fail(MBB_ERR_STATE, "the one-launch sampler run timed out waiting for a half-step; the ensemble it "
                                        "left behind is not a state of the chain: set the sampler's state again");
         }
@@ -1360,6 +1399,8 @@ extern "C" int mbb_sampler_advance_async(mbb_ctx *c, void *sp, int nsteps, doubl
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0) return fail(MBB_ERR_ARG, "bad sampler arguments");
+    if (s->lost) return sampler_check_pending(c, s);
+    s->unchecked = true;
     return sampler_enqueue(c, s, nsteps, stretch_a, false, false);
 }
 
@@ -1372,6 +1413,8 @@ extern "C" int mbb_sampler_advance_timed(mbb_ctx *c, void *sp, int nsteps, doubl
     if (rc) return rc;
     mbb_sampler_state *s = (mbb_sampler_state *)sp;
     if (!s || nsteps < 0 || !wall_s || !stream_ms) return fail(MBB_ERR_ARG, "bad sampler arguments");
+    if (s->lost) return sampler_check_pending(c, s);
+    s->unchecked = true;
     if (!c->ev_timed[0]) {
         HIPCHK(hipEventCreate(&c->ev_timed[0]));
         HIPCHK(hipEventCreate(&c->ev_timed[1]));
@@ -1872,6 +1915,62 @@ extern "C" int mbb_lnlike_allgather_device(mbb_ctx *c, const double *d_pars, int
     if (n <= 0 || !d_pars || !d_lnl || !d_all) return fail(MBB_ERR_ARG, "bad batch buffers");
     if ((rc = launch_lnlike(c, d_pars, n, d_lnl, d_status, nullptr))) return rc;
     return mbb_allgather_f64(c, d_lnl, d_all, n);
+}
+
+// The sharded boundary as ONE call, host arrays in and out (what emcee's pool does per half-step,
+// mbb_fit.py:80-81: every worker evaluates its share of the rows, everybody gets all the answers): this
+// rank's n parameter rows go to the device without a copy command (through the BAR, or read by the kernel
+// from pinned memory), the fused kernel writes its lnprob into this rank's slice of the gather buffer and
+// its row status straight into pinned host memory, ONE in-place ncclAllGather of n doubles per rank, one
+// copy of the nranks*n gathered values to a pinned landing buffer, one stream wait.
+extern "C" int mbb_lnlike_allgather(mbb_ctx *c, const double *pars, int n, double *all, int32_t *status)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0 || !pars || !all) return fail(MBB_ERR_ARG, "bad batch buffers");
+    if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
+    const int nranks = c->comm ? c->nranks : 1, rank = c->comm ? c->rank : 0;
+    if (!c->comm && c->nranks != 1) return fail(MBB_ERR_STATE, "communicator not initialised");
+    if ((rc = ensure_capacity(c, (size_t)n, false))) return rc;
+    const size_t total = (size_t)nranks * n;
+    if (total > c->gather_cap) {
+        size_t cap = c->gather_cap ? c->gather_cap : 1024;
+        while (cap < total) cap *= 2;
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_gather); free_host(c->h_gather);
+        c->d_gather = c->h_gather = nullptr; c->gather_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->d_gather, cap * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&c->h_gather, cap * sizeof(double), hipHostMallocDefault));
+        c->gather_cap = cap;
+    }
+    const size_t nbytes = (size_t)n * 5 * sizeof(double);
+    const bool push = c->opt_zero_copy && c->opt_bar_params && c->w_pars;
+    double *dp;
+    int32_t *ds;
+    if (push) {
+        memcpy(c->w_pars, pars, nbytes);
+        __builtin_ia32_sfence();
+        dp = c->w_pars;
+    } else {
+        memcpy(c->h_pars, pars, nbytes);
+        if (c->opt_zero_copy) HIPCHK(hipHostGetDevicePointer((void **)&dp, c->h_pars, 0));
+        else {
+            HIPCHK(hipMemcpyAsync(c->d_pars, c->h_pars, nbytes, hipMemcpyHostToDevice, c->stream));
+            dp = c->d_pars;
+        }
+    }
+    if (c->opt_zero_copy) HIPCHK(hipHostGetDevicePointer((void **)&ds, c->h_status, 0));
+    else ds = c->d_status;
+    double *mine = c->d_gather + (size_t)rank * n;
+    if ((rc = launch_lnlike(c, dp, n, mine, ds, nullptr))) return rc;
+    if ((rc = mbb_allgather_f64(c, mine, c->d_gather, n))) return rc;
+    HIPCHK(hipMemcpyAsync(c->h_gather, c->d_gather, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!c->opt_zero_copy)
+        HIPCHK(hipMemcpyAsync(c->h_status, c->d_status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = wait_stream(c))) return rc;
+    memcpy(all, c->h_gather, total * sizeof(double));
+    if (status) memcpy(status, c->h_status, (size_t)n * sizeof(int32_t));
+    return MBB_OK;
 }
 
 extern "C" int mbb_allgather_f64(mbb_ctx *c, const double *d_send, double *d_recv, int count)

@@ -139,8 +139,9 @@ class DeviceEnsembleSampler(object):
                 barrier()
         N = int(N)
         lead = (self.nsources, self.k) if self.nsources > 1 else (self.k,)
-        # (zeros where a run is sharded with the one-hop exchange: only this rank's walkers are filled in)
-        alloc = np.zeros if barrier else np.empty
+        # (zeros where a run is sharded over ranks -- the one-hop exchange or a communicator, whether or not a
+        # barrier was handed in: only this rank's walkers are filled in there)
+        alloc = np.zeros if (barrier or ctx.info("nranks") > 1) else np.empty
         chain = alloc(lead + (N, 5)) if storechain else None
         lnp = alloc(lead + (N,)) if storechain else None
         pos = np.empty(lead + (5,))

@@ -38,6 +38,7 @@ class RcclComm(object):
         self._bufs = None
 
     def buffers(self, per):
+        """Device buffers for callers that keep the rows resident (mbb_lnlike_allgather_device)."""
         if per > self._cap:
             if self._bufs:
                 for b in self._bufs:
@@ -81,12 +82,11 @@ class ShardedLikelihood(object):
         if hi - lo < per:                       # ragged tail: pad with a valid row
             local[hi - lo:] = p[0]
         if isinstance(self.comm, RcclComm):
+            # one native call: rows through the BAR / pinned memory, the fused kernel, ONE ncclAllGather of
+            # `per` doubles per rank, the gathered vector into a pinned landing buffer, one stream wait
+            # (round 3 made three blocking copies around an asynchronous call here)
             ctx = self.like._sync_device()
-            d_pars, d_lnl, d_st, d_all = self.comm.buffers(per)
-            d_pars.upload(local)
-            ctx.lnlike_allgather_device(d_pars, per, d_lnl, d_st, d_all)
-            full = d_all.download(np.float64, world * per)
-            st = d_st.download(np.int32, per)
+            full, st = ctx.lnlike_allgather(local, world)
             from . import _native
             _native.raise_for_status(st[:hi - lo])
         else:

@@ -412,6 +412,13 @@ class response_set(object):
                      str(r[4]).lower(), str(r[5]).lower(), float(r[6]), float(r[7]),
                      dir=indir)
         if inputfile is None:
+            # the arrays the shallow copies share are frozen: `rs[name].response[:] *= k` on one wheel raises
+            # instead of silently changing every later wheel of the process (the reference gives each wheel
+            # arrays of its own, response.py:252-332)
+            for resp in self._responses.values():
+                for v in vars(resp).values():
+                    if isinstance(v, np.ndarray):
+                        v.setflags(write=False)
             _BUILTIN_WHEEL.update((name, copy.copy(resp)) for name, resp in self._responses.items())
 
     def add(self, name, spec, xtype, xunits, senstype, normtype, xnorm, normparam, dir=None):

@@ -563,8 +563,22 @@ def test_rccl_single_rank_allgather(mbb, g_lnl):
     ctx.comm_destroy()
     comm = RcclComm(ctx, 0, 1, uid)
     sharded = ShardedLikelihood(like, comm)
-    assert np.array_equal(sharded(g_lnl["cfg2/thick_walpha/pars"]), like(g_lnl["cfg2/thick_walpha/pars"]),
-                          equal_nan=True)
+    allp = g_lnl["cfg2/thick_walpha/pars"]
+    want = like(allp)
+    assert np.array_equal(sharded(allp), want, equal_nan=True)
+    # the boundary call of a sharded run (mbb_lnlike_allgather: host rows in, every rank's lnprob out, one native
+    # call) without a communicator, through a real one-rank RCCL communicator, and with and without zero-copy
+    for with_comm in (False, True):
+        if with_comm:
+            ctx.comm_init(1, 0, ctx.comm_unique_id())         # (a unique id makes one communicator)
+        for zc in (1, 0):
+            ctx.set_option("zero_copy", zc)
+            for n in (1, 125, 250, allp.shape[0]):
+                full, st = ctx.lnlike_allgather(allp[:n], 1)
+                assert np.array_equal(full, want[:n], equal_nan=True) and st.shape == (n,), (with_comm, zc, n)
+            assert np.array_equal(sharded(allp), want, equal_nan=True)
+        ctx.set_option("zero_copy", 1)
+    ctx.comm_destroy()
 
 
 # --------------------------------------------- batched multi-source mode (cfg5)
@@ -1623,11 +1637,24 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         # synchronous call as an error, and the sampler wants its state set again
         ctx.set_option("flow_spin_log2", 1)
         s1.advance_async(5); ctx.sync()
-        with pytest.raises(Exception, match="set the sampler's state again"):
-            s1.run_mcmc(None, 1)
         ctx.set_option("flow_spin_log2", 0)
+        nfall = ctx.info("flow_fallbacks")
+        # (a run long enough to take the one-launch form itself: round 3 backed the lost rows up, found the stale
+        # flag after its own launch, "redid" the run from them and returned a chain; a reset must not wipe the
+        # give-up either, and a further asynchronous advance is refused as well)
+        for attempt in (lambda: s1.run_mcmc(None, 5), lambda: s1.run_mcmc(None, 1), lambda: (s1.reset(), s1.run_mcmc(None, 5)),
+                        lambda: s1.advance_async(5), lambda: s1.advance_timed(5)):
+            with pytest.raises(Exception, match="set the sampler's state again"):
+                attempt()
+        assert ctx.info("flow_fallbacks") == nfall
         s1.run_mcmc(p0, 3)
         assert ctx.info("last_kernel_form") == form
+        s2 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
+        ctx.set_option("lookahead_sampler", 0)
+        want = s2.run_mcmc(p0, 3)[:2]
+        ctx.set_option("lookahead_sampler", 1)
+        got = s1.run_mcmc(None, 0)[:2]
+        assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
 
 
 def test_one_launch_sampler_ignores_records_left_in_reused_memory(mbb, g_lnl):

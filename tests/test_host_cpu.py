@@ -62,6 +62,14 @@ def test_builtin_wheel_is_cached_not_shared():
     assert a["SPIRE_350um"]._nresp != b["SPIRE_350um"]._nresp
     assert b["SPIRE_500um"] is not response_set()["SPIRE_500um"]
     np.testing.assert_allclose(b["SPIRE_250um"].normfac, 3.0796e-3, atol=1e-4)
+    # the arrays behind the copies are shared, so they are frozen: writing into one raises instead of
+    # changing every later wheel of the process
+    keep = b["SPIRE_500um"].response.copy()
+    with pytest.raises(ValueError):
+        b["SPIRE_500um"].response[:] *= 2.0
+    with pytest.raises(ValueError):
+        b["SPIRE_500um"].wavelength[0] = 1.0
+    assert np.array_equal(response_set()["SPIRE_500um"].response, keep)
 
 
 def test_passband_tables_match_reference(g_pb):
@@ -287,6 +295,33 @@ def test_bench_supervisor_collects_merges_and_ends_ranks(how, rc_want, checks):
     line = json.loads(out[0])
     assert rc == rc_want and checks(line), (rc, line)
     assert line["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("how,rc_zero,checks", [
+    # a peer wedged after the measurement: the value stands
+    ("hang1", True, lambda d: d["value"] == 2.0e6 and d["supervisor_timeout"] and d["ranks_ended_badly"] == {"1": -9}),
+    # rank 0 itself wedged in something optional after its line (the parts it had printed are kept)
+    ("part,hang0", True, lambda d: d["value"] == 2.0e6 and d["supervisor_timeout"] and d["exchange_validation"]["rccl"]["ok"]),
+    # wedged before anything was measured: an error line, not silence
+    ("noline,hang0", False, lambda d: d["value"] is None and d["supervisor_timeout"] and "deadline" in d["error"]),
+])
+def test_bench_supervisor_deadline_ends_the_ranks_and_still_prints_the_line(how, rc_zero, checks):
+    """Round 3's supervisor waited 1500 s by default -- longer than the driver's limit for the whole command --
+    and printed only after every rank had ended.  Now the deadline (480 s by default, 6 s here) ends the ranks
+    and the ONE line is printed from whatever rank 0 had handed over: the measured value if there was one, an
+    error otherwise.  Worst cases of the defaults stay inside the driver's 600 s."""
+    import json
+    import time
+    import bench
+    assert bench.SUPERVISOR_DEADLINE_S <= 480 and bench.GUARD_S <= 45 and bench.OPTIONAL_UNTIL_S <= 240
+    t0 = time.time()
+    rc, out = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         {"MBB_BENCH_FAKE_WORKER": how, "MBB_BENCH_GRACE_S": "300", "MBB_BENCH_DEADLINE_S": "6"})
+    assert time.time() - t0 < 60
+    assert len(out) == 1, out
+    line = json.loads(out[0])
+    assert (rc == 0) == rc_zero and checks(line), (rc, line)
+    assert line["supervisor_deadline_s"] == 6.0
 
 
 def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
