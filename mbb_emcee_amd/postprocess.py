@@ -8,12 +8,21 @@ of a batched kernel call, so no de-duplication is needed.  Only the arithmetic
 is provided; the results object, its HDF5 layout and the cosmology
 (astropy) stay out of scope -- pass the luminosity distance in.
 
-Parity: peak wavelength and the frequency integral are checked against the
-reference's own numbers (tests/golden/sed.npz).  ``results.py`` itself cannot be
-imported here (astropy.units), so ``dustmass`` and ``predict_flux`` are PARITY
-UNPINNED: the tests hold them to independent identities instead (the implied flux
-density, the thick/thin ratio tau/(1 - e^-tau), scalings; predicted fluxes against
-``likelihood.model_flux`` / ``get_sed``, which are pinned).
+Parity: PINNED.  Every function here is checked against what the reference's own
+``mbb_results`` returns for a 32 x 16 x 5 chain of each model variant
+(tests/golden/results.npz, made by tests/golden/make_golden_results.py from the
+imported ``results.py``): ``compute_peaklambda``, ``compute_lir``,
+``compute_dustmass``, ``_predict_flux`` for passbands and wavelengths.  Two things
+the reference does that a caller should know about:
+
+* ``compute_peaklambda`` maps ``peaklambda_inner(step, opthin=False, noalpha=False)``
+  without keyword arguments (results.py:574-581), so the peak of a chain from an
+  optically THIN fit is computed with the optically thick model.  ``peak_wavelength``
+  uses the fit's own model -- what the likelihood's lambda_peak prior uses
+  (likelihood.py:748-750) -- unless asked for ``model="reference"``.
+* ``_map_chain`` re-uses the previous step's value when ``numpy.allclose(prev, curr)``
+  (rtol 1e-5; results.py:556-562), so distinct steps closer than that share a value
+  there.  Here every chain entry is computed.
 """
 import numpy as np
 
@@ -30,11 +39,17 @@ def _rows(chain):
     return c.reshape(-1, 5), c.shape[:-1]
 
 
-def peak_wavelength(like, chain):
+def peak_wavelength(like, chain, model="fit"):
     """Observer-frame wavelength of peak f_nu [um] for every chain entry
-    (results.py:570-581 -> modified_blackbody.max_wave)."""
+    (results.py:570-581 -> modified_blackbody.max_wave, modified_blackbody.py:581-637).
+    ``model="fit"``: the fit's own model; ``model="reference"``: optically thick with
+    alpha whatever the fit's, which is what ``mbb_results.compute_peaklambda`` returns
+    (see the module docstring)."""
+    if model not in ("fit", "reference"):
+        raise ValueError("model must be 'fit' or 'reference'")
     rows, shape = _rows(chain)
-    out, st = like.context.sed_prologue(rows, like.opthin, like.noalpha, like.wavenorm,
+    opthin, noalpha = (like.opthin, like.noalpha) if model == "fit" else (False, False)
+    out, st = like.context.sed_prologue(rows, opthin, noalpha, like.wavenorm,
                                         want_peak=True)
     _native.raise_for_status(st)
     return out[:, 5].reshape(shape)

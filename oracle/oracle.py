@@ -124,6 +124,83 @@ class OracleSED(object):
             return None
         return self.s.hcokt / self.s.xmerge
 
+    def freq_integrate(self, minwave, maxwave):
+        """modified_blackbody.freq_integrate (modified_blackbody.py:639-674): scipy's `quad` (QUADPACK QAGS,
+        the third-party routine the reference itself calls; scipy is part of this image) over f_nu in GHz,
+        in erg/s/cm^2."""
+        from scipy.integrate import quad
+        minwave, maxwave = float(minwave), float(maxwave)
+        if minwave <= 0.0:
+            raise ValueError("Minimum wavelength must be > 0.0")
+        if minwave > maxwave:
+            minwave, maxwave = maxwave, minwave
+        um_to_GHz = 299792458e-3
+        return 1e-17 * quad(lambda f: float(self.f_nu(f)[0]), um_to_GHz / maxwave, um_to_GHz / minwave)[0]
+
+
+# ---- chain post-processing restated (results.py:534-944), one chain entry at a time as the reference does.
+# Checked against fixtures the reference's own mbb_results produced (tests/golden/results.npz).
+MPC_IN_CM = 3.0856775814913673e24          # astropy's Mpc (results.py:778 `lumdist.to(u.cm)`)
+
+
+def post_peaklambda(chain, opthin=False, noalpha=False, as_reference=True):
+    """results.py:570-581.  The reference maps `peaklambda_inner(step, opthin=False, noalpha=False)` without
+    keyword arguments: whatever the fit's model, the peak is that of the optically thick model with alpha
+    (`as_reference=True`); False gives the fit's own model (what likelihood.py:748-750 uses for its prior)."""
+    c = np.asarray(chain, dtype=np.float64).reshape(-1, 5)
+    ot, na = (False, False) if as_reference else (opthin, noalpha)
+    out = np.array([OracleSED(*p, opthin=ot, noalpha=na).max_wave() for p in c])
+    return out.reshape(np.shape(chain)[:-1])
+
+
+def post_lir(chain, redshift, lumdist_mpc, opthin=False, noalpha=False, wavemin=8.0, wavemax=1000.0):
+    """results.py:627-674 with mbb_freqint (results.py:1271-1330): 10^12 L_sun."""
+    c = np.asarray(chain, dtype=np.float64).reshape(-1, 5)
+    opz = 1.0 + float(redshift)
+    pre = 3.11749657e4 * float(lumdist_mpc) ** 2
+    out = np.array([OracleSED(*p, opthin=opthin, noalpha=noalpha).freq_integrate(wavemin * opz, wavemax * opz) for p in c])
+    return pre * out.reshape(np.shape(chain)[:-1])
+
+
+def post_dustmass(chain, redshift, lumdist_mpc, wavenorm=500.0, opthin=False, kappa=2.64, kappa_wave=125.0):
+    """results.py:726-801 (_dmass_calc + compute_dustmass), scalar arithmetic with math.expm1 as there: 10^8 M_sun."""
+    import math
+    c = np.asarray(chain, dtype=np.float64).reshape(-1, 5)
+    dl2 = (float(lumdist_mpc) * MPC_IN_CM) ** 2
+    opz = 1.0 + float(redshift)
+    wavenorm_rest = wavenorm / opz
+    nunorm_rest = 299792458e6 / wavenorm_rest
+    temp_fac = 6.6260693e-27 * nunorm_rest / 1.38065e-16
+    bnu_fac = 2 * 6.6260693e-27 * nunorm_rest ** 3 / 299792458e2 ** 2
+    knu_fac = wavenorm_rest / kappa_wave
+    msolar8 = 1.97792e41
+    out = np.empty(c.shape[0])
+    for i, step in enumerate(c):
+        T = step[0] * opz
+        beta = step[1]
+        S_nu = step[4] * 1e-26
+        B_nu = bnu_fac / math.expm1(temp_fac / T)
+        K_nu = 10.0 * kappa * knu_fac ** (-beta)
+        m = dl2 * S_nu / (opz * K_nu * B_nu * msolar8)
+        if not opthin:
+            tau_nu = (step[2] / wavenorm) ** beta
+            m *= -tau_nu / math.expm1(-tau_nu)
+        out[i] = m
+    return out.reshape(np.shape(chain)[:-1])
+
+
+def post_predict_flux(chain, spec, opthin=False, noalpha=False):
+    """results.py:895-944: `spec` a wavelength in um (the SED there) or one passband as (wave, sedmult, normfac)
+    (response.py:572-576).  The SED is built with the modified_blackbody default wavenorm, as there."""
+    c = np.asarray(chain, dtype=np.float64).reshape(-1, 5)
+    if isinstance(spec, tuple):
+        L = OracleLikelihood(np.ones(1), np.ones(1), bands=[spec], opthin=opthin, noalpha=noalpha,
+                             lowlim=np.full(5, -np.inf))
+        out = L(c, return_flux=True)[1][:, 0]
+    else:
+        out = np.array([OracleSED(*p, opthin=opthin, noalpha=noalpha)(float(spec))[0] for p in c])
+    return out.reshape(np.shape(chain)[:-1])
+
 
 class OracleLikelihood(object):
     """likelihood.__call__ restated (likelihood.py:790-834) on explicit tables.

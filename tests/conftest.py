@@ -34,6 +34,12 @@ def g_pb():
 
 
 @pytest.fixture(scope="session")
+def g_res():
+    """Chain post-processing as the reference's own mbb_results computed it (make_golden_results.py)."""
+    return np.load(os.path.join(GOLDEN, "results.npz"))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
     O.build()

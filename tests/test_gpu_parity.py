@@ -932,6 +932,34 @@ def test_postprocess_chain(mbb, g_lnl, oracle):
     assert md.shape == (6, 10) and np.all(md > 0)       # identities: tests/test_host_cpu.py
 
 
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_postprocess_vs_reference_results(mbb, g_res, name, opthin, noalpha):
+    """SURVEY.md 8f rank 4, pinned: `postprocess.*` on the GPU against what the reference's own mbb_results
+    returned for the same 32 x 16 x 5 chain (results.py:570-581, :627-674, :746-801, :895-944;
+    tests/golden/make_golden_results.py).  Tolerances: SURVEY 8c's for max_wave (1e-10) and fluxes (1e-12);
+    L_IR is held to 2e-7 because the reference's own `quad` stops at epsrel 1.5e-8 of ITS estimate."""
+    from mbb_emcee_amd import postprocess as pp
+    k = name + "/"
+    chain = g_res[k + "chain"]
+    z, dl = float(g_res["redshift"]), float(g_res["lumdist_mpc"])
+    bands = [str(b) for b in g_res["bands"]]
+    like = mbb.likelihood(response=True, opthin=opthin, noalpha=noalpha)
+    like.set_phot(bands, g_res[k + "data_flux"], 0.1 * g_res[k + "data_flux"] + 1.0)
+    rec_allclose(like(chain.reshape(-1, 5)).reshape(32, 16), g_res[k + "lnprobability"], rtol=1e-10, kind="lnL")
+    rec_allclose(pp.peak_wavelength(like, chain, model="reference"), g_res[k + "peaklambda"], rtol=1e-10, kind="max_wave")
+    rec_allclose(pp.peak_wavelength(like, chain), g_res[k + "peaklambda_own_model"], rtol=1e-10, kind="max_wave")
+    rec_allclose(pp.lir(like, chain, z, dl), g_res[k + "lir"], rtol=2e-7, kind="L_IR")
+    rec_allclose(pp.dustmass(like, chain, z, dl), g_res[k + "dustmass"], rtol=1e-13, kind="dust mass")
+    specs = [str(b) for b in g_res["pred_bands"]] + [float(w) for w in g_res["pred_waves"]]
+    got = pp.predict_flux(like, chain, specs)
+    assert got.shape == (32, 16, 4)
+    for i, s in enumerate(specs):
+        rec_allclose(got[..., i], g_res[k + "predict/" + (s if isinstance(s, str) else "%g" % s)], rtol=1e-12,
+                     kind="predicted flux")
+    rec_allclose(pp.predict_flux(like, chain, "SCUBA2_450um"), g_res[k + "predict/SCUBA2_450um"], rtol=1e-12,
+                 kind="predicted flux")
+
+
 def test_predict_flux_over_a_chain(mbb, g_lnl, oracle):
     """postprocess.predict_flux (results.py:895-944): predicted band fluxes through any
     passband of the wheel and SED values at any wavelength for every chain entry, in
@@ -1642,7 +1670,7 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         # (a run long enough to take the one-launch form itself: round 3 backed the lost rows up, found the stale
         # flag after its own launch, "redid" the run from them and returned a chain; a reset must not wipe the
         # give-up either, and a further asynchronous advance is refused as well)
-        for attempt in (lambda: s1.run_mcmc(None, 5), lambda: s1.run_mcmc(None, 1), lambda: (s1.reset(), s1.run_mcmc(None, 5)),
+        for attempt in (lambda: s1.run_mcmc(None, 5), lambda: s1.run_mcmc(None, 1), lambda: (ctx.lib.mbb_sampler_reset(ctx.h, s1._h), s1.run_mcmc(None, 5)),
                         lambda: s1.advance_async(5), lambda: s1.advance_timed(5)):
             with pytest.raises(Exception, match="set the sampler's state again"):
                 attempt()

@@ -107,3 +107,42 @@ def test_lnlike_priors_and_peak(oracle, g_lnl, g_pb):
                                 has_gprior=[0, 0, 0, 0, 0, 1], gprior_mean=[0, 0, 0, 0, 0, 250.0],
                                 gprior_sigma=[1, 1, 1, 1, 1, 20.0])
     lnl_close(L(pars), g_lnl["cfg2/thin_peak/lnl"], rtol=1e-13)
+
+
+RES_VARIANTS = [("thin_walpha", True, False), ("thick_walpha", False, False), ("thick_noalpha", False, True),
+                ("thin_noalpha", True, True)]
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", RES_VARIANTS)
+def test_postprocess_oracle_vs_reference_results(oracle, g_res, g_pb, name, opthin, noalpha):
+    """the oracle's restatement of mbb_results' chain post-processing against what the
+    reference's own results.py produced for a 32 x 16 x 5 chain (tests/golden/make_golden_results.py): peak
+    wavelength (results.py:570-581 -- the reference computes it with the optically THICK model whatever the
+    fit's, see the fixture script), L_IR (:627-674), dust mass (:746-801), predicted fluxes (:895-944)."""
+    k = name + "/"
+    chain = g_res[k + "chain"]
+    z, dl = float(g_res["redshift"]), float(g_res["lumdist_mpc"])
+    assert float(g_res[k + "max_close_but_unequal"]) == 0.0
+    assert relerr(oracle.post_peaklambda(chain, opthin, noalpha, as_reference=True), g_res[k + "peaklambda"]) < 1e-13
+    assert relerr(oracle.post_peaklambda(chain, opthin, noalpha, as_reference=False), g_res[k + "peaklambda_own_model"]) < 1e-13
+    if opthin:          # the quirk is real: the two differ for a thin fit
+        assert relerr(g_res[k + "peaklambda"], g_res[k + "peaklambda_own_model"]) > 1e-3
+    assert relerr(oracle.post_dustmass(chain, z, dl, opthin=opthin), g_res[k + "dustmass"]) < 1e-14
+    sub = chain[:6]                     # (scipy quad per entry: a sample)
+    assert relerr(oracle.post_lir(sub, z, dl, opthin, noalpha), g_res[k + "lir"][:6]) < 1e-12
+    for b in g_res["pred_bands"]:
+        band = golden_bands(g_pb, [b])[0]
+        assert relerr(oracle.post_predict_flux(chain, band, opthin, noalpha), g_res[k + "predict/" + str(b)]) < 5e-14
+    for wv in g_res["pred_waves"]:
+        assert relerr(oracle.post_predict_flux(chain, float(wv), opthin, noalpha), g_res[k + "predict/%g" % wv]) < 5e-14
+
+
+@pytest.mark.parametrize("name,opthin,noalpha", RES_VARIANTS)
+def test_postprocess_dustmass_vs_reference_results(g_res, name, opthin, noalpha):
+    """`postprocess.dustmass` is host arithmetic (a closed form in the chain values): pinned here, without a GPU,
+    to the reference's compute_dustmass (results.py:726-801)."""
+    import mbb_emcee_amd as mbb
+    from mbb_emcee_amd import postprocess
+    like = mbb.likelihood(opthin=opthin, noalpha=noalpha)
+    got = postprocess.dustmass(like, g_res[name + "/chain"], float(g_res["redshift"]), float(g_res["lumdist_mpc"]))
+    assert got.shape == (32, 16) and relerr(got, g_res[name + "/dustmass"]) < 1e-13
