@@ -948,7 +948,24 @@ def test_postprocess_vs_reference_results(mbb, g_res, name, opthin, noalpha):
     rec_allclose(like(chain.reshape(-1, 5)).reshape(32, 16), g_res[k + "lnprobability"], rtol=1e-10, kind="lnL")
     rec_allclose(pp.peak_wavelength(like, chain, model="reference"), g_res[k + "peaklambda"], rtol=1e-10, kind="max_wave")
     rec_allclose(pp.peak_wavelength(like, chain), g_res[k + "peaklambda_own_model"], rtol=1e-10, kind="max_wave")
-    rec_allclose(pp.lir(like, chain, z, dl), g_res[k + "lir"], rtol=2e-7, kind="L_IR")
+    # L_IR: the reference's `quad` (default epsrel 1.5e-8 of its own error ESTIMATE) does not know about the kink
+    # of f_nu at the merge frequency: against a quadrature split there, its values for these chains are off by up
+    # to 3.9e-7 (thick+alpha, entry [21, 12]; 1.2e-8 thin+alpha, 1e-10 without alpha).  So: 5e-7 against the
+    # reference's numbers, and 1e-9 against the split quadrature of the oracle SED for a sample that includes
+    # the reference's worst entry.
+    got_lir = pp.lir(like, chain, z, dl)
+    rec_allclose(got_lir, g_res[k + "lir"], rtol=5e-7, kind="L_IR vs the reference's quad")
+    from scipy.integrate import quad
+    from oracle import oracle as O
+    opz, flat = 1.0 + z, got_lir.reshape(-1)
+    for i in sorted(set(range(0, 512, 37)) | {348}):
+        sed = O.OracleSED(*chain.reshape(-1, 5)[i], opthin=opthin, noalpha=noalpha)
+        pts = [299792.458 / (1000.0 * opz), 299792.458 / (8.0 * opz)]
+        if not noalpha and pts[0] < 299792.458 / sed.wavemerge < pts[1]:
+            pts.insert(1, 299792.458 / sed.wavemerge)
+        val = sum(quad(lambda f: float(sed.f_nu(f)[0]), a, b, epsrel=1e-13, epsabs=0, limit=400)[0]
+                  for a, b in zip(pts[:-1], pts[1:]))
+        rec_allclose(flat[i], 3.11749657e4 * dl ** 2 * 1e-17 * val, rtol=1e-9, kind="L_IR vs split quadrature")
     rec_allclose(pp.dustmass(like, chain, z, dl), g_res[k + "dustmass"], rtol=1e-13, kind="dust mass")
     specs = [str(b) for b in g_res["pred_bands"]] + [float(w) for w in g_res["pred_waves"]]
     got = pp.predict_flux(like, chain, specs)
