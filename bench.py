@@ -432,6 +432,75 @@ def config_roofline(name, plain_us, half_step_us, form, half, ctx):
     return roof
 
 
+def postprocess_leg(like, pos, cpu=True):
+    """SURVEY.md 8f rank 4 measured: the chain post-processing of mbb_results (results.py:570-581 peak wavelength,
+    :627-674 L_IR, :746-801 dust mass, :895-944 predicted fluxes) over a stored 250 x 250 chain of the bench
+    workload, every entry one row of a batched kernel call -- wall clock of the user-level calls (host arrays in
+    and out), median of 5 -- with the CPU oracle's restatement of the same functions timed beside it on a bounded
+    sample (one thread: the reference does these one chain entry at a time in Python) and compared to it."""
+    import mbb_emcee_amd as mbb
+    from mbb_emcee_amd import postprocess as pp
+    nsteps = 250
+    smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=21)
+    smp.run_mcmc(pos, 50, storechain=False)
+    smp.reset()
+    smp.run_mcmc(None, nsteps)
+    chain = np.ascontiguousarray(smp.chain)                 # [walker, step, 5], emcee's layout
+    del smp
+    rows = chain.shape[0] * chain.shape[1]
+    z, dl = 2.3, 18700.0
+    bands2 = ["SPIRE_250um", "SCUBA2_450um"]                # one fitted band, one that is not
+    calls = {"peak_wavelength": lambda: pp.peak_wavelength(like, chain),
+             "lir": lambda: pp.lir(like, chain, z, dl),
+             "predict_flux_2_bands": lambda: pp.predict_flux(like, chain, bands2),
+             "predict_flux_2_wavelengths": lambda: pp.predict_flux(like, chain, [70.0, 1100.0]),
+             "dustmass_host": lambda: pp.dustmass(like, chain, z, dl)}
+    out = {"chain": [int(x) for x in chain.shape], "rows": rows}
+    got = {}
+    for name, fn in calls.items():
+        got[name] = fn()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        t = float(np.median(ts))
+        out[name] = {"wall_us": t * 1e6, "rows_per_s": rows / t}
+    out["note"] = ("wall clock of the user-level call (chain on the host in, result on the host out: PCIe and the Python "
+                   "around the kernel included); the reference computes each of these one chain entry at a time")
+    if cpu:
+        from oracle import oracle as O
+        flat = chain.reshape(-1, 5)
+        resp = like._responsewheel
+        cb = {"cores": 1, "kind": "port"}
+
+        def timed(fn, sample):
+            t0 = time.perf_counter(); r = fn(sample); dt = time.perf_counter() - t0
+            return r, dt
+        # bounded samples: about 2-5 s of CPU each
+        sel = flat[:: max(1, rows // 2000)][:2000]
+        ref, dt = timed(lambda c: O.post_peaklambda(c, like.opthin, like.noalpha, as_reference=False), sel)
+        g = got["peak_wavelength"].reshape(-1)[:: max(1, rows // 2000)][:2000]
+        cb["peak_wavelength"] = {"rows_per_s": len(sel) / dt, "sample_rows": len(sel),
+                                 "max_rel_err_gpu_vs_oracle": float(np.max(np.abs(g - ref) / ref))}
+        assert cb["peak_wavelength"]["max_rel_err_gpu_vs_oracle"] < 1e-10
+        sel = flat[:: max(1, rows // 300)][:300]
+        ref, dt = timed(lambda c: O.post_lir(c, z, dl, like.opthin, like.noalpha), sel)
+        g = got["lir"].reshape(-1)[:: max(1, rows // 300)][:300]
+        cb["lir"] = {"rows_per_s": len(sel) / dt, "sample_rows": len(sel),
+                     "max_rel_err_gpu_vs_oracle": float(np.max(np.abs(g - ref) / ref)),
+                     "note": "the oracle integrates with scipy's quad as the reference does: its own error is up to 4e-7 "
+                             "(tests/test_gpu_parity.py::test_postprocess_vs_reference_results)"}
+        assert cb["lir"]["max_rel_err_gpu_vs_oracle"] < 1e-6
+        sel = flat[:: max(1, rows // 2000)][:2000]
+        r = resp[bands2[0]]
+        ref, dt = timed(lambda c: O.post_predict_flux(c, (r.wavelength, r._sedmult, r._normfac), like.opthin, like.noalpha), sel)
+        g = got["predict_flux_2_bands"][..., 0].reshape(-1)[:: max(1, rows // 2000)][:2000]
+        cb["predict_flux_per_band"] = {"rows_per_s": len(sel) / dt, "sample_rows": len(sel),
+                                       "max_rel_err_gpu_vs_oracle": float(np.max(np.abs(g - ref) / np.abs(ref)))}
+        assert cb["predict_flux_per_band"]["max_rel_err_gpu_vs_oracle"] < 1e-12
+        out["cpu_baseline"] = cb
+    return out
+
+
 def ensemble_crc(pos, lnp):
     import zlib
     return zlib.crc32(np.ascontiguousarray(pos).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp).tobytes())
@@ -1293,6 +1362,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     # likelihood.__call__ once per half-step (what an external sampler such as emcee does)
     if not args.no_fit:
         out["user_runs"] = user_runs(like, pos)
+        out["postprocess"] = postprocess_leg(like, pos, cpu=not args.no_cpu)
 
     # ---- the other single-GPU configurations of BASELINE.json (configs[0], configs[3]): M1, M2, the
     # plain launch, its fp64 roofline from the committed PMC pass of that launch, the CPU oracle on

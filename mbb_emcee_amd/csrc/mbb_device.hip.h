@@ -213,18 +213,17 @@ __device__ inline float thick_merge_root_f32(float alpha, float beta, float lx0,
                 ghi = __shfl(g, (lane & 48) + j);
             }
         } else {
-            float g[16];
+            // one lane: the same 16 values one after the other, counted, none kept (an indexed array of them
+            // cost k_prologue 100 B of scratch per lane); the two at the ends of the chosen sub-interval are
+            // only wanted after the last round and are evaluated again there -- the same bits
             j = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                g[i] = merge_eqn_f32(fmaf((float)i, du, ulo), alpha3, beta, betal2, lx0);
-                j += (g[i] < 0.0f) ? 1 : 0;
-            }
+            for (int i = 0; i < 16; ++i)
+                j += (merge_eqn_f32(fmaf((float)i, du, ulo), alpha3, beta, betal2, lx0) < 0.0f) ? 1 : 0;
             j = min(max(j, 1), 15);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                glo = (i == j - 1) ? g[i] : glo;
-                ghi = (i == j) ? g[i] : ghi;
+            if (round == 2) {
+                glo = merge_eqn_f32(fmaf((float)(j - 1), du, ulo), alpha3, beta, betal2, lx0);
+                ghi = merge_eqn_f32(fmaf((float)j, du, ulo), alpha3, beta, betal2, lx0);
             }
         }
         const float nlo = fmaf((float)(j - 1), du, ulo), nhi = fmaf((float)j, du, ulo);
