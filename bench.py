@@ -442,9 +442,9 @@ def postprocess_leg(like, pos, cpu=True):
     from mbb_emcee_amd import postprocess as pp
     nsteps = 250
     smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=21)
-    smp.run_mcmc(pos, 50, storechain=False)
+    cur, lnp = smp.run_mcmc(pos, 50, storechain=False)[:2]
     smp.reset()
-    smp.run_mcmc(None, nsteps)
+    smp.run_mcmc(cur, nsteps, lnprob0=lnp)
     chain = np.ascontiguousarray(smp.chain)                 # [walker, step, 5], emcee's layout
     del smp
     rows = chain.shape[0] * chain.shape[1]
@@ -1066,8 +1066,15 @@ def worker_body(args, rank, world, local_rank, base, fail):
             out["kernel_avg_us"] = k_us
         out["half_step_us"] = k_us
         if world == 1 and not args.no_extras:
-            out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form,
-                              pairs=run["pairs"], staged=run["staged"]))
+            # (whatever goes wrong beside the timed region is said on the line; it does not take the
+            # measured value with it)
+            try:
+                out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form,
+                                  pairs=run["pairs"], staged=run["staged"], partial=out))
+            except Exception as e:           # noqa
+                import traceback
+                traceback.print_exc()
+                out["extras_error"] = "%s: %s" % (type(e).__name__, e)
         elif world > 1:
             alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
             out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None,
@@ -1214,10 +1221,11 @@ def sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok):
     return res
 
 
-def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True):
-    """Everything on the line besides the timed region (rank 0, one GPU)."""
+def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True, partial=None):
+    """Everything on the line besides the timed region (rank 0, one GPU).  `partial`: the caller's line, filled in
+    leg by leg, so that what was measured before a leg failed is kept."""
     import mbb_emcee_amd as mbb
-    out = {}
+    out = partial if partial is not None else {}
     half = NW_PER_GPU // 2
     pos = allw[:NW_PER_GPU]
 
