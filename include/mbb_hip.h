@@ -97,6 +97,19 @@ int mbb_set_gpriors(mbb_ctx *ctx, const int32_t has[6], const double mean[6],
 int mbb_lnlike_batch(mbb_ctx *ctx, const double *pars, int n, double *lnl,
                      int32_t *status, double *model_flux);
 
+/* The same boundary call with the copies taken out (what likelihood.__call__ uses for an (n, 5) array,
+ * likelihood.py:790-834, once per emcee half-step).  mbb_boundary_buffers returns host addresses that hold
+ * until more than nmax rows are asked for or the context goes: *in -- the caller writes its parameter rows
+ * [n x 5] straight INTO it (device memory behind the PCIe BAR where there is a large BAR, else the pinned
+ * block the kernel reads); *out / *status (may be NULL) -- pinned blocks the kernel writes lnprob [n] and row
+ * status [n] to.  mbb_lnlike_call(ctx, n) evaluates the first n rows of *in: same kernel, same results as
+ * mbb_lnlike_batch, bit for bit.  It returns MBB_OK, a negative error (MBB_ERR_STATE: ask for the buffers
+ * again -- capacity or the zero_copy / bar_params options changed), or, positive, the row status of the first
+ * row the reference would have raised ValueError for (2 alpha <= 0, 3 beta < 0, 6 no merge point:
+ * modified_blackbody.py:219-224, :294-316); rows below a lower limit are -inf with status 1, as ever. */
+int mbb_boundary_buffers(mbb_ctx *ctx, int nmax, double **in, double **out, int32_t **status);
+int mbb_lnlike_call(mbb_ctx *ctx, int n);
+
 /* Same computation on device-resident buffers, enqueued on the context's
  * stream, asynchronous.  d_model_flux / d_status may be NULL. */
 int mbb_lnlike_batch_device(mbb_ctx *ctx, const double *d_pars, int n,
@@ -193,7 +206,9 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * 2 -- the default -- watches the result slots in pinned memory, which are final
  * before the kernel's completion signal is; "spin_budget" = polls before it falls back
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
- * parameter rows into device memory through the PCIe BAR), "seg_chunks", "pack_tails" (band
+ * parameter rows into device memory through the PCIe BAR), "launch_api" (how the likelihood launch of given rows
+ * is handed to the runtime: 0 hipLaunchKernel, the default; 1 hipModuleLaunchKernel with the argument block as
+ * one packed buffer -- measurement: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug", "roof_threads" / "roof_wgs_per_cu" (measurement only: the geometry of
  * mbb_roof_probe), "xchg_spin_max" (polls before a launch waiting for a peer

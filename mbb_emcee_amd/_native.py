@@ -31,6 +31,8 @@ SIGNATURES = {
     "mbb_set_limits": (C.c_int, [_vp, _dp, _ip, _dp]),
     "mbb_set_gpriors": (C.c_int, [_vp, _ip, _dp, _dp]),
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
+    "mbb_boundary_buffers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "mbb_lnlike_call": (C.c_int, [_vp, C.c_int]),
     "mbb_lnlike_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "mbb_lnlike_repeat_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int]),
     "mbb_roof_probe": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp, _dp]),
@@ -158,6 +160,7 @@ class Context(object):
         # the same entry point with untyped pointer arguments (see lnlike_batch)
         self._lnlike_batch_raw = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp)(
             ("mbb_lnlike_batch", self.lib))
+        self._lnlike_call_raw = C.CFUNCTYPE(C.c_int, _vp, C.c_int)(("mbb_lnlike_call", self.lib))
 
     def close(self):
         if getattr(self, "h", None):
@@ -233,6 +236,20 @@ class Context(object):
         if rc:
             _check(rc)
         return (lnl, st, fl) if want_flux else (lnl, st)
+
+    def boundary_views(self, nmax):
+        """numpy views of the blocks the boundary call works on (mbb_boundary_buffers): `rows` [cap, 5] -- write
+        parameter rows straight into it (device memory behind the BAR where there is one) -- and `lnl` [cap],
+        `status` [cap], pinned memory the kernel writes.  Valid until a later call asks for more rows."""
+        cap = 256
+        while cap < nmax:
+            cap *= 2
+        pin, pout, pst = _vp(), _vp(), _vp()
+        _check(self.lib.mbb_boundary_buffers(self.h, cap, C.byref(pin), C.byref(pout), C.byref(pst)))
+        rows = np.ctypeslib.as_array(C.cast(pin, _dp), shape=(cap, 5))
+        lnl = np.ctypeslib.as_array(C.cast(pout, _dp), shape=(cap,))
+        st = np.ctypeslib.as_array(C.cast(pst, _ip), shape=(cap,))
+        return cap, rows, lnl, st
 
     def lnlike_batch_device(self, d_pars, n, d_lnl, d_status=None, d_flux=None):
         _check(self.lib.mbb_lnlike_batch_device(

@@ -151,6 +151,12 @@ struct mbb_ctx {
     int32_t *d_status = nullptr;
     double *h_pars = nullptr, *h_lnl = nullptr, *h_mflux = nullptr;   // pinned
     double *w_pars = nullptr;    // device memory the host writes through the PCIe BAR (fine-grained), or null
+    double *dv_pars = nullptr, *dv_lnl = nullptr, *dv_mflux = nullptr;   // the pinned blocks as the device addresses them
+    int32_t *dv_status = nullptr;
+    double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
+    size_t call_cap = 0;         // ... and the capacity that answer was given for
+    hipFunction_t mod_fn[40] = {};   // launch_api 1: the kernels' module handles, by variant
+    long opt_launch_api = 0;     // 0 hipLaunchKernel (triple chevron); 1 hipModuleLaunchKernel with a packed argument buffer
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
     size_t gather_cap = 0;
     int large_bar = -1;
@@ -486,6 +492,10 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         HIPCHK(hipHostMalloc((void **)&c->h_pars, cap * 5 * sizeof(double), hflags));
         HIPCHK(hipHostMalloc((void **)&c->h_lnl, cap * sizeof(double), hflags));
         HIPCHK(hipHostMalloc((void **)&c->h_status, cap * sizeof(int32_t), hflags));
+        HIPCHK(hipHostGetDevicePointer((void **)&c->dv_pars, c->h_pars, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&c->dv_lnl, c->h_lnl, 0));
+        HIPCHK(hipHostGetDevicePointer((void **)&c->dv_status, c->h_status, 0));
+        c->call_in = nullptr; c->call_cap = 0;
         // With a large BAR the host can store into (fine-grained) device memory directly:
         // posted writes, and the kernel then reads its parameter rows from local memory
         // instead of pulling them across PCIe.
@@ -511,6 +521,7 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         c->d_mflux = nullptr; c->h_mflux = nullptr; c->cap_flux = 0;
         HIPCHK(hipMalloc((void **)&c->d_mflux, cap * sizeof(double)));
         HIPCHK(hipHostMalloc((void **)&c->h_mflux, cap * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void **)&c->dv_mflux, c->h_mflux, 0));
         c->cap_flux = cap;
     }
     return MBB_OK;
@@ -791,6 +802,16 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             g = want;
         }
     }
+    if (c->opt_launch_api == 1) {
+        // the module-launch entry with the argument block handed over as ONE packed buffer: no per-argument
+        // marshalling in the runtime (A/B: tools/probe_boundary_breakdown.py, profiles/r04/boundary_breakdown.txt)
+        hipFunction_t &f = c->mod_fn[vi_of_kernel];
+        if (!f) HIPCHK(hipGetFuncBySymbol(&f, (const void *)kern));
+        size_t sz = sizeof(a);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)smem_total, c->stream, nullptr, extra));
+        return MBB_OK;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_total, c->stream, a);
     HIPCHK(hipGetLastError());
     return MBB_OK;
@@ -816,6 +837,51 @@ extern "C" int mbb_lnlike_repeat_device(mbb_ctx *c, const double *d_pars, int n,
     return MBB_OK;
 }
 
+// The zero-copy host path once the parameter rows are where the kernel reads them (device memory the host
+// wrote through the BAR when `push`, the pinned block otherwise): launch, watch the result slots in pinned
+// memory (or wait for the stream), leave lnl / status / model flux in c->h_lnl, c->h_status, c->h_mflux.
+static int lnlike_zero_copy(mbb_ctx *c, int n, bool push, bool model_flux, long t_a)
+{
+    int rc;
+    auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
+    // the kernel reads the pinned parameter block and writes lnL straight
+    // into pinned host memory: no copy commands on the stream at all
+    double *const dp = push ? c->w_pars : c->dv_pars, *const dl = c->dv_lnl, *const df = model_flux ? c->dv_mflux : nullptr;
+    int32_t *const ds = c->dv_status;
+    // spin_wait = 2: do not wait for the kernel's completion signal at all.  The
+    // result slots in pinned memory are pre-filled with patterns the kernel never
+    // writes (a NaN with a payload; it produces the canonical NaN), and the host
+    // watches them: a walker's results are final the moment they appear, before the
+    // end-of-kernel bookkeeping.  status is written after lnl by the same lane.
+    const bool watch = c->opt_spin == 2 && !model_flux && n <= 8192;
+    c->last_watch_seen = -1;
+    if (watch) {
+        uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
+        for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
+    }
+    const long t_b = now_ns();
+    if ((rc = launch_lnlike(c, dp, n, dl, ds, df))) return rc;
+    const long t_c = now_ns();
+    bool seen = false;
+    if (watch) {
+        // acquire loads: the copies out of h_lnl / h_status below must not be satisfied
+        // from before the slot was seen to change
+        const uint64_t *hl = reinterpret_cast<const uint64_t *>(c->h_lnl);
+        const int32_t *hs = c->h_status;
+        int i = 0;
+        for (long spins = 0; spins < c->opt_spin_budget; ++spins) {   // default ~ tens of ms, then give up
+            while (i < n && __atomic_load_n(&hl[i], __ATOMIC_ACQUIRE) != kLnlSentinel &&
+                   __atomic_load_n(&hs[i], __ATOMIC_ACQUIRE) != kStatusSentinel) ++i;
+            if (i == n) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        c->last_watch_seen = seen ? 1 : 0;
+    }
+    if (!seen && (rc = wait_stream(c))) return rc;
+    c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
+    return MBB_OK;
+}
+
 extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *lnl,
                                 int32_t *status, double *model_flux)
 {
@@ -836,46 +902,7 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
         memcpy(c->h_pars, pars, nbytes);
     }
     if (c->opt_zero_copy) {
-        // the kernel reads the pinned parameter block and writes lnL straight
-        // into pinned host memory: no copy commands on the stream at all
-        double *dp, *dl, *df = nullptr;
-        int32_t *ds;
-        if (push) dp = c->w_pars;
-        else HIPCHK(hipHostGetDevicePointer((void **)&dp, c->h_pars, 0));
-        HIPCHK(hipHostGetDevicePointer((void **)&dl, c->h_lnl, 0));
-        HIPCHK(hipHostGetDevicePointer((void **)&ds, c->h_status, 0));
-        if (model_flux) HIPCHK(hipHostGetDevicePointer((void **)&df, c->h_mflux, 0));
-        // spin_wait = 2: do not wait for the kernel's completion signal at all.  The
-        // result slots in pinned memory are pre-filled with patterns the kernel never
-        // writes (a NaN with a payload; it produces the canonical NaN), and the host
-        // watches them: a walker's results are final the moment they appear, before the
-        // end-of-kernel bookkeeping.  status is written after lnl by the same lane.
-        const bool watch = c->opt_spin == 2 && !model_flux && n <= 8192;
-        c->last_watch_seen = -1;
-        if (watch) {
-            uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
-            for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
-        }
-        const long t_b = now_ns();
-        if ((rc = launch_lnlike(c, dp, n, dl, ds, df))) return rc;
-        const long t_c = now_ns();
-        bool seen = false;
-        if (watch) {
-            // acquire loads: the copies out of h_lnl / h_status below must not be satisfied
-            // from before the slot was seen to change
-            const uint64_t *hl = reinterpret_cast<const uint64_t *>(c->h_lnl);
-            const int32_t *hs = c->h_status;
-            int i = 0;
-            for (long spins = 0; spins < c->opt_spin_budget; ++spins) {   // default ~ tens of ms, then give up
-                while (i < n && __atomic_load_n(&hl[i], __ATOMIC_ACQUIRE) != kLnlSentinel &&
-                       __atomic_load_n(&hs[i], __ATOMIC_ACQUIRE) != kStatusSentinel) ++i;
-                if (i == n) { seen = true; break; }
-                __builtin_ia32_pause();
-            }
-            c->last_watch_seen = seen ? 1 : 0;
-        }
-        if (!seen && (rc = wait_stream(c))) return rc;
-        c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
+        if ((rc = lnlike_zero_copy(c, n, push, model_flux != nullptr, t_a))) return rc;
     } else {
         HIPCHK(hipMemcpyAsync(c->d_pars, c->h_pars, nbytes, hipMemcpyHostToDevice, c->stream));
         if ((rc = launch_lnlike(c, c->d_pars, n, c->d_lnl, c->d_status,
@@ -892,6 +919,48 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
     memcpy(lnl, c->h_lnl, (size_t)n * sizeof(double));
     if (status) memcpy(status, c->h_status, (size_t)n * sizeof(int32_t));
     if (model_flux) memcpy(model_flux, c->h_mflux, (size_t)n * c->nb * sizeof(double));
+    return MBB_OK;
+}
+
+// The boundary call with the copies taken out (the caller is likelihood.__call__,
+// likelihood.py:790-834, once per emcee half-step).  mbb_boundary_buffers hands the binding the host
+// addresses of the block it writes the parameter rows INTO -- device memory behind the BAR where there is one,
+// else the pinned block the kernel reads -- and of the pinned blocks the kernel writes lnprob and row status
+// to; mbb_lnlike_call then evaluates the first n rows of that block: no pointer arguments, no memcpy on either
+// side, the row status looked through here.  The addresses hold until a call asks for more rows than `nmax`
+// (ask again then) or the context is destroyed.
+extern "C" int mbb_boundary_buffers(mbb_ctx *c, int nmax, double **in, double **out, int32_t **status)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (nmax <= 0 || !in || !out) return fail(MBB_ERR_ARG, "bad arguments");
+    if ((rc = ensure_capacity(c, (size_t)nmax, false))) return rc;
+    const bool push = c->opt_zero_copy && c->opt_bar_params && c->w_pars;
+    c->call_in = push ? c->w_pars : c->h_pars;
+    c->call_cap = c->cap;
+    *in = c->call_in; *out = c->h_lnl;
+    if (status) *status = c->h_status;
+    return MBB_OK;
+}
+
+// Returns MBB_OK, a negative error, or -- positive -- the status code of the first row that the reference
+// would have raised for (alpha <= 0, beta < 0, no merge point: modified_blackbody.py:219-224, :294-316).
+extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
+{
+    int rc = use(c);
+    if (rc) return rc;
+    if (n <= 0) return n == 0 ? MBB_OK : fail(MBB_ERR_ARG, "bad row count");
+    if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
+    const bool push = c->opt_zero_copy && c->opt_bar_params && c->w_pars;
+    if (!c->opt_zero_copy || !c->call_in || c->call_cap != c->cap || (size_t)n > c->cap ||
+        c->call_in != (push ? c->w_pars : c->h_pars))
+        return fail(MBB_ERR_STATE, "mbb_boundary_buffers first (or again: the buffers or the host-path options changed)");
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    if (push) __builtin_ia32_sfence();             // the caller's stores through the BAR, drained before the doorbell
+    if ((rc = lnlike_zero_copy(c, n, push, false, ts.tv_sec * 1000000000L + ts.tv_nsec))) return rc;
+    const int32_t *hs = c->h_status;
+    for (int i = 0; i < n; ++i)
+        if (hs[i] >= 2 && hs[i] != 7) return hs[i];
     return MBB_OK;
 }
 
@@ -1739,6 +1808,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "spin_budget")) c->opt_spin_budget = value < 0 ? 0 : value;
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
+    else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;

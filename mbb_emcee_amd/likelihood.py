@@ -39,6 +39,7 @@ class likelihood(object):
         self._device = device
         self._ctx = None
         self._dirty = True
+        self._fast = None      # the boundary call's buffers and views (see __call__)
 
         self._lowlim = np.array([1, 0.1, 1, 0.1, 1e-3])               # :73
         self._limprior_order = copy.copy(self._param_order)            # :77-79
@@ -317,11 +318,54 @@ class likelihood(object):
         _native.raise_for_status(st)
         return fl
 
+    def _fast_views(self, n):
+        """Views for the boundary call of n rows: the rows of the block the kernel reads its parameters from
+        (device memory behind the PCIe BAR, or pinned memory) and of the pinned block it writes lnprob to.
+        One native call when the capacity has to grow, a dictionary look-up afterwards."""
+        ctx = self._sync_device()
+        f = self._fast
+        if f is None or n > f[3] or f[6] is not ctx:
+            cap, rows, lnl, st = ctx.boundary_views(n)
+            self._fast = f = (ctx._lnlike_call_raw, ctx.h.value, {}, cap, rows, lnl, ctx)
+        if len(f[2]) > 64:
+            f[2].clear()
+        v = f[2][n] = (f[4][:n], f[5][:n])
+        return v
+
     def __call__(self, pars):
         """ln P(pars | data) including limits and priors (likelihood.py:790-834).
 
         (5,) -> float;  (n, 5) -> float64[n], all rows in one kernel launch.
         Rows below a lower limit give -inf."""
+        # What a sampler calls once per half-step (emcee: mbb_fit.py:80-81) or once per walker: a float array
+        # of rows, or one row, with nothing changed since the last call.  The rows are written straight into
+        # the block the kernel reads (no copy of them anywhere else), the native call takes a row count and
+        # nothing else, the result is copied out of the pinned block the kernel wrote.  Whatever is unusual --
+        # first call, changed data or limits, a row the reference raises for, options that switch the host
+        # path -- takes the general path below, which also does the raising.
+        if not self._dirty and type(pars) is np.ndarray and pars.dtype.kind == "f" and self._nsources == 1:
+            f = self._fast
+            if pars.ndim == 2 and pars.shape[1] == 5 and pars.shape[0] > 0:
+                n = pars.shape[0]
+                v = f[2].get(n) if f is not None else None
+                if v is None:
+                    v = self._fast_views(n)
+                    f = self._fast
+                v[0][...] = pars
+                rc = f[0](f[1], n)
+                if rc == 0:
+                    return v[1].copy()
+                self._fast = None
+            elif pars.ndim == 1 and pars.shape[0] == 5:
+                v = f[2].get(1) if f is not None else None
+                if v is None:
+                    v = self._fast_views(1)
+                    f = self._fast
+                v[0][0] = pars
+                rc = f[0](f[1], 1)
+                if rc == 0:
+                    return float(v[1][0])
+                self._fast = None
         p = np.asarray(pars, dtype=np.float64)
         if p.ndim == 1:
             if p.shape[0] != 5:
@@ -363,6 +407,7 @@ class likelihood(object):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_ctx"] = None
+        d["_fast"] = None
         d["_dirty"] = True
         d.pop("_sed", None)
         return d

@@ -27,31 +27,43 @@ def med_us(fn, reps=2000):
 def main():
     like, flux = make_likelihood(0)
     ctx = like._sync_device()
-    for n in (125, 250):
+    for n in (125, 250, 1):
         p = np.ascontiguousarray(walkers(1)[:n])
-        call, call90 = med_us(lambda: like(p))
-        ctypes_, _ = med_us(lambda: ctx.lnlike_batch(p))
-        ph = []
-        for _ in range(2000):
-            ctx.lnlike_batch(p)
-            ph.append((ctx.info("last_prep_ns"), ctx.info("last_launch_ns"), ctx.info("last_wait_ns")))
-        prep, launch, wait = (np.median(np.array(ph), axis=0) / 1e3)
+        row = p[0].copy()
+        res = {}
+        # interleaved A/B of how the launch is handed to the runtime (option launch_api), three rounds each
+        for rnd in range(3):
+            for api in (0, 1):
+                ctx.set_option("launch_api", api)
+                call, call90 = med_us((lambda: like(p)) if n > 1 else (lambda: like(row)), reps=1500)
+                ph = []
+                for _ in range(1500):
+                    like(p) if n > 1 else like(row)
+                    ph.append((ctx.info("last_prep_ns"), ctx.info("last_launch_ns"), ctx.info("last_wait_ns")))
+                prep, launch, wait = (np.median(np.array(ph), axis=0) / 1e3)
+                res.setdefault(api, []).append((call, call90, prep, launch, wait))
+        ctx.set_option("launch_api", 0)
+        old, _ = med_us(lambda: ctx.lnlike_batch(p))            # round 3's binding: two allocations, three addresses, memcpy in and out
         dp = ctx.alloc(p.nbytes); dp.upload(p)
         dl, ds = ctx.alloc(n * 8), ctx.alloc(n * 4)
         ctx.lnlike_repeat_device(dp, n, dl, ds, 200); ctx.sync()
         e0, e1 = ctx.event(), ctx.event()
         ctx.record(e0); ctx.lnlike_repeat_device(dp, n, dl, ds, 1000); ctx.record(e1); ctx.sync()
         kern = ctx.elapsed_ms(e0, e1)
-        c_total = prep + launch + wait
-        print("rows %d" % n)
-        print("  likelihood.__call__            %6.2f us  (p90 %.2f)" % (call, call90))
-        print("    Python above the C-ABI call  %6.2f us  (likelihood.__call__ - Context.lnlike_batch)" % (call - ctypes_))
-        print("    ctypes + numpy in the binding %5.2f us  (Context.lnlike_batch - time inside mbb_lnlike_batch)" % (ctypes_ - c_total))
-        print("    inside mbb_lnlike_batch      %6.2f us" % c_total)
-        print("      rows -> device (BAR) + sentinels   %5.2f us" % prep)
-        print("      hipLaunchKernel                    %5.2f us" % launch)
-        print("      launch latency + kernel + poll     %5.2f us   of which the kernel alone %.2f us (events, back to back)" % (wait, kern))
-        print("  => %.3g evals/s at the boundary; the kernel is %.0f %% of a call" % (n / (call * 1e-6), 100.0 * kern / call), flush=True)
+        print("rows %d%s" % (n, "  (one row: what emcee calls per walker without vectorize)" if n == 1 else ""))
+        for api in (0, 1):
+            call, call90, prep, launch, wait = np.median(np.array(res[api]), axis=0)
+            c_total = prep + launch + wait
+            print("  launch_api %d (%s)" % (api, "hipLaunchKernel" if api == 0 else "hipModuleLaunchKernel, packed argument buffer"))
+            print("    likelihood.__call__            %6.2f us  (p90 %.2f)   rounds: %s" % (call, call90, " ".join("%.2f" % r[0] for r in res[api])))
+            print("      Python + ctypes around the C call %5.2f us  (checks, rows written into the BAR block, the call, the copy out)" % (call - c_total))
+            print("      inside mbb_lnlike_call       %6.2f us" % c_total)
+            print("        fence + sentinels                  %5.2f us" % prep)
+            print("        the launch call                    %5.2f us" % launch)
+            print("        launch latency + kernel + poll     %5.2f us   of which the kernel alone %.2f us (events, back to back)" % (wait, kern))
+        print("  round 3's binding (Context.lnlike_batch: copies in and out, status array) %6.2f us" % old)
+        best = min(np.median(np.array(res[a]), axis=0)[0] for a in (0, 1))
+        print("  => %.3g evals/s at the boundary; the kernel is %.0f %% of a call" % (n / (best * 1e-6), 100.0 * kern / best), flush=True)
 
 
 if __name__ == "__main__":
