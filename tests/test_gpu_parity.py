@@ -1009,6 +1009,62 @@ def test_predict_flux_over_a_chain(mbb, g_lnl, oracle):
         pp.predict_flux(like, chain, -3.0)
 
 
+def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
+    """likelihood.__call__ takes a shorter way for what a sampler hands over per half-step (a float array of rows
+    or one row, nothing changed since the last call): rows written straight into the block the kernel reads,
+    mbb_lnlike_call(ctx, n), the result copied out of the pinned block.  It must give what mbb_lnlike_batch gives,
+    bit for bit, for every kind of array, across capacity growth, and must hand everything unusual -- rows the
+    reference raises for, changed limits, switched host-path options -- to the general path."""
+    import pickle
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    allp = np.tile(g_lnl["cfg2/thick_walpha/pars"], (20, 1))          # 6620 rows, edge rows (-inf) among them
+    want = ctx.lnlike_batch(allp)[0]
+    assert np.isneginf(want).any()
+    for n in (125, 10, 300, 1, 125, 1000, 6620, 250, 125):           # capacity grows 256 -> 8192 on the way
+        got = like(allp[:n])
+        assert type(got) is np.ndarray and got.shape == (n,) and np.array_equal(got, want[:n], equal_nan=True), n
+        assert like._fast is not None and n in like._fast[2]
+    assert got.base is None                                           # a copy, not a view of the pinned block
+    keep = like(allp[:125])
+    like(allp[125:250])
+    assert np.array_equal(keep, want[:125], equal_nan=True)           # ... so a later call does not change it
+    # other layouts and float types take the same way; one row gives a Python float
+    f32 = allp[:200].astype(np.float32)
+    assert np.array_equal(like(f32), ctx.lnlike_batch(f32.astype(np.float64))[0], equal_nan=True)
+    assert np.array_equal(like(np.asfortranarray(allp[:200])), want[:200], equal_nan=True)
+    assert np.array_equal(like(allp[:400:2]), want[:400:2], equal_nan=True)
+    one = like(allp[3])
+    assert type(one) is float and one == want[3]
+    assert like(allp[3].astype(np.float32)) == ctx.lnlike_batch(allp[3].astype(np.float32).astype(np.float64))[0][0]
+    assert like(list(allp[3])) == want[3] and np.array_equal(like(allp[:7].tolist()), want[:7])      # (general path)
+    # rows the reference raises for (modified_blackbody.py:219-224) raise here too, and the next call is fine
+    bad = allp[:50].copy(); bad[17, 3] = -1.0
+    with pytest.raises(ValueError, match="alpha"):
+        like(bad)
+    bad[17, 3] = 3.0; bad[4, 1] = -0.5
+    with pytest.raises(ValueError, match="beta"):
+        like(bad[4])
+    assert np.array_equal(like(allp[:50]), want[:50], equal_nan=True)
+    nan = allp[:50].copy(); nan[9, 0] = np.nan
+    assert np.isnan(like(nan)[9]) and np.array_equal(np.delete(like(nan), 9), np.delete(want[:50], 9), equal_nan=True)
+    # a changed limit goes through the general path once (upload) and the result is the new one
+    like.set_uplim("T", 12.0)
+    new = like(allp[:125])
+    assert not np.array_equal(new, want[:125], equal_nan=True) and np.array_equal(new, ctx.lnlike_batch(allp[:125])[0], equal_nan=True)
+    like._has_uplim[0] = False; like._dirty = True
+    assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+    # switched host-path options: still right, whichever way it goes
+    for opt, val in (("zero_copy", 0), ("zero_copy", 1), ("bar_params", 0), ("bar_params", 1), ("spin_wait", 0), ("spin_wait", 2),
+                     ("launch_api", 1), ("launch_api", 0)):
+        ctx.set_option(opt, val)
+        for _ in range(3):
+            assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True), (opt, val)
+    # a pickled copy builds its own context and buffers
+    twin = pickle.loads(pickle.dumps(like))
+    assert twin._fast is None and np.array_equal(twin(allp[:125]), want[:125], equal_nan=True)
+
+
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
     """The three ways an emcee-style sampler can call the likelihood -- row by row
     (emcee's plain map, mbb_fit.py:80-81 with threads=1), through a pool's map with a
@@ -1040,6 +1096,10 @@ def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
     calls = []
     orig = like.context.lnlike_batch
     monkeypatch.setattr(like.context, "lnlike_batch", lambda p, **k: calls.append(len(p) // 5 if p.ndim == 1 else p.shape[0]) or orig(p, **k))
+    # (... whichever way the launch is made: the general path above, or the boundary call of __call__'s fast path)
+    raw = like.context._lnlike_call_raw
+    monkeypatch.setattr(like.context, "_lnlike_call_raw", lambda h, n: calls.append(n) or raw(h, n))
+    like._fast = None
     mbb.EnsembleSampler(20, 5, Wrapper(like), seed=3, vectorize=False, pool=like).run_mcmc(p0, 2)
     assert calls == [20, 10, 10, 10, 10]
     # ... but only when the function IS the likelihood: a posterior of the caller's own (a lambda that
