@@ -1017,7 +1017,7 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
     reference raises for, changed limits, switched host-path options -- to the general path."""
     import pickle
     like = _cfg2_like(mbb, g_lnl)
-    ctx = like.context
+    ctx = like._sync_device()
     allp = np.tile(g_lnl["cfg2/thick_walpha/pars"], (20, 1))          # 6620 rows, edge rows (-inf) among them
     want = ctx.lnlike_batch(allp)[0]
     assert np.isneginf(want).any()
