@@ -224,6 +224,11 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * walkers per CU ("form 7"); 0: only the proposals are prepared ahead ("form 5")),
  * "merged_flow_pairs" (pairs of walkers a form-7 workgroup serves: 0 = the host's choice -- one while every
  * pair and candidate has a CU of its own, two for the ensembles beyond, up to four walkers per CU; 1 or 2 force it),
+ * "resident_sampler" (default 1: ensembles beyond one pair of walkers per CU -- where form 7 has no CU per pair and
+ * candidate -- run as ONE launch per 4096 steps as well, a workgroup owning several walkers of each half and doing for
+ * them, half-step after half-step, what the half-step launch does, rows handed over through check words instead of a
+ * launch boundary ("form 8", k_flowr: up to 8 walkers per CU and half); 0: off; 2: every eligible ensemble takes it),
+ * "resident_walkers" (walkers per workgroup and half of that form; 0 = the host's choice, ceil(half / CUs)),
  * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
  * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),

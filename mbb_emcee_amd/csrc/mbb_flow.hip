@@ -30,3 +30,13 @@ MBB_FLOWM_INST(false, true)
 MBB_FLOWM_INST(true, false)
 MBB_FLOWM_INST(true, true)
 #undef MBB_FLOWM_INST
+
+#include "mbb_flowr.hip.h"
+#define MBB_FLOWR_INST(OT, NA)                                     \
+    template __global__ void k_flowr<OT, NA, false>(const LikeArgs); \
+    template __global__ void k_flowr<OT, NA, true>(const LikeArgs);
+MBB_FLOWR_INST(false, false)
+MBB_FLOWR_INST(false, true)
+MBB_FLOWR_INST(true, false)
+MBB_FLOWR_INST(true, true)
+#undef MBB_FLOWR_INST

@@ -53,6 +53,23 @@ MBB_FLOWM_EXT(false, true)
 MBB_FLOWM_EXT(true, false)
 MBB_FLOWM_EXT(true, true)
 #undef MBB_FLOWM_EXT
+// ... and k_flowr, sampler form 8: the launch train made resident (mbb_flowr.hip.h)
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void k_flowr(const LikeArgs a);
+#define MBB_FLOWR_EXT(OT, NA)                                               \
+    extern template __global__ void k_flowr<OT, NA, false>(const LikeArgs); \
+    extern template __global__ void k_flowr<OT, NA, true>(const LikeArgs);
+MBB_FLOWR_EXT(false, false)
+MBB_FLOWR_EXT(false, true)
+MBB_FLOWR_EXT(true, false)
+MBB_FLOWR_EXT(true, true)
+#undef MBB_FLOWR_EXT
+constexpr int kFrMaxWHost = 8;
+static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h
+{
+    return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 8 + 8 * 2) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
+}
 constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)   // = flowm_lds() of mbb_flowm.hip.h
 {
@@ -192,6 +209,9 @@ struct mbb_ctx {
     long opt_xflow = 1;       // ... also for a sharded ensemble with the one-hop exchange (SMODE 6)
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
+    long opt_flowr = 1;       // 1: ensembles beyond one pair of walkers per CU run as ONE resident launch too, several walkers per
+                              // workgroup, nothing computed ahead (k_flowr, form 8); 0: off; 2: every eligible ensemble takes it
+    long opt_flowr_walkers = 0;   // walkers per workgroup and half of that form (0: the host's choice, ceil(half / CUs))
     long opt_flowm_pairs = 0; // pairs of walkers per form-7 workgroup: 0 = one while every (pair, candidate) has a CU, two beyond
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
@@ -629,6 +649,8 @@ struct SamplerLaunch {
     double *spec;                 // != nullptr: the one-launch run's device state
     bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
     bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
+    bool resident = false;        // k_flowr (form 8): the launch train made resident, several walkers per workgroup
+    int res_w = 1;                // ... walkers per workgroup and half
     unsigned long long serial = 0;   // ... the number of its launch (in its check words and decision words)
     int parity = 0;               // ... which of the two sets of completion counters it uses
 };
@@ -692,6 +714,47 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     c->last_stage = stage ? 1 : 0;
     void (*kern)(const LikeArgs);
     int vi_of_kernel = 0;
+    if (sl && sl->resident) {
+        // sampler form 8: ceil(n / W) workgroups of 16 waves, every one resident, W walkers of each half apiece
+        a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
+        a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
+        a.m_count = sl->m_count;
+        a.step = sl->step; a.half = sl->half; a.stretch_a = sl->stretch_a; a.seed = sl->seed;
+        a.nw_src = sl->nw_src;
+        a.persist = sl->persist;
+        a.flow_serial = c->flow_serial = sl->serial;
+        a.spec = sl->spec;
+        a.spec_cfg = (int)((c->opt_flow_spin_log2 & 0x3f) << 24) | (sl->parity & 1);
+        a.n_ahead = 0;
+        const int Wr = sl->res_w, wgs = (n + Wr - 1) / Wr, thr = 1024;
+        a.wpb = Wr;
+        a.cov_in_lds = (c->has_cov && flowr_lds_bytes(c->nb, c->npart, true, Wr) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
+        const size_t sm = flowr_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0, Wr);
+        const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
+        const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
+        if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
+        if (wgs > c->cu_count || Wr > kFrMaxWHost)
+            return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
+        static void (*const rtable[8])(const LikeArgs) = {
+            k_flowr<false, false, false>, k_flowr<false, false, true>, k_flowr<false, true, false>, k_flowr<false, true, true>,
+            k_flowr<true, false, false>, k_flowr<true, false, true>, k_flowr<true, true, false>, k_flowr<true, true, true>};
+        const int ri = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+        kern = rtable[ri];
+        c->last_wpb = Wr; c->last_threads = thr; c->last_grid = wgs; c->last_smem = (long)sm_total;
+        c->last_stage = stg ? 1 : 0; c->last_smode = 8; c->last_ahead = 0;
+        if (static_lds(c) + sm_total > 60 * 1024) {
+            size_t &g = c->lds_granted[72 + ri];
+            if (sm_total > g) {
+                size_t want = (sm_total + 16383) & ~(size_t)16383;
+                if (want > dyn_limit) want = dyn_limit;
+                HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+                g = want;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(thr), sm_total, c->stream, a);
+        HIPCHK(hipGetLastError());
+        return MBB_OK;
+    }
     if (sl && sl->merged) {
         // sampler form 7: 2 n workgroups of (quadrature waves + 5), every one resident; its own LDS plan
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
@@ -1224,7 +1287,15 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     // bitwise those of the plain launch train, which is what larger ensembles, several sources and
     // very short runs take.
     bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&
-                      nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps) && wpb_1 == 1;
+                      nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps);
+    // form 8 (k_flowr): several walkers of each half per workgroup, nothing ahead -- what ensembles beyond one
+    // pair of walkers per CU take (up to kFrMaxWHost walkers per CU and half)
+    int res_w = c->opt_flowr_walkers > 0 ? (int)std::min<long>(c->opt_flowr_walkers, kFrMaxWHost)
+                                         : ((int)nl + c->cu_count - 1) / c->cu_count;
+    const bool res_fits = res_w >= 1 && res_w <= kFrMaxWHost && ((int)nl + res_w - 1) / res_w <= c->cu_count;
+    const bool merged1_ok = c->opt_flowm && c->opt_flowm_pairs != 2 && 2 * (int)nl <= c->cu_count && wpb_1 == 1;
+    const bool resident = one_launch && res_fits && (c->opt_flowr == 2 || (c->opt_flowr == 1 && !merged1_ok));
+    if (!resident) one_launch = one_launch && wpb_1 == 1;
     if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
     if (one_launch) {
         const size_t R = (size_t)s->rows();
@@ -1244,8 +1315,8 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
         const bool form5 = la_worth && la_ahead + (int)nl <= c->cu_count;
         const bool merged1 = c->opt_flowm && c->opt_flowm_pairs != 2 && 2 * (int)nl <= c->cu_count;
         const bool merged2 = c->opt_flowm && c->opt_flowm_pairs != 1 && 2 * (((int)nl + 1) / 2) <= c->cu_count;
-        const bool merged = merged1 || (merged2 && (c->opt_flowm_pairs == 2 || !(form5 && la_sparse)));
-        if (merged || form5) {
+        const bool merged = !resident && (merged1 || (merged2 && (c->opt_flowm_pairs == 2 || !(form5 && la_sparse))));
+        if (merged || form5 || resident) {
             // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
             // resident, the tables are staged once, a row's half-step starts when the rows it
             // depends on are done (no launch boundary, no grid-wide barrier)
@@ -1259,17 +1330,17 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 HIPCHK(hipMemcpyAsync(s->d_bak + R * 6, s->d_nacc, R * sizeof(unsigned int), hipMemcpyDeviceToDevice, c->stream));
             }
             s->flow_used = backup;
-            if (merged && s->spec_form != 7) {
-                // form 7 finds its completion counters cleared by the launch before it; after another form
-                // (or a run that gave up) has used the memory, once from here
+            if ((merged || resident) && s->spec_form != 7 && s->spec_form != 8) {
+                // forms 7 and 8 find their completion counters cleared by the launch before it (either's); after
+                // another form (or a run that gave up) has used the memory, once from here
                 const FlowMView fvh = flowm_view(s->d_spec, (int)R);
                 HIPCHK(hipMemsetAsync(fvh.done, 0, 2 * kFmRing * 16 * sizeof(unsigned long long), c->stream));
                 s->flowm_parity = 0;
             }
-            s->spec_form = merged ? 7 : 5;
+            s->spec_form = resident ? 8 : (merged ? 7 : 5);
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
-                if (merged) {
+                if (merged || resident) {
                     // one launch, nothing before or after it: it files the rows it finds and stores the last ones back
                     sl.serial = ++g_flow_serial;
                     sl.parity = s->flowm_parity;
@@ -1285,9 +1356,11 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.nacc = s->d_nacc;
                 sl.seed = s->seed + 0x9E3779B97F4A7C15ull * (s->steps_done + (unsigned long long)t0 + 1ull);
                 sl.merged = merged;
+                sl.resident = resident;
+                sl.res_w = res_w;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 // the sampler's rows from the slots the launch's last moves went to
-                if (!merged)
+                if (!merged && !resident)
                     hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream, s->d_pos6,
                                        s->d_spec, (int)R, 2 * nt);
                 HIPCHK(hipGetLastError());
@@ -1297,7 +1370,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
         }
         // (no room for the workgroups that work ahead: the launch train)
     }
-    sl.spec = nullptr; sl.merged = false; sl.persist = 0;
+    sl.spec = nullptr; sl.merged = false; sl.resident = false; sl.persist = 0;
     for (int t = 0; t < nsteps; ++t)
         for (int h = 0; h < 2; ++h) {
             const int hb = h ? half : 0;
@@ -1815,6 +1888,8 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
     else if (!strcmp(name, "merged_flow_pairs")) c->opt_flowm_pairs = value;
+    else if (!strcmp(name, "resident_sampler")) c->opt_flowr = value;
+    else if (!strcmp(name, "resident_walkers")) c->opt_flowr_walkers = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "flow_min_steps")) c->opt_flow_min_steps = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;

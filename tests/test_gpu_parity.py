@@ -1039,13 +1039,21 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
     assert like(allp[3].astype(np.float32)) == ctx.lnlike_batch(allp[3].astype(np.float32).astype(np.float64))[0][0]
     assert like(list(allp[3])) == want[3] and np.array_equal(like(allp[:7].tolist()), want[:7])      # (general path)
     # rows the reference raises for (modified_blackbody.py:219-224) raise here too, and the next call is fine
+    # (with the lower limits where they are such rows are gated to -inf first, likelihood.py:643-670; so they are opened)
     bad = allp[:50].copy(); bad[17, 3] = -1.0
+    assert np.isneginf(like(bad)[17])
+    like.set_lowlim("alpha", -5.0); like.set_lowlim("beta", -5.0)
     with pytest.raises(ValueError, match="alpha"):
-        like(bad)
+        like(bad)                                                     # (first call after the change: the general path)
+    with pytest.raises(ValueError, match="alpha"):
+        like(bad)                                                     # (the boundary call, which hands over to it)
     bad[17, 3] = 3.0; bad[4, 1] = -0.5
     with pytest.raises(ValueError, match="beta"):
         like(bad[4])
-    assert np.array_equal(like(allp[:50]), want[:50], equal_nan=True)
+    ok50 = like(allp[:50])
+    like.set_lowlim("alpha", 0.1); like.set_lowlim("beta", 0.1)
+    fin = np.isfinite(want[:50])
+    assert np.array_equal(ok50[fin], want[:50][fin]) and np.array_equal(like(allp[:50]), want[:50], equal_nan=True)
     nan = allp[:50].copy(); nan[9, 0] = np.nan
     assert np.isnan(like(nan)[9]) and np.array_equal(np.delete(like(nan), 9), np.delete(want[:50], 9), equal_nan=True)
     # a changed limit goes through the general path once (upload) and the result is the new one
@@ -1386,11 +1394,15 @@ def test_one_hop_exchange_three_processes_one_gpu():
 def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
-            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0}),
+            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0, "resident_sampler": 0}),
             ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1,
-                                              "merged_flow_pairs": 0}),
+                                              "merged_flow_pairs": 0, "resident_sampler": 0}),
             ("one launch, quadrature ahead, two pairs of walkers per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "merged_flow_pairs": 2})]
+             {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "merged_flow_pairs": 2, "resident_sampler": 0}),
+            ("one launch, the train made resident (form 8), one walker of each half per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2}),
+            ("one launch, the train made resident (form 8), three walkers of each half per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_walkers": 3})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
@@ -1441,6 +1453,35 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
             assert np.array_equal(x, y), (flow, rows, waves)
     like.context.set_option("lookahead_rows", 0); like.context.set_option("lookahead_waves", 0)
     like.context.set_option("merged_flow_sampler", 1)
+
+
+@pytest.mark.parametrize("nw,W", [(514, 0), (1000, 0), (2000, 0), (2000, 8), (4096, 0), (300, 5), (36, 8)])
+def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, g_lnl, nw, W):
+    """Sampler form 8 (k_flowr): ensembles beyond one pair of walkers per CU -- cfg3's 2000 walkers on one GPU
+    among them -- run as ONE launch per run with several walkers of each half per workgroup, the rows handed over
+    through check words instead of a launch boundary.  Nothing is computed ahead or twice: the chain, the final
+    state and the counts are bitwise the launch train's, whatever the number of walkers per workgroup (the
+    host's choice, a forced one, a last workgroup that owns fewer)."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like.context
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
+    out = []
+    for resident in (0, 1):
+        ctx.set_option("lookahead_sampler", resident); ctx.set_option("resident_sampler", 2 if W else 1); ctx.set_option("resident_walkers", W)
+        s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=nw + 1)
+        a = s.run_mcmc(p0, 9)
+        if resident:
+            assert ctx.info("last_kernel_form") == 8 and ctx.info("flow_fallbacks") == 0
+            assert ctx.info("last_wpb") == (W or -(-(nw // 2) // ctx.info("cu_count")))
+        b = s.run_mcmc(None, 6, storechain=False)
+        s.advance_async(5); ctx.sync()
+        c = s.run_mcmc(None, 4)
+        out.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
+        assert ctx.info("last_kernel_form") == (8 if resident else 1)
+    for x, y in zip(*out):
+        assert np.array_equal(x, y), (nw, W)
+    assert out[0][6].shape == (nw, 13, 5) and 0.1 < out[0][8].mean() / 24 < 0.9
+    lnl_close(out[1][5], like(out[1][4]))
 
 
 def test_lookahead_sampler_forms_with_priors_limits_and_long_runs(mbb, g_lnl):
