@@ -1695,6 +1695,7 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     not started and left to time out: the run takes the launch-per-half-step form, same chain."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
+    ctx.set_option("resident_sampler", 0)          # (this is about forms 5 and 7; form 8 takes over what they cannot hold)
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(250, 5)))
     out = []
     for rows, waves, merged, form in ((1, 1, 0, 1), (0, 0, 0, 5), (0, 0, 1, 7)):     # 500 + 125 workgroups do not fit 256 CUs

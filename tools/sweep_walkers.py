@@ -4,7 +4,7 @@
     python tools/sweep_walkers.py [sizes ...]
 
 For every ensemble size: the form the host chooses (mbb_hip.hip, sampler_enqueue), and -- where they are
-eligible -- each of the forms forced through the options: us per MCMC step by HIP events on the stream,
+eligible -- each of the forms (7, 5, 8, the launch train) forced through the options: us per MCMC step by HIP events on the stream,
 evals/s = walkers / that.  The cut-overs between the forms (form 7 up to 2 walkers per CU, form 5 while
 movers + working-ahead workgroups fit, the launch train beyond) are then read off the curve.
 250 000 walkers = cfg5's count run as ONE ensemble of that size (the multi-source launch is bench.py's cfg5).
@@ -19,10 +19,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mbb_emcee_amd as mbb
 from bench import make_likelihood, TRUTH
 
-SIZES = [18, 64, 128, 250, 256, 258, 384, 510, 512, 1000, 2000, 4096, 250000]
+SIZES = [18, 64, 128, 250, 256, 258, 300, 340, 384, 450, 512, 514, 768, 1000, 1500, 2000, 3000, 4096, 16384]
 FORMS = (("chosen", {}),
-         ("form7", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1}),
-         ("form5", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0}),
+         ("form7", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "resident_sampler": 0}),
+         ("form5", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0, "resident_sampler": 0}),
+         ("form8", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2}),
          ("train", {"lookahead_sampler": 0}))
 
 
@@ -39,6 +40,7 @@ def main():
         done = {}
         for name, opts in FORMS:
             ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", 1)
+            ctx.set_option("resident_sampler", 1)
             for o, v in opts.items():
                 ctx.set_option(o, v)
             s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=5)
@@ -61,6 +63,7 @@ def main():
             print("%8d %-7s %5d %6d %12.2f %12.4g" % (nw, name, form, ctx.info("last_grid"), us, nw / (us * 1e-6)), flush=True)
             del s
     ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", 1)
+    ctx.set_option("resident_sampler", 1)
     print(json.dumps(rows))
 
 
