@@ -1293,8 +1293,12 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     int res_w = c->opt_flowr_walkers > 0 ? (int)std::min<long>(c->opt_flowr_walkers, kFrMaxWHost)
                                          : ((int)nl + c->cu_count - 1) / c->cu_count;
     const bool res_fits = res_w >= 1 && res_w <= kFrMaxWHost && ((int)nl + res_w - 1) / res_w <= c->cu_count;
-    const bool merged1_ok = c->opt_flowm && c->opt_flowm_pairs != 2 && 2 * (int)nl <= c->cu_count && wpb_1 == 1;
-    const bool resident = one_launch && res_fits && (c->opt_flowr == 2 || (c->opt_flowr == 1 && !merged1_ok));
+    // (by default only where the look-ahead forms have no room: beyond two pairs of walkers per CU.  Measured,
+    // profiles/r04/walker_sweep.txt, us per step: up to 512 walkers form 7 / form 5 / form 7 with two pairs per
+    // workgroup 6.1 / 9.7 / 11.5 against 12.6 for this form; beyond, this form against the launch train 16.3 / 19.0
+    // at 514 walkers, 16.8 / 19.2 at 1000, 23.1 / 26.0 at 2000, 35.6 / 37.9 at 4096)
+    const bool ahead_room = c->opt_flowm && 2 * (((int)nl + 1) / 2) <= c->cu_count;
+    const bool resident = one_launch && res_fits && (c->opt_flowr == 2 || (c->opt_flowr == 1 && !ahead_room));
     if (!resident) one_launch = one_launch && wpb_1 == 1;
     if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
     if (one_launch) {
