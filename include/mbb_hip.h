@@ -207,8 +207,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * before the kernel's completion signal is; "spin_budget" = polls before it falls back
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "launch_api" (how the likelihood launch of given rows
- * is handed to the runtime: 0 hipLaunchKernel, the default; 1 hipModuleLaunchKernel with the argument block as
- * one packed buffer -- measurement: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
+ * is handed to the runtime: 1, the default, hipModuleLaunchKernel with the argument block as one packed buffer;
+ * 0 hipLaunchKernel -- 0.2 us more per call: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug", "roof_threads" / "roof_wgs_per_cu" (measurement only: the geometry of
  * mbb_roof_probe), "xchg_spin_max" (polls before a launch waiting for a peer
@@ -228,6 +228,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * candidate -- run as ONE launch per 4096 steps as well, a workgroup owning several walkers of each half and doing for
  * them, half-step after half-step, what the half-step launch does, rows handed over through check words instead of a
  * launch boundary ("form 8", k_flowr: up to 8 walkers per CU and half); 0: off; 2: every eligible ensemble takes it),
+ * "resident_ahead" (default 1: that resident run constructs every walker's proposal a half-step ahead, for both outcomes of
+ * its partner's pending move, beside the quadrature of the half-step before ("form 9", k_flowa); 0: nothing ahead, form 8),
  * "resident_walkers" (walkers per workgroup and half of that form; 0 = the host's choice, ceil(half / CUs)),
  * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
  * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the

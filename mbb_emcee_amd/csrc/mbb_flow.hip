@@ -40,3 +40,13 @@ MBB_FLOWR_INST(false, true)
 MBB_FLOWR_INST(true, false)
 MBB_FLOWR_INST(true, true)
 #undef MBB_FLOWR_INST
+
+#include "mbb_flowa.hip.h"
+#define MBB_FLOWA_INST(OT, NA)                                     \
+    template __global__ void k_flowa<OT, NA, false>(const LikeArgs); \
+    template __global__ void k_flowa<OT, NA, true>(const LikeArgs);
+MBB_FLOWA_INST(false, false)
+MBB_FLOWA_INST(false, true)
+MBB_FLOWA_INST(true, false)
+MBB_FLOWA_INST(true, true)
+#undef MBB_FLOWA_INST

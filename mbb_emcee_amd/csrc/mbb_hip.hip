@@ -64,6 +64,22 @@ MBB_FLOWR_EXT(false, true)
 MBB_FLOWR_EXT(true, false)
 MBB_FLOWR_EXT(true, true)
 #undef MBB_FLOWR_EXT
+// ... and k_flowa, form 9: the same resident run with the constructor a half-step ahead (mbb_flowa.hip.h)
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void k_flowa(const LikeArgs a);
+#define MBB_FLOWA_EXT(OT, NA)                                               \
+    extern template __global__ void k_flowa<OT, NA, false>(const LikeArgs); \
+    extern template __global__ void k_flowa<OT, NA, true>(const LikeArgs);
+MBB_FLOWA_EXT(false, false)
+MBB_FLOWA_EXT(false, true)
+MBB_FLOWA_EXT(true, false)
+MBB_FLOWA_EXT(true, true)
+#undef MBB_FLOWA_EXT
+static size_t flowa_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowa_lds() of mbb_flowa.hip.h
+{
+    return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 10) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
+}
 constexpr int kFrMaxWHost = 8;
 static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h
 {
@@ -173,7 +189,7 @@ struct mbb_ctx {
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
     hipFunction_t mod_fn[40] = {};   // launch_api 1: the kernels' module handles, by variant
-    long opt_launch_api = 0;     // 0 hipLaunchKernel (triple chevron); 1 hipModuleLaunchKernel with a packed argument buffer
+    long opt_launch_api = 1;     // 1 hipModuleLaunchKernel with a packed argument buffer (-0.2 us per call, profiles/r04/boundary_breakdown.txt); 0 hipLaunchKernel
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
     size_t gather_cap = 0;
     int large_bar = -1;
@@ -211,12 +227,14 @@ struct mbb_ctx {
     long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
     long opt_flowr = 1;       // 1: ensembles beyond one pair of walkers per CU run as ONE resident launch too, several walkers per
                               // workgroup, nothing computed ahead (k_flowr, form 8); 0: off; 2: every eligible ensemble takes it
+    long opt_flowr_ahead = 1;     // that form with the SED constructor running a half-step ahead, for both outcomes of each
+                                  // partner's pending move (k_flowa, form 9); 0: nothing ahead (k_flowr, form 8)
     long opt_flowr_walkers = 0;   // walkers per workgroup and half of that form (0: the host's choice, ceil(half / CUs))
     long opt_flowm_pairs = 0; // pairs of walkers per form-7 workgroup: 0 = one while every (pair, candidate) has a CU, two beyond
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[80] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[88] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -651,6 +669,7 @@ struct SamplerLaunch {
     bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
     bool resident = false;        // k_flowr (form 8): the launch train made resident, several walkers per workgroup
     int res_w = 1;                // ... walkers per workgroup and half
+    bool res_ahead = false;       // ... with the constructor a half-step ahead (k_flowa, form 9)
     unsigned long long serial = 0;   // ... the number of its launch (in its check words and decision words)
     int parity = 0;               // ... which of the two sets of completion counters it uses
 };
@@ -728,20 +747,24 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.n_ahead = 0;
         const int Wr = sl->res_w, wgs = (n + Wr - 1) / Wr, thr = 1024;
         a.wpb = Wr;
-        a.cov_in_lds = (c->has_cov && flowr_lds_bytes(c->nb, c->npart, true, Wr) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
-        const size_t sm = flowr_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0, Wr);
+        const bool ahead = sl->res_ahead;
+        auto lds_of = [&](bool cov) { return ahead ? flowa_lds_bytes(c->nb, c->npart, cov, Wr) : flowr_lds_bytes(c->nb, c->npart, cov, Wr); };
+        a.cov_in_lds = (c->has_cov && lds_of(true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
+        const size_t sm = lds_of(a.cov_in_lds != 0);
         const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
         const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
         if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
         if (wgs > c->cu_count || Wr > kFrMaxWHost)
             return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
-        static void (*const rtable[8])(const LikeArgs) = {
+        static void (*const rtable[16])(const LikeArgs) = {
             k_flowr<false, false, false>, k_flowr<false, false, true>, k_flowr<false, true, false>, k_flowr<false, true, true>,
-            k_flowr<true, false, false>, k_flowr<true, false, true>, k_flowr<true, true, false>, k_flowr<true, true, true>};
-        const int ri = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+            k_flowr<true, false, false>, k_flowr<true, false, true>, k_flowr<true, true, false>, k_flowr<true, true, true>,
+            k_flowa<false, false, false>, k_flowa<false, false, true>, k_flowa<false, true, false>, k_flowa<false, true, true>,
+            k_flowa<true, false, false>, k_flowa<true, false, true>, k_flowa<true, true, false>, k_flowa<true, true, true>};
+        const int ri = (ahead ? 8 : 0) + ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
         kern = rtable[ri];
         c->last_wpb = Wr; c->last_threads = thr; c->last_grid = wgs; c->last_smem = (long)sm_total;
-        c->last_stage = stg ? 1 : 0; c->last_smode = 8; c->last_ahead = 0;
+        c->last_stage = stg ? 1 : 0; c->last_smode = ahead ? 9 : 8; c->last_ahead = 0;
         if (static_lds(c) + sm_total > 60 * 1024) {
             size_t &g = c->lds_granted[72 + ri];
             if (sm_total > g) {
@@ -1362,6 +1385,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.merged = merged;
                 sl.resident = resident;
                 sl.res_w = res_w;
+                sl.res_ahead = c->opt_flowr_ahead != 0;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
                 // the sampler's rows from the slots the launch's last moves went to
                 if (!merged && !resident)
@@ -1894,6 +1918,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "merged_flow_pairs")) c->opt_flowm_pairs = value;
     else if (!strcmp(name, "resident_sampler")) c->opt_flowr = value;
     else if (!strcmp(name, "resident_walkers")) c->opt_flowr_walkers = value;
+    else if (!strcmp(name, "resident_ahead")) c->opt_flowr_ahead = value;
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "flow_min_steps")) c->opt_flow_min_steps = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;

@@ -1391,6 +1391,9 @@ def test_one_hop_exchange_three_processes_one_gpu():
     _run_xchg_worker(3, {"MBB_XCHG_TEST_WALKERS": "72", "MBB_XCHG_TEST_SKIP_LOST_PEER": "1"})
 
 
+FORM_RESIDENT = 9      # what "last_kernel_form" says for the default resident run of a large ensemble (k_flowa)
+
+
 def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
@@ -1400,9 +1403,13 @@ def _sampler_forms(ctx):
             ("one launch, quadrature ahead, two pairs of walkers per workgroup",
              {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "merged_flow_pairs": 2, "resident_sampler": 0}),
             ("one launch, the train made resident (form 8), one walker of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2}),
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0}),
             ("one launch, the train made resident (form 8), three walkers of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_walkers": 3})]
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0, "resident_walkers": 3}),
+            ("one launch, resident, constructor a half-step ahead (form 9), one walker of each half per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
+            ("one launch, resident, constructor a half-step ahead (form 9), three walkers of each half per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1, "resident_walkers": 3})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
@@ -1455,8 +1462,9 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     like.context.set_option("merged_flow_sampler", 1)
 
 
-@pytest.mark.parametrize("nw,W", [(514, 0), (1000, 0), (2000, 0), (2000, 8), (4096, 0), (300, 5), (36, 8)])
-def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, g_lnl, nw, W):
+@pytest.mark.parametrize("ahead", [1, 0])
+@pytest.mark.parametrize("nw,W", [(514, 0), (1000, 0), (2000, 0), (2000, 8), (4096, 0), (300, 5), (36, 8), (26, 7), (300, 2)])
+def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, g_lnl, nw, W, ahead):
     """Sampler form 8 (k_flowr): ensembles beyond one pair of walkers per CU -- cfg3's 2000 walkers on one GPU
     among them -- run as ONE launch per run with several walkers of each half per workgroup, the rows handed over
     through check words instead of a launch boundary.  Nothing is computed ahead or twice: the chain, the final
@@ -1468,18 +1476,19 @@ def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, 
     out = []
     for resident in (0, 1):
         ctx.set_option("lookahead_sampler", resident); ctx.set_option("resident_sampler", 2 if W else 1); ctx.set_option("resident_walkers", W)
+        ctx.set_option("resident_ahead", ahead)
         s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=nw + 1)
         a = s.run_mcmc(p0, 9)
         if resident:
-            assert ctx.info("last_kernel_form") == 8 and ctx.info("flow_fallbacks") == 0
+            assert ctx.info("last_kernel_form") == (9 if ahead else 8) and ctx.info("flow_fallbacks") == 0
             assert ctx.info("last_wpb") == (W or -(-(nw // 2) // ctx.info("cu_count")))
         b = s.run_mcmc(None, 6, storechain=False)
         s.advance_async(5); ctx.sync()
         c = s.run_mcmc(None, 4)
         out.append((a[0], a[1], b[0], b[1], c[0], c[1], s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-        assert ctx.info("last_kernel_form") == (8 if resident else 1)
+        assert ctx.info("last_kernel_form") == ((9 if ahead else 8) if resident else 1)
     for x, y in zip(*out):
-        assert np.array_equal(x, y), (nw, W)
+        assert np.array_equal(x, y), (nw, W, ahead)
     assert out[0][6].shape == (nw, 13, 5) and 0.1 < out[0][8].mean() / 24 < 0.9
     lnl_close(out[1][5], like(out[1][4]))
 
@@ -1551,7 +1560,7 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
             pos, lnp, _ = s.run_mcmc(p0, nsteps)
             pos2, lnp2, _ = s.run_mcmc(None, 3)
             out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-            assert like.context.info("last_kernel_form") == (8 if "form 8" in form else
+            assert like.context.info("last_kernel_form") == (8 if "form 8" in form else 9 if "form 9" in form else
                                                              {"plain": 1, "one launch, row by row": 5,
                                                               "one launch, quadrature ahead, two pairs of walkers per workgroup": 7,
                                                               "one launch, quadrature ahead": 7}[form])
@@ -1677,7 +1686,7 @@ def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
     the launch train) -- and returns a wall time that covers the stream time."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
-    for nw, form in ((60, 7), (300, 5), (400, 7), (600, 1)):
+    for nw, form in ((60, 7), (300, 5), (400, 7), (600, FORM_RESIDENT)):
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
         a = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
         b = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
