@@ -66,6 +66,7 @@ if os.environ.get("MBB_BENCH_WALKERS_PER_GPU"):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
 N_SIMD = 1024                  # 256 CUs x 4
+ONE_LAUNCH_FORMS = (7, 8, 9)   # sampler forms whose launches cover many half-steps: counters are taken per half-step
 # N > 1: what the supervisor allows the whole run, what a rank allows any one step that may wedge (communicator
 # set-up, a rehearsal, a timed run), and the age of the run beyond which nothing optional is started any more
 SUPERVISOR_DEADLINE_S, GUARD_S, OPTIONAL_UNTIL_S = 480.0, 45.0, 240.0
@@ -179,6 +180,8 @@ def kernel_key(form, opthin=False, noalpha=False, staged=True, pairs=None):
     if form == 7:
         key = "k_flowm<%s, %s, %s," % (b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
         return key + (" %d>" % pairs if pairs else "")
+    if form in (8, 9):          # the resident forms: k_flowr (nothing ahead), k_flowa (constructor a half-step ahead)
+        return "%s<%s, %s, %s>" % ("k_flowr" if form == 8 else "k_flowa", b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
     return "k_lnlike<%s, %s, %d, %s>" % (b[bool(opthin)], b[bool(noalpha)], form, b[bool(staged)])
 
 
@@ -249,15 +252,15 @@ def dominant_kernel_roofline(form, pairs, staged, k_us, steps, kern_label, nq, n
     if err:
         roof_errors.append(err)
     per_launch = 1.0
-    if pm and form in (5, 7) and "counters_per_half_step" in pm:
+    if pm and form in ONE_LAUNCH_FORMS and "counters_per_half_step" in pm:
         pm = dict(pm)
         pm["counters_per_launch"] = pm["counters_per_half_step"]
         per_launch = 2.0 * min(steps, 4096)
-    elif pm and form in (5, 7):
+    elif pm and form in ONE_LAUNCH_FORMS:
         roof_errors.append("%s: the entry of %s has no counters_per_half_step" % (pm_src, kname))
         pm = None
     roof = valu_roofline(pm, pm_src, k_us * 1e-6, kern_label)
-    if roof and form in (5, 7):
+    if roof and form in ONE_LAUNCH_FORMS:
         roof["unit_of_counts"] = ("one half-step (125 walkers moved; the quadrature of 250 candidates and the constructor of up to "
                                   "1000 variants run for them)" if form == 7 else
                                   "one half-step (125 walkers moved, 250 proposals prepared ahead)")
@@ -303,7 +306,7 @@ def dominant_kernel_roofline(form, pairs, staged, k_us, steps, kern_label, nq, n
         roof_errors.append(err)
     traffic = None
     if tr:
-        traffic = tr.get("traffic_bytes_per_half_step" if form in (5, 7) else "traffic_bytes_per_launch")
+        traffic = tr.get("traffic_bytes_per_half_step" if form in ONE_LAUNCH_FORMS else "traffic_bytes_per_launch")
         if traffic is None:
             roof_errors.append("%s: the entry of %s has no per-half-step traffic" % (traffic_src, kname))
     hbm = {"bound": "hbm", "achieved": alg_bytes / (k_us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -312,7 +315,7 @@ def dominant_kernel_roofline(form, pairs, staged, k_us, steps, kern_label, nq, n
            "algorithmic_bytes_per_launch": alg_bytes * per_launch, "algorithmic_bytes_per_half_step": alg_bytes,
            "note": "not the binding roof (SURVEY.md 8d): fp64 transcendental work on 41 KB per half-step.  "
                    + ("Per half-step; the tables are staged once per launch, what crosses the fabric every half-step "
-                      "is the hand-over between workgroups (records, rows, the words they poll)" if form in (5, 7) else
+                      "is the hand-over between workgroups (records, rows, the words they poll)" if form in ONE_LAUNCH_FORMS else
                       "The traffic above the algorithmic bytes is the passband table, the polynomial tables and the "
                       "kernel code reaching each of the 8 XCD L2s once per launch")}
     if roof is None:
@@ -416,8 +419,8 @@ def config_roofline(name, plain_us, half_step_us, form, half, ctx):
     roof = valu_roofline(plain, src, plain_us * 1e-6,
                          "k_lnlike<plain> n=%d (%d workgroups x %d threads)" % (half, ctx.info("last_grid"), ctx.info("last_threads"))) \
         if plain else {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None}
-    smp = next((v for k, v in d["kernels"].items() if ("k_flowm<" in k or ", 5, " in k) and "counters_per_half_step" in v), None)
-    if smp and form in (5, 7):
+    smp = next((v for k, v in d["kernels"].items() if any(n in k for n in ("k_flowm<", "k_flowa<", "k_flowr<")) and "counters_per_half_step" in v), None)
+    if smp and form in ONE_LAUNCH_FORMS:
         sm = dict(smp)
         sm["counters_per_launch"] = smp["counters_per_half_step"]
         r2 = valu_roofline(sm, src, half_step_us * 1e-6, "sampler form %d, per half-step" % form)
@@ -1046,7 +1049,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = run["form"]
         out["config"] = dict(out["config"])
-        if form in (5, 6, 7):
+        if form in (6,) + ONE_LAUNCH_FORMS:
             nlaunch = (args.steps + 4095) // 4096
             if form == 7:
                 kern_label = ("k_flowm<thick,alpha,staged>: %d workgroups, one per (pair of walkers, candidate); constructor, "
@@ -1054,11 +1057,17 @@ def worker_body(args, rank, world, local_rank, base, fail):
                 out["config"]["sampler_form"] = ("one launch per 4096 steps, the quadrature of both candidates ahead of the partner's "
                                                  "decision (k_flowm, form 7): the timed region is %d launch(es) of %d half-steps"
                                                  % (nlaunch, 2 * args.steps))
+            elif form in (8, 9):
+                kern_label = ("%s<thick,alpha,staged>: %d workgroups, each owning %d walker(s) of each half%s"
+                              % ("k_flowr" if form == 8 else "k_flowa", ctx.info("last_grid"), ctx.info("last_wpb"),
+                                 "; the constructor a half-step ahead for both outcomes of the partner's pending move" if form == 9 else ""))
+                out["config"]["sampler_form"] = ("one launch per 4096 steps, resident (form %d): the timed region is %d launch(es) of %d "
+                                                 "half-steps" % (form, nlaunch, 2 * args.steps))
             else:
                 kern_label = ("k_lnlike<thick,alpha,one-launch look-ahead run,staged>: %d workgroups move walkers, %d work "
                               "ahead" % (half, ctx.info("last_workgroups_ahead")))
-                out["config"]["sampler_form"] = ("one launch per 4096 steps%s (k_lnlike SMODE %d): the timed region is %d launch(es) "
-                                                 "of %d half-steps" % (" on every rank" if form == 6 else "", form, nlaunch, 2 * args.steps))
+                out["config"]["sampler_form"] = ("one launch per 4096 steps on every rank (k_lnlike SMODE %d): the timed region is %d "
+                                                 "launch(es) of %d half-steps" % (form, nlaunch, 2 * args.steps))
             out["kernel_avg_us"] = stream_ms * 1e3 / nlaunch
         else:
             kern_label = "k_lnlike<thick,alpha,sampler,staged> n=%d" % half
@@ -1278,11 +1287,13 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     last = props[(2 * (ksteps - 1) + 1) % (2 * NSETS)]
     assert np.array_equal(like(last), got, equal_nan=True)
 
-    # ---- the same chain as a train of launches, one per half-step (what round 1 and the
-    # first half of round 2 timed), and with the look-ahead as extra workgroups of each launch
+    # ---- the same chain in the sampler's other forms: a train of launches, one per half-step (what round 1 and the
+    # first half of round 2 timed), and the resident forms larger ensembles take (form 9: the constructor a half-step
+    # ahead; form 8: nothing ahead), here with one walker of each half per workgroup
     forms = {}
     for name, opts in (("one_launch_per_half_step", {"lookahead_sampler": 0}),
-                       ("one_launch_per_run_proposals_ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0})):
+                       ("resident_constructor_ahead_form9", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
+                       ("resident_nothing_ahead_form8", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0})):
         for o, v in opts.items():
             ctx.set_option(o, v)
         s2 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
@@ -1291,9 +1302,11 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
         f0, f1 = ctx.event(), ctx.event()
         ctx.record(f0); s2.advance_async(ksteps); ctx.record(f1); ctx.sync()
         forms[name] = {"stream_us_per_step": ctx.elapsed_ms(f0, f1) * 1e3 / ksteps,
-                       "evals_per_s": NW_PER_GPU * ksteps / (ctx.elapsed_ms(f0, f1) * 1e-3)}
+                       "evals_per_s": NW_PER_GPU * ksteps / (ctx.elapsed_ms(f0, f1) * 1e-3),
+                       "kernel_form": ctx.info("last_kernel_form")}
         del s2
     ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", 1)
+    ctx.set_option("resident_sampler", 1); ctx.set_option("resident_ahead", 1)
     forms["note"] = "the other forms of the device sampler, same chain bit for bit (stream time, HIP events)"
     out["other_sampler_forms"] = forms
 

@@ -212,27 +212,25 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
  * "virtual_ranks", "debug", "roof_threads" / "roof_wgs_per_cu" (measurement only: the geometry of
  * mbb_roof_probe), "xchg_spin_max" (polls before a launch waiting for a peer
- * gives up); the forms of the single-GPU sampler, same chains bit for bit:
+ * gives up); the forms of the single-GPU sampler, same chains bit for bit (which one a run takes by default, and
+ * what each costs: sampler_enqueue in mbb_hip.hip, profiles/r04/walker_sweep.txt):
  * "lookahead_sampler" (default 1; 0: the plain train of one launch per half-step),
- * "flow_sampler" (default 1: one launch per 4096 steps, the half-steps handing over row by row, the
- * proposals prepared ahead of the decisions they depend on; 0: the plain train as well),
+ * "flow_sampler" (default 1: one launch per 4096 steps, every workgroup resident, rows handed over through check
+ * words instead of a launch boundary; 0: the plain train as well),
  * "flow_min_steps" (runs shorter than this take the plain train: a one-launch run costs ~14 us
  * beside its steps; default from profiles/r03/flowm_short_runs.txt),
- * "merged_flow_sampler" (default 1: in that one launch the passband quadrature of both proposals a
- * walker can end up making, and the SED constructor for every outcome still open, run ahead of the
- * decisions they depend on -- one workgroup per pair of walkers and candidate, ensembles up to two
- * walkers per CU ("form 7"); 0: only the proposals are prepared ahead ("form 5")),
- * "merged_flow_pairs" (pairs of walkers a form-7 workgroup serves: 0 = the host's choice -- one while every
- * pair and candidate has a CU of its own, two for the ensembles beyond, up to four walkers per CU; 1 or 2 force it),
- * "resident_sampler" (default 1: ensembles beyond one pair of walkers per CU -- where form 7 has no CU per pair and
- * candidate -- run as ONE launch per 4096 steps as well, a workgroup owning several walkers of each half and doing for
- * them, half-step after half-step, what the half-step launch does, rows handed over through check words instead of a
- * launch boundary ("form 8", k_flowr: up to 8 walkers per CU and half); 0: off; 2: every eligible ensemble takes it),
- * "resident_ahead" (default 1: that resident run constructs every walker's proposal a half-step ahead, for both outcomes of
- * its partner's pending move, beside the quadrature of the half-step before ("form 9", k_flowa); 0: nothing ahead, form 8),
- * "resident_walkers" (walkers per workgroup and half of that form; 0 = the host's choice, ceil(half / CUs)),
- * "lookahead_rows" / "lookahead_waves" (0 = the host's choice: candidates per wave and waves per
- * workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
+ * "merged_flow_sampler" (default 1: ensembles of up to two walkers per CU take "form 7", k_flowm -- one workgroup per
+ * pair of walkers and candidate; the passband quadrature of both proposals a walker can end up making, and the SED
+ * constructor for every outcome still open, run ahead of the decisions they depend on; 0: those ensembles take the
+ * resident forms below too),
+ * "resident_sampler" (default 1: ensembles beyond that run as ONE launch per 4096 steps as well, a workgroup owning
+ * W = ceil(half / CUs) walkers of each half, up to 8; 0: off, the plain train; 2: every eligible ensemble takes it),
+ * "resident_ahead" (default 1: up to four walkers per CU and half that run constructs every walker's proposal a half-step
+ * ahead, for both outcomes of its partner's pending move, beside the quadrature of the half-step before -- "form 9",
+ * k_flowa; beyond, and with 0, nothing runs ahead -- "form 8", k_flowr; 2: always ahead),
+ * "resident_walkers" (walkers per workgroup and half of the resident forms; 0 = the host's choice),
+ * "lookahead_rows" / "lookahead_waves" (the sharded one-launch run: 0 = the host's choice of candidates per wave and
+ * waves per workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),
  * "flow_spin_log2" (0 = 22: log2 of the polls before a wait
  * inside the one-launch run gives up; mbb_sampler_run then redoes the run as a launch train and

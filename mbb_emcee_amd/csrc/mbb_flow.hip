@@ -1,4 +1,4 @@
-// mbb_flow.hip -- the one-launch look-ahead sampler run (k_lnlike, SMODE 5; SMODE 6 sharded) in a translation unit
+// mbb_flow.hip -- the one-launch sampler runs (k_flowm, k_flowr, k_flowa; k_lnlike SMODE 6, sharded) in a translation unit
 // of its own, because it wants other code generation than the rest of the library: the kernel
 // is a loop over half-steps around two long dependent chains, and with the default pipeline the
 // compiler hoists every loop-invariant value out of that loop, runs out of registers and
@@ -9,8 +9,6 @@
 #include "mbb_kernels.hip.h"
 
 #define MBB_FLOW_INST(OT, NA)                                            \
-    template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
-    template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);  \
     template __global__ void k_lnlike<OT, NA, 6, false>(const LikeArgs); \
     template __global__ void k_lnlike<OT, NA, 6, true>(const LikeArgs);
 MBB_FLOW_INST(false, false)
@@ -22,9 +20,7 @@ MBB_FLOW_INST(true, true)
 #include "mbb_flowm.hip.h"
 #define MBB_FLOWM_INST(OT, NA)                                            \
     template __global__ void k_flowm<OT, NA, false, 1>(const LikeArgs); \
-    template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);  \
-    template __global__ void k_flowm<OT, NA, false, 2>(const LikeArgs); \
-    template __global__ void k_flowm<OT, NA, true, 2>(const LikeArgs);
+    template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);
 MBB_FLOWM_INST(false, false)
 MBB_FLOWM_INST(false, true)
 MBB_FLOWM_INST(true, false)

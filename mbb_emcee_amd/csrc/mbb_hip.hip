@@ -29,10 +29,8 @@
 #include "mbb_device.hip.h"
 #include "mbb_kernels.hip.h"
 
-// SMODE 5 and 6 are instantiated in mbb_flow.hip (its own compiler flags)
+// SMODE 6 is instantiated in mbb_flow.hip (its own compiler flags)
 #define MBB_FLOW_EXT(OT, NA)                                                    \
-    extern template __global__ void k_lnlike<OT, NA, 5, false>(const LikeArgs); \
-    extern template __global__ void k_lnlike<OT, NA, 5, true>(const LikeArgs);  \
     extern template __global__ void k_lnlike<OT, NA, 6, false>(const LikeArgs); \
     extern template __global__ void k_lnlike<OT, NA, 6, true>(const LikeArgs);
 MBB_FLOW_EXT(false, false)
@@ -45,9 +43,7 @@ template <bool OPTHIN, bool NOALPHA, bool STAGE, int NP>
 __global__ void k_flowm(const LikeArgs a);
 #define MBB_FLOWM_EXT(OT, NA)                                                   \
     extern template __global__ void k_flowm<OT, NA, false, 1>(const LikeArgs); \
-    extern template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);  \
-    extern template __global__ void k_flowm<OT, NA, false, 2>(const LikeArgs); \
-    extern template __global__ void k_flowm<OT, NA, true, 2>(const LikeArgs);
+    extern template __global__ void k_flowm<OT, NA, true, 1>(const LikeArgs);
 MBB_FLOWM_EXT(false, false)
 MBB_FLOWM_EXT(false, true)
 MBB_FLOWM_EXT(true, false)
@@ -230,7 +226,6 @@ struct mbb_ctx {
     long opt_flowr_ahead = 1;     // that form with the SED constructor running a half-step ahead, for both outcomes of each
                                   // partner's pending move (k_flowa, form 9); 0: nothing ahead (k_flowr, form 8)
     long opt_flowr_walkers = 0;   // walkers per workgroup and half of that form (0: the host's choice, ceil(half / CUs))
-    long opt_flowm_pairs = 0; // pairs of walkers per form-7 workgroup: 0 = one while every (pair, candidate) has a CU, two beyond
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
@@ -792,10 +787,8 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.n_ahead = 0;
         const int nq = std::min(threads / 64, 11);
         const int thr = (nq + 5) * 64;
-        // pairs of walkers per workgroup: one where every (pair, candidate) gets a CU of its own, else two --
-        // the roles then take the two pairs one after the other in every half-step (mbb_flowm.hip.h)
-        const int np = c->opt_flowm_pairs == 1 ? 1 : (c->opt_flowm_pairs == 2 ? 2 : (2 * n <= c->cu_count ? 1 : 2));
-        const int wgs = 2 * ((n + np - 1) / np);
+        const int np = 1;              // (round 3 also had two pairs of walkers per workgroup: superseded by form 9)
+        const int wgs = 2 * n;
         a.cov_in_lds = (c->has_cov && flowm_lds_bytes(c->nb, c->npart, true, np) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
         const size_t sm = flowm_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0, np);
         const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
@@ -803,13 +796,11 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
         if (wgs > c->cu_count)
             return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
-#define MBB_FM_TABLE(NP)                                                                                        \
-    k_flowm<false, false, false, NP>, k_flowm<false, false, true, NP>, k_flowm<false, true, false, NP>,       \
-        k_flowm<false, true, true, NP>, k_flowm<true, false, false, NP>, k_flowm<true, false, true, NP>,      \
-        k_flowm<true, true, false, NP>, k_flowm<true, true, true, NP>
-        static void (*const mtable[16])(const LikeArgs) = {MBB_FM_TABLE(1), MBB_FM_TABLE(2)};
-#undef MBB_FM_TABLE
-        const int mi = (np - 1) * 8 + ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+        static void (*const mtable[8])(const LikeArgs) = {
+            k_flowm<false, false, false, 1>, k_flowm<false, false, true, 1>, k_flowm<false, true, false, 1>,
+            k_flowm<false, true, true, 1>, k_flowm<true, false, false, 1>, k_flowm<true, false, true, 1>,
+            k_flowm<true, true, false, 1>, k_flowm<true, true, true, 1>};
+        const int mi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
         kern = mtable[mi];
         c->last_wpb = np; c->last_threads = thr; c->last_grid = wgs; c->last_smem = (long)sm_total;
         c->last_stage = stg ? 1 : 0; c->last_smode = 7; c->last_ahead = 0;
@@ -858,19 +849,20 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     }
     {
         // forms: 0 the likelihood of given rows, 1 the half-step, 2 the half-step with the one-hop
-        // exchange, 5 / 6 the one-launch look-ahead run on one GPU / across ranks (slots 3, 4)
-        const int smode = !sl ? 0 : (sl->spec ? (sl->xflow ? 6 : 5) : (sl->xseq ? 2 : 1));
-        const int slot = smode >= 5 ? smode - 2 : smode;
-        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 10 + slot * 2 + (stage ? 1 : 0);
+        // exchange, 6 the one-launch look-ahead run across the ranks of a sharded ensemble (slot 3).
+        // (Its single-GPU twin, SMODE 5, went in round 4: forms 7 and 9 are faster at every ensemble size.)
+        const int smode = !sl ? 0 : (sl->spec ? 6 : (sl->xseq ? 2 : 1));
+        if (sl && sl->spec && !sl->xflow) return fail(MBB_ERR_STATE, "one-launch run without a form");
+        const int slot = smode == 6 ? 3 : smode;
+        const int vi = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 8 + slot * 2 + (stage ? 1 : 0);
         c->last_smode = smode;
-        c->last_ahead = smode >= 5 ? a.n_ahead : 0;
+        c->last_ahead = smode == 6 ? a.n_ahead : 0;
         vi_of_kernel = vi;
 #define MBB_VARIANTS(OT, NA)                                                                        \
     k_lnlike<OT, NA, 0, false>, k_lnlike<OT, NA, 0, true>, k_lnlike<OT, NA, 1, false>,              \
         k_lnlike<OT, NA, 1, true>, k_lnlike<OT, NA, 2, false>, k_lnlike<OT, NA, 2, true>,           \
-        k_lnlike<OT, NA, 5, false>, k_lnlike<OT, NA, 5, true>,                                      \
         k_lnlike<OT, NA, 6, false>, k_lnlike<OT, NA, 6, true>
-        static void (*const table[40])(const LikeArgs) = {
+        static void (*const table[32])(const LikeArgs) = {
             MBB_VARIANTS(false, false), MBB_VARIANTS(false, true), MBB_VARIANTS(true, false),
             MBB_VARIANTS(true, true)};
 #undef MBB_VARIANTS
@@ -1302,27 +1294,28 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     }
     int wpb_1 = 0, thr_1 = 0;
     pick_geometry(c, (int)nl, wpb_1, thr_1);
-    // Option "lookahead_sampler" (default 1) -- one GPU, one ensemble, one walker per workgroup, every
-    // workgroup resident: the run is ONE launch per 4096 steps in which the next half-steps' proposals
-    // (draw, SED constructor, penalties) are prepared for both outcomes of each partner's pending move
-    // while this half-step is being decided, so that a mover starts from a finished record instead
-    // of the ~4 us dependent chain of the constructor.  Same draws, same arithmetic: chains are
-    // bitwise those of the plain launch train, which is what larger ensembles, several sources and
-    // very short runs take.
+    // Options "lookahead_sampler" / "flow_sampler" (default 1) -- one GPU, one ensemble, every workgroup resident: the run
+    // is ONE launch per 4096 steps, rows handed over through check words instead of a launch boundary; chains are bitwise
+    // those of the plain launch train, which is what several sources, very short runs and ensembles beyond 8 walkers per CU
+    // and half take.  Which form (profiles/r04/walker_sweep.txt, us per MCMC step, cfg2 bands):
+    //   form 7 (k_flowm): a workgroup per (pair of walkers, candidate), quadrature and constructor ahead of the decisions
+    //           they depend on -- while each has a CU of its own: 6.0-6.3 up to 256 walkers;
+    //   form 9 (k_flowa): a workgroup owns W = ceil(half / CUs) walkers of each half, the constructor a half-step ahead
+    //           for both outcomes of the partner's pending move -- 8.2-8.6 from 258 to 512 walkers (round 3's forms there,
+    //           removed this round: form 5 9.6-10.2 up to 340, form 7 with two pairs per workgroup 11.5 up to 512),
+    //           11.8-12.0 up to 1000, 17.3 at 1500, 21.0 at 2000 (train: 18.9 / 19.1 / 22.4 / 25.9);
+    //   form 8 (k_flowr): the same ownership, nothing ahead -- from five walkers per CU and half on, where the constructor
+    //           waves of form 9 cost the quadrature more than running ahead gains: 29.3 at 3000, 35.5 at 4096 (32.0 / 37.9).
     bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&
                       nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps);
-    // form 8 (k_flowr): several walkers of each half per workgroup, nothing ahead -- what ensembles beyond one
-    // pair of walkers per CU take (up to kFrMaxWHost walkers per CU and half)
+    const bool merged = one_launch && c->opt_flowm && c->opt_flowr != 2 && 2 * (int)nl <= c->cu_count && wpb_1 == 1;
     int res_w = c->opt_flowr_walkers > 0 ? (int)std::min<long>(c->opt_flowr_walkers, kFrMaxWHost)
                                          : ((int)nl + c->cu_count - 1) / c->cu_count;
     const bool res_fits = res_w >= 1 && res_w <= kFrMaxWHost && ((int)nl + res_w - 1) / res_w <= c->cu_count;
-    // (by default only where the look-ahead forms have no room: beyond two pairs of walkers per CU.  Measured,
-    // profiles/r04/walker_sweep.txt, us per step: up to 512 walkers form 7 / form 5 / form 7 with two pairs per
-    // workgroup 6.1 / 9.7 / 11.5 against 12.6 for this form; beyond, this form against the launch train 16.3 / 19.0
-    // at 514 walkers, 16.8 / 19.2 at 1000, 23.1 / 26.0 at 2000, 35.6 / 37.9 at 4096)
-    const bool ahead_room = c->opt_flowm && 2 * (((int)nl + 1) / 2) <= c->cu_count;
-    const bool resident = one_launch && res_fits && (c->opt_flowr == 2 || (c->opt_flowr == 1 && !ahead_room));
-    if (!resident) one_launch = one_launch && wpb_1 == 1;
+    const bool resident = one_launch && !merged && c->opt_flowr != 0 && res_fits;
+    // (the constructor ahead up to four walkers per CU and half; option "resident_ahead": 0 never, 2 always)
+    const bool res_ahead = c->opt_flowr_ahead == 2 || (c->opt_flowr_ahead == 1 && res_w <= 4);
+    one_launch = merged || resident;
     if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
     if (one_launch) {
         const size_t R = (size_t)s->rows();
@@ -1332,21 +1325,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
             HIPCHK(hipMalloc((void **)&s->d_spec, spec_words(R) * sizeof(double)));
             HIPCHK(hipMemsetAsync(s->d_spec, 0, spec_words(R) * sizeof(double), c->stream));
         }
-        int la_rows, la_aw, la_ahead;
-        bool la_sparse = false;
-        const bool la_worth = lookahead_plan(c, (int)nl, thr_1, half, la_rows, la_aw, la_ahead, &la_sparse);
-        // Which one-launch form (profiles/r03/walker_sweep.txt, us per step): form 7 with a workgroup per (pair,
-        // candidate) while each has a CU of its own (6.1, up to 256 walkers); beyond, form 5 while its working-ahead
-        // workgroups hold at most 8 candidates each (9.6-10.2, up to ~340 walkers); then form 7 with two pairs per
-        // workgroup (11.1, flat up to 512 walkers; form 5 is at 13.6-15 there and the launch train at 15.7)
-        const bool form5 = la_worth && la_ahead + (int)nl <= c->cu_count;
-        const bool merged1 = c->opt_flowm && c->opt_flowm_pairs != 2 && 2 * (int)nl <= c->cu_count;
-        const bool merged2 = c->opt_flowm && c->opt_flowm_pairs != 1 && 2 * (((int)nl + 1) / 2) <= c->cu_count;
-        const bool merged = !resident && (merged1 || (merged2 && (c->opt_flowm_pairs == 2 || !(form5 && la_sparse))));
-        if (merged || form5 || resident) {
-            // ... and all of it in ONE launch per 4096 steps (k_lnlike SMODE 5): every workgroup is
-            // resident, the tables are staged once, a row's half-step starts when the rows it
-            // depends on are done (no launch boundary, no grid-wide barrier)
+        {
             sl.spec = s->d_spec;
             // what the run starts from, kept so that a run that times out (a workgroup that is not
             // resident: another process on the GPU) can be redone as a launch train (mbb_sampler_run)
@@ -1364,19 +1343,13 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 HIPCHK(hipMemsetAsync(fvh.done, 0, 2 * kFmRing * 16 * sizeof(unsigned long long), c->stream));
                 s->flowm_parity = 0;
             }
-            s->spec_form = resident ? 8 : (merged ? 7 : 5);
+            s->spec_form = resident ? 8 : 7;
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
-                if (merged || resident) {
-                    // one launch, nothing before or after it: it files the rows it finds and stores the last ones back
-                    sl.serial = ++g_flow_serial;
-                    sl.parity = s->flowm_parity;
-                    s->flowm_parity ^= 1;
-                } else {
-                    hipLaunchKernelGGL(k_flow_init, dim3((unsigned)((R * 8 + 255) / 256)), dim3(256), 0, c->stream,
-                                       s->d_pos6, s->d_spec, (int)R);
-                }
-                HIPCHK(hipGetLastError());
+                // one launch, nothing before or after it: it files the rows it finds and stores the last ones back
+                sl.serial = ++g_flow_serial;
+                sl.parity = s->flowm_parity;
+                s->flowm_parity ^= 1;
                 sl.s_begin = 0; sl.c_begin = half; sl.step = t0; sl.half = 0;
                 sl.persist = 2 * nt;
                 sl.chain6 = store ? s->d_chain6 + ((size_t)t0 * 2 * nl) * 6 : nullptr;
@@ -1385,18 +1358,12 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.merged = merged;
                 sl.resident = resident;
                 sl.res_w = res_w;
-                sl.res_ahead = c->opt_flowr_ahead != 0;
+                sl.res_ahead = res_ahead;
                 if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
-                // the sampler's rows from the slots the launch's last moves went to
-                if (!merged && !resident)
-                    hipLaunchKernelGGL(k_flow_finish, dim3((unsigned)((R * 6 + 255) / 256)), dim3(256), 0, c->stream, s->d_pos6,
-                                       s->d_spec, (int)R, 2 * nt);
-                HIPCHK(hipGetLastError());
             }
             s->steps_done += (unsigned long long)nsteps;
             return MBB_OK;
         }
-        // (no room for the workgroups that work ahead: the launch train)
     }
     sl.spec = nullptr; sl.merged = false; sl.resident = false; sl.persist = 0;
     for (int t = 0; t < nsteps; ++t)
@@ -1915,7 +1882,6 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
     else if (!strcmp(name, "flow_sampler")) c->opt_flow = value;
     else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
-    else if (!strcmp(name, "merged_flow_pairs")) c->opt_flowm_pairs = value;
     else if (!strcmp(name, "resident_sampler")) c->opt_flowr = value;
     else if (!strcmp(name, "resident_walkers")) c->opt_flowr_walkers = value;
     else if (!strcmp(name, "resident_ahead")) c->opt_flowr_ahead = value;

@@ -1397,11 +1397,8 @@ FORM_RESIDENT = 9      # what "last_kernel_form" says for the default resident r
 def _sampler_forms(ctx):
     """(name, options) of the single-GPU device sampler's forms; the first is the reference."""
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
-            ("one launch, row by row", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0, "resident_sampler": 0}),
-            ("one launch, quadrature ahead", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1,
-                                              "merged_flow_pairs": 0, "resident_sampler": 0}),
-            ("one launch, quadrature ahead, two pairs of walkers per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "merged_flow_pairs": 2, "resident_sampler": 0}),
+            ("one launch, quadrature ahead (form 7)", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1,
+                                                       "resident_sampler": 1}),
             ("one launch, the train made resident (form 8), one walker of each half per workgroup",
              {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0}),
             ("one launch, the train made resident (form 8), three walkers of each half per workgroup",
@@ -1409,18 +1406,18 @@ def _sampler_forms(ctx):
             ("one launch, resident, constructor a half-step ahead (form 9), one walker of each half per workgroup",
              {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
             ("one launch, resident, constructor a half-step ahead (form 9), three walkers of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1, "resident_walkers": 3})]
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1, "resident_walkers": 3}),
+            ("one launch, resident, constructor a half-step ahead (form 9), seven walkers of each half per workgroup",
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 2, "resident_walkers": 7})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
-    """The device sampler prepares the next half-step's proposals (draw, SED constructor,
-    penalties) ahead of time, for both outcomes of each partner's pending move -- in ONE launch per
-    run whose half-steps hand over row by row (SMODE 5), or, by default, in one launch per run where the passband quadrature of both
-    candidates runs ahead of the partner's decision as well (k_flowm, form 7: one workgroup per pair of
-    walkers and candidate).  Same draws and same arithmetic, so chain,
-    lnprob, final state and acceptance counts must be bitwise those of the plain train of one
-    launch per half-step: every model variant, stored and unstored runs in sequence, shapes of
-    the working-ahead workgroups other than the host's choice."""
+    """The one-launch forms of the device sampler -- form 7 (k_flowm: one workgroup per pair of walkers and candidate,
+    quadrature and constructor ahead of the decisions they depend on), form 8 (k_flowr: the launch train made resident,
+    several walkers of each half per workgroup) and form 9 (k_flowa: the same with the constructor a half-step ahead for
+    both outcomes of each partner's pending move) -- make the same draws and do the same arithmetic per proposal as the
+    plain train of one launch per half-step, so chain, lnprob, final state and acceptance counts must be bitwise its:
+    every model variant, stored and unstored runs in sequence."""
     bands = [str(b) for b in g_lnl["cfg2/bands"]]
     for name, opthin, noalpha in VARIANTS:
         k = "cfg2/" + name
@@ -1441,25 +1438,6 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
             for x, y in zip(res[0], r):
                 assert np.array_equal(x, y), (name, form[0])
         assert res[0][6].shape == (250, 47, 5) and 0.1 < res[0][8].mean() / 102 < 0.9
-    # other shapes of the workgroups that work ahead
-    like = mbb.likelihood(response=True)
-    like.set_phot(bands, g_lnl["cfg2/thick_walpha/flux"], g_lnl["cfg2/thick_walpha/unc"])
-    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(5).normal(size=(100, 5)))
-    ref = None
-    for flow, rows, waves in ((1, 0, 0), (1, 2, 4), (1, 4, 16), (1, 1, 7), (1, 1, 16), (1, 4, 4), (1, 2, 3)):
-        ctx = like.context
-        ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", flow); ctx.set_option("merged_flow_sampler", 0)
-        ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
-        s = mbb.DeviceEnsembleSampler(100, 5, like, seed=3)
-        out = s.run_mcmc(p0, 30)[:2] + (s.chain.copy(), s.naccepted.copy())
-        if ref is None:
-            ctx.set_option("lookahead_sampler", 0)
-            s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=3)
-            ref = s0.run_mcmc(p0, 30)[:2] + (s0.chain.copy(), s0.naccepted.copy())
-        for x, y in zip(ref, out):
-            assert np.array_equal(x, y), (flow, rows, waves)
-    like.context.set_option("lookahead_rows", 0); like.context.set_option("lookahead_waves", 0)
-    like.context.set_option("merged_flow_sampler", 1)
 
 
 @pytest.mark.parametrize("ahead", [1, 0])
@@ -1560,10 +1538,7 @@ def test_lookahead_sampler_forms_other_band_sets_and_geometries(mbb, g_lnl):
             pos, lnp, _ = s.run_mcmc(p0, nsteps)
             pos2, lnp2, _ = s.run_mcmc(None, 3)
             out.append((pos, lnp, pos2, lnp2, s.chain.copy(), s.lnprobability.copy(), s.naccepted.copy()))
-            assert like.context.info("last_kernel_form") == (8 if "form 8" in form else 9 if "form 9" in form else
-                                                             {"plain": 1, "one launch, row by row": 5,
-                                                              "one launch, quadrature ahead, two pairs of walkers per workgroup": 7,
-                                                              "one launch, quadrature ahead": 7}[form])
+            assert like.context.info("last_kernel_form") == (1 if form == "plain" else int(form[form.index("(form ") + 6]))
         for form, r in zip(_sampler_forms(None)[1:], out[1:]):
             for x, y in zip(out[0], r):
                 assert np.array_equal(x, y), (form[0], options)
@@ -1642,12 +1617,10 @@ def test_random_sampler_configurations_all_forms_equal(mbb, seed):
     for form, r in zip(_sampler_forms(None)[1:], res[1:]):
         for x, y in zip(res[0], r):
             assert np.array_equal(x, y, equal_nan=True), (seed, form[0], names, nw, opts)
-    assert forms[0] == 1
-    if nw <= 256:
-        assert forms[2] == 7 and forms[3] == 7, forms       # every (pair, candidate) has a CU / two pairs share one
-    elif nw <= 500:
-        # form 5 while its working-ahead workgroups stay sparse, form 7 with two pairs per workgroup beyond
-        assert forms[1] in (5, 1) and forms[2] in (5, 7) and forms[3] == 7, forms
+    # (the forced forms ran as asked; the default one-launch entry: form 7 while every pair and candidate has a CU
+    # of its own, the resident form with the constructor ahead beyond)
+    assert forms[0] == 1 and forms[2:] == [8, 8, 9, 9, 9], forms
+    assert forms[1] == (7 if nw <= 256 else 9), (nw, forms)
 
 
 def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
@@ -1682,11 +1655,12 @@ def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
 
 def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
     """mbb_sampler_advance_timed (bench.py's timed region on one GPU) enqueues exactly what advance_async does --
-    the same chain afterwards, whatever form the run takes (form 7, form 7 with two pairs per workgroup, form 5,
-    the launch train) -- and returns a wall time that covers the stream time."""
+    the same chain afterwards, whatever form the run takes (form 7; form 9 with one, two and four walkers of each half
+    per workgroup; form 8 beyond; the launch train for an ensemble too large for any) -- and returns a wall time that
+    covers the stream time."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
-    for nw, form in ((60, 7), (300, 5), (400, 7), (600, FORM_RESIDENT)):
+    for nw, form in ((60, 7), (300, 9), (600, 9), (2000, 9), (2600, 8), (4200, 1)):
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
         a = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
         b = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
@@ -1700,36 +1674,32 @@ def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
 
 
 def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
-    """The one-launch run needs every workgroup on the GPU at once.  A shape of the working-ahead
-    workgroups that does not fit (forced through the options here; too many walkers elsewhere) is
-    not started and left to time out: the run takes the launch-per-half-step form, same chain."""
+    """The one-launch forms need every workgroup on the GPU at once.  An ensemble with no form that fits -- more
+    than 8 walkers per CU and half, or the resident forms switched off beyond form 7's range -- is not started and
+    left to time out: the run takes the launch-per-half-step form, same chain; and each form ends where the next
+    begins."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
-    ctx.set_option("resident_sampler", 0)          # (this is about forms 5 and 7; form 8 takes over what they cannot hold)
-    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(250, 5)))
-    out = []
-    for rows, waves, merged, form in ((1, 1, 0, 1), (0, 0, 0, 5), (0, 0, 1, 7)):     # 500 + 125 workgroups do not fit 256 CUs
-        ctx.set_option("lookahead_rows", rows); ctx.set_option("lookahead_waves", waves)
-        ctx.set_option("merged_flow_sampler", merged)
-        s = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
+    cus = ctx.info("cu_count")
+    for nw, opts, form in ((cus, {}, 7), (cus + 2, {}, 9), (cus + 2, {"resident_sampler": 0}, 1), (8 * cus, {}, 9),
+                           (8 * cus + 2, {}, 8), (16 * cus, {}, 8), (16 * cus + 2, {}, 1), (cus, {"merged_flow_sampler": 0}, 9),
+                           (60, {"resident_sampler": 2, "resident_walkers": 9}, 8)):
+        for o in ("merged_flow_sampler", "resident_sampler"):
+            ctx.set_option(o, 1)
+        ctx.set_option("resident_walkers", 0)
+        for o, v in opts.items():
+            ctx.set_option(o, v)
+        p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(nw, 5)))
+        ctx.set_option("lookahead_sampler", 1)
+        s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=9)
         pos, lnp, _ = s.run_mcmc(p0, 4)
-        assert ctx.info("last_kernel_form") == form and np.isfinite(lnp).all()
-        out.append((pos, lnp, s.chain.copy()))
-    ctx.set_option("lookahead_sampler", 0)
-    s2 = mbb.DeviceEnsembleSampler(250, 5, like, seed=9)
-    pos2, lnp2, _ = s2.run_mcmc(p0, 4)
-    for pos, lnp, ch in out:
-        assert np.array_equal(pos, pos2) and np.array_equal(lnp, lnp2) and np.array_equal(ch, s2.chain)
-    # 300 walkers: 150 pairs x 2 candidates do not fit one per CU (form 7), 150 movers + 150 ahead do (form 5)
-    ctx.set_option("lookahead_sampler", 1)
-    p3 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(300, 5)))
-    s3 = mbb.DeviceEnsembleSampler(300, 5, like, seed=9)
-    r3 = s3.run_mcmc(p3, 4)[:2]
-    assert ctx.info("last_kernel_form") == 5
-    ctx.set_option("lookahead_sampler", 0)
-    s4 = mbb.DeviceEnsembleSampler(300, 5, like, seed=9)
-    r4 = s4.run_mcmc(p3, 4)[:2]
-    assert np.array_equal(r3[0], r4[0]) and np.array_equal(r3[1], r4[1]) and np.array_equal(s3.chain, s4.chain)
+        assert ctx.info("last_kernel_form") == form and np.isfinite(lnp).all(), (nw, opts, ctx.info("last_kernel_form"))
+        if nw > 8 * cus:
+            continue                                          # (the large ones are compared in the test above this one's size)
+        ctx.set_option("lookahead_sampler", 0)
+        s2 = mbb.DeviceEnsembleSampler(nw, 5, like, seed=9)
+        pos2, lnp2, _ = s2.run_mcmc(p0, 4)
+        assert np.array_equal(pos, pos2) and np.array_equal(lnp, lnp2) and np.array_equal(s.chain, s2.chain), (nw, opts)
 
 
 def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, g_lnl):
@@ -1739,9 +1709,10 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
     of launches -- the caller gets the chain it would have got, with a warning.  A give-up is a
     property of the moment: the next run takes the one-launch form again; only three give-ups in a
     row rest it, for sixteen runs."""
-    for merged, form in ((1, 7), (0, 5)):
+    for merged, ahead, form in ((1, 1, 7), (0, 1, 9), (0, 0, 8)):
         like = _cfg2_like(mbb, g_lnl)
         ctx = like.context
+        ctx.set_option("resident_ahead", ahead)
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(100, 5)))
         ctx.set_option("lookahead_sampler", 0)
         s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)

@@ -341,9 +341,9 @@ def test_bench_roofline_lookups_name_kernels_the_library_has_and_the_committed_s
     import bench
     lib = os.path.join(ROOT, "mbb_emcee_amd", "libmbb_hip.so")
     syms = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
-    have = set(re.findall(r"\bvoid (k_(?:lnlike|flowm)<[^>]*>)\(LikeArgs\)", syms))
+    have = set(re.findall(r"\bvoid (k_(?:lnlike|flowm|flowa|flowr)<[^>]*>)\(LikeArgs\)", syms))
     assert len(have) >= 50
-    keys = [bench.kernel_key(7, pairs=1), bench.kernel_key(7, pairs=2), bench.kernel_key(5), bench.kernel_key(1),
+    keys = [bench.kernel_key(7, pairs=1), bench.kernel_key(8), bench.kernel_key(9), bench.kernel_key(1),
             bench.kernel_key(0), bench.kernel_key(0, staged=False), bench.kernel_key(7, opthin=True, pairs=1),
             bench.kernel_key(0, opthin=True)]
     for key in keys:
@@ -358,7 +358,7 @@ def test_bench_roofline_lookups_name_kernels_the_library_has_and_the_committed_s
     assert os.path.exists(os.path.join(ROOT, roof["counters_source"]))
     assert os.path.exists(os.path.join(ROOT, hbm["traffic_source"]))
     # the other sampler forms: the algorithmic figure is always there; a missing summary is said, not hidden
-    for form in (5, 1):
+    for form in (9, 8, 1):
         r, h = bench.dominant_kernel_roofline(form, 1, True, 5.0, 20, "label", 2209, 8, 125)
         assert np.isfinite(r["frac"]) and r["frac"] > 0
         assert (r["counted"]["frac"] is not None) or r.get("error")
@@ -703,6 +703,37 @@ def test_flowm_protocol_model():
     assert finished and lead <= lag + nb
     with pytest.raises(FM.Violation):
         F7.run(ix, lib, n2, 10, random.Random(1), guard=False, partner=avoid0, stall=((0, 0), 4, 20000))
+
+
+def test_resident_forms_protocol_model():
+    """The hand-over protocol of the resident sampler forms (k_flowr, form 8; k_flowa, form 9: workgroups owning
+    several walkers of each half, rows / proposals / decision words filed under the move number mod four slots),
+    restated on the host with the kernel's index arithmetic and constants and run in random and adversarial order,
+    every store landing at a random later time: with the lag guard no slot is reused under a reader and every run
+    completes, whatever the number of walkers per workgroup; without it a stalled workgroup gets one overwritten."""
+    import random
+    import _flow_model as FM
+    import _flowa_model as FA
+    import _flowm_model as F7
+    LC, lib = _hosttables_lib()
+    ix = FM.Index(lib)
+    slots, lag, ring, _, _ = F7.consts(lib)
+    # a row version written in half-step j is read (form 9) by the constructors of j + 3 and rewritten in j + 2 slots
+    assert lag <= 2 * slots - 3 and ring >= 2 * lag
+    for ahead in (True, False):
+        for seed in range(8):
+            rng = random.Random(seed)
+            n2, W = rng.choice(((2, 1), (3, 2), (5, 2), (7, 3), (9, 8)))
+            lead, events, finished = FA.run(ix, lib, n2, W, nsteps=10, rng=rng, ahead=ahead)
+            assert finished and lead <= lag + 2, (ahead, seed, lead)
+        # adversary: nobody draws workgroup 0's walkers as partners, and its constructor sleeps through half-step 4:
+        # the others run ahead until the guard stops them, the sleeper wakes up to intact slots
+        n2 = 4
+        avoid0 = lambda r, j: 1 + (r + j) % (n2 - 1)
+        lead, events, finished = FA.run(ix, lib, n2, 1, 10, random.Random(1), ahead=ahead, partner=avoid0, stall=(0, 4, 20000))
+        assert finished and lead <= lag + 2
+        with pytest.raises(FM.Violation):
+            FA.run(ix, lib, n2, 1, 10, random.Random(1), ahead=ahead, guard=False, partner=avoid0, stall=(0, 4, 20000))
 
 
 def test_every_option_is_documented_in_the_header():

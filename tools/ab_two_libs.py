@@ -59,7 +59,7 @@ def measure(s):
     step = ev_time(ctx, lambda: s["smp"].advance_async(500)) * 1e3 / 500
     c5.lnlike_repeat_device(s["d5"], s["n5"], s["l5"], s["s5"], 6); c5.sync()
     k5 = ev_time(c5, lambda: c5.lnlike_repeat_device(s["d5"], s["n5"], s["l5"], s["s5"], 6)) * 1e3 / 6
-    # the same chain with only the proposals ahead (form 5: what 258-510 walkers take)
+    # the same chain in the resident form with the constructor ahead (form 9: what ensembles beyond 256 walkers take)
     ctx.set_option("merged_flow_sampler", 0)
     s["smp"].advance_async(50); ctx.sync()
     step5 = ev_time(ctx, lambda: s["smp"].advance_async(500)) * 1e3 / 500
@@ -79,13 +79,13 @@ def main():
     for k, lib in (("A", a), ("B", b)):
         v = np.array(res[k])
         out[k] = {"lib": lib, "kernel_125_us": float(np.median(v[:, 0])), "sampler_step_us": float(np.median(v[:, 1])),
-                  "cfg5_launch_us": float(np.median(v[:, 2])), "sampler_step_form5_us": float(np.median(v[:, 3])),
+                  "cfg5_launch_us": float(np.median(v[:, 2])), "sampler_step_form9_us": float(np.median(v[:, 3])),
                   "min": [float(x) for x in v.min(axis=0)]}
-        print("%s %-40s 125-walker launch %.3f us   sampler step %.3f us (form 5: %.3f)   cfg5 launch %.1f us" %
-              (k, os.path.basename(lib), out[k]["kernel_125_us"], out[k]["sampler_step_us"], out[k]["sampler_step_form5_us"],
+        print("%s %-40s 125-walker launch %.3f us   sampler step %.3f us (form 9: %.3f)   cfg5 launch %.1f us" %
+              (k, os.path.basename(lib), out[k]["kernel_125_us"], out[k]["sampler_step_us"], out[k]["sampler_step_form9_us"],
                out[k]["cfg5_launch_us"]))
-    print("B/A: %.4f  %.4f (form 5: %.4f)  %.4f" % tuple(out["B"][x] / out["A"][x] for x in
-                                                      ("kernel_125_us", "sampler_step_us", "sampler_step_form5_us", "cfg5_launch_us")))
+    print("B/A: %.4f  %.4f (form 9: %.4f)  %.4f" % tuple(out["B"][x] / out["A"][x] for x in
+                                                      ("kernel_125_us", "sampler_step_us", "sampler_step_form9_us", "cfg5_launch_us")))
     print(json.dumps(out))
 
 

@@ -22,7 +22,7 @@ def make(opts):
 
 
 FORMS = {"plain": {"lookahead_sampler": 0, "flow_sampler": 0},
-         "form5": {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0},
+         "form9": {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1},
          "form7": {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "flow_spin_log2": SPIN}}
 res = {}
 for name, opts in FORMS.items():
@@ -35,7 +35,7 @@ for name, opts in FORMS.items():
     print(name, "form", like.context.info("last_kernel_form"), "fallbacks", like.context.info("flow_fallbacks"),
           "threads", like.context.info("last_threads"), "grid", like.context.info("last_grid"),
           "%.2f s" % (time.time() - t0), flush=True)
-for name in ("form5", "form7"):
+for name in ("form9", "form7"):
     same = all(np.array_equal(x, y) for x, y in zip(res["plain"], res[name]))
     print(name, "bitwise equal to the plain train:", same, flush=True)
     if not same:
@@ -48,7 +48,7 @@ for name in ("form5", "form7"):
         print("  first differing (walker, step):", bad[np.argsort(bad[:, 1])][:8].tolist())
 if not all(np.array_equal(x, y) for x, y in zip(res["plain"], res["form7"])):
     sys.exit(1)
-for name in ("form5", "form7", "form5", "form7"):
+for name in ("form9", "form7", "form9", "form7"):
     like = make(FORMS[name])
     ctx = like._sync_device()
     smp = mbb.DeviceEnsembleSampler(NW, 5, like, seed=11)

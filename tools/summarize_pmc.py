@@ -23,10 +23,10 @@ def main(fetch_dir, write_dir, out, half_steps="0"):
                    "Infinity-Cache hits are counted.",
            "kernels": {}}
     for k in f:
-        if "lnlike" in k or "k_flowm" in k:
+        if "lnlike" in k or "k_flow" in k:
             res["kernels"][k] = {"FETCH_SIZE": f[k], "WRITE_SIZE": w.get(k),
                                  "traffic_bytes_per_launch": 1024.0 * (f[k]["median_KB"] + (w[k]["median_KB"] if k in w else 0.0))}
-            if (", 5, " in k or "k_flowm" in k) and int(half_steps) > 0:
+            if any(n in k for n in ("k_flowm", "k_flowa", "k_flowr")) and int(half_steps) > 0:
                 # the one-launch sampler kernel: its launches cover different numbers of half-steps
                 res["kernels"][k]["half_steps_in_all_launches"] = int(half_steps)
                 res["kernels"][k]["traffic_bytes_per_half_step"] = \

@@ -18,7 +18,7 @@ def main(run_dir, bench_json, out):
     line = json.load(open(bench_json))
     steps, warm = line["steps"], line["warmup"]
     trace = glob.glob(run_dir + "/*/*_kernel_trace.csv")[0]
-    rows = [r for r in csv.DictReader(open(trace)) if "k_flowm<" in r["Kernel_Name"] or ", 5, " in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(trace)) if any(n in r["Kernel_Name"] for n in ("k_flowm<", "k_flowa<", "k_flowr<"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     covered = [60, warm, steps]                       # bench.py: rehearsal, warm-up, timed region (steps)
     launches = []

@@ -4,9 +4,9 @@
     python tools/sweep_walkers.py [sizes ...]
 
 For every ensemble size: the form the host chooses (mbb_hip.hip, sampler_enqueue), and -- where they are
-eligible -- each of the forms (7, 5, 8, 9, the launch train) forced through the options: us per MCMC step by HIP events on the stream,
-evals/s = walkers / that.  The cut-overs between the forms (form 7 up to 2 walkers per CU, form 5 while
-movers + working-ahead workgroups fit, the launch train beyond) are then read off the curve.
+eligible -- each of the forms (7, 8, 9, the launch train) forced through the options: us per MCMC step by HIP events on the stream,
+evals/s = walkers / that.  The cut-overs between the forms (form 7 up to 2 walkers per CU, form 9 up to four
+walkers per CU and half, form 8 up to eight, the launch train beyond) are then read off the curve.
 250 000 walkers = cfg5's count run as ONE ensemble of that size (the multi-source launch is bench.py's cfg5).
 """
 import json
@@ -22,7 +22,6 @@ from bench import make_likelihood, TRUTH
 SIZES = [18, 64, 128, 250, 256, 258, 300, 340, 384, 450, 512, 514, 768, 1000, 1500, 2000, 3000, 4096, 16384]
 FORMS = (("chosen", {}),
          ("form7", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1, "resident_sampler": 0}),
-         ("form5", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 0, "resident_sampler": 0}),
          ("form8", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0}),
          ("form9", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
          ("train", {"lookahead_sampler": 0}))
