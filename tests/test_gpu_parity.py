@@ -1454,7 +1454,7 @@ def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, 
     out = []
     for resident in (0, 1):
         ctx.set_option("lookahead_sampler", resident); ctx.set_option("resident_sampler", 2 if W else 1); ctx.set_option("resident_walkers", W)
-        ctx.set_option("resident_ahead", ahead)
+        ctx.set_option("resident_ahead", 2 if ahead else 0)      # (2: ahead whatever the number of walkers per workgroup)
         s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=nw + 1)
         a = s.run_mcmc(p0, 9)
         if resident:
