@@ -1253,6 +1253,11 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     bnd["note"] = ("SURVEY.md 8d M1: host float64[n,5] in -> host float64[n] out through likelihood.__call__ "
                    "(what emcee calls per half-step, mbb_fit.py:80-81), PCIe inclusive, never `value`")
     out["boundary"] = bnd
+    # M1 where a reader of the line looks first: what an external sampler such as emcee gets per half-step of the
+    # bench's ensemble (125 rows), next to `value`, which is the device-resident sampler's rate (M2)
+    out["boundary_M1"] = {"rows": half, "p50_us": bnd["rows_%d" % half]["median_us"], "p90_us": bnd["rows_%d" % half]["p90_us"],
+                          "evals_per_s": bnd["rows_%d" % half]["evals_per_s"],
+                          "what": "synchronous likelihood.__call__(float64[125, 5]) -> float64[125], host arrays in and out"}
 
     # ---- pipelined upper bound: independent launches on pre-computed proposals
     NSETS = 8
@@ -1309,6 +1314,30 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     ctx.set_option("resident_sampler", 1); ctx.set_option("resident_ahead", 1)
     forms["note"] = "the other forms of the device sampler, same chain bit for bit (stream time, HIP events)"
     out["other_sampler_forms"] = forms
+
+    # ---- larger ensembles on this one GPU (BASELINE.json configs[2] is 2000 walkers over 8 GPUs; here the whole of it
+    # on one): the resident forms, us per MCMC step and evals/s, with the launch train beside them
+    big = {}
+    for nwb in (512, 1000, 2000, 4096):
+        pb = allw[:nwb] if allw.shape[0] >= nwb else np.tile(allw, (nwb // allw.shape[0] + 1, 1))[:nwb] * (1.0 + 1e-3 * np.arange(nwb)[:, None] / nwb)
+        row = {}
+        for name, look in (("one_launch", 1), ("launch_train", 0)):
+            ctx.set_option("lookahead_sampler", look)
+            sb_ = mbb.DeviceEnsembleSampler(nwb, 5, like, seed=11)
+            sb_.run_mcmc(pb, 20, storechain=False)
+            sb_.advance_async(50); ctx.sync()
+            g0, g1 = ctx.event(), ctx.event()
+            ctx.record(g0); sb_.advance_async(300); ctx.record(g1); ctx.sync()
+            us = ctx.elapsed_ms(g0, g1) * 1e3 / 300
+            row[name] = {"us_per_step": us, "evals_per_s": nwb / (us * 1e-6), "kernel_form": ctx.info("last_kernel_form"),
+                         "workgroups": ctx.info("last_grid"), "walkers_per_workgroup_and_half": ctx.info("last_wpb")}
+            assert np.all(np.isfinite(sb_.run_mcmc(None, 0, storechain=False)[1]))
+            del sb_
+        big["walkers_%d" % nwb] = row
+    ctx.set_option("lookahead_sampler", 1)
+    big["note"] = ("one ensemble of that many walkers on this GPU, 300 steps by HIP events; kernel_form 9 = resident with the "
+                   "constructor a half-step ahead (k_flowa), 8 = resident, nothing ahead (k_flowr), 1 = one launch per half-step")
+    out["large_ensembles"] = big
 
     # ---- the empirical roof of the sample arithmetic, measured now
     sec, slots, roof_mhz = ctx.roof_probe(TRUTH, reps=40)
