@@ -145,15 +145,27 @@ def test_special_spec_errors():
         wheel.add_special("ALMA_alma_200")          # between bands 4 and 6
     with pytest.raises(ValueError):
         response("x").setup("box_100")
-    r = response("d")
-    r.setup("delta_300", xtype="freq", xunits="ghz")  # works here
-    np.testing.assert_allclose(r.effective_wavelength, 299792.458 / 300)
     # dsb given in wavelength units is converted consistently
     a, b = response("a"), response("b")
     a.setup("dsb_230_16_8", xtype="freq", xunits="ghz", normtype="flat", xnorm=230.0)
     lam = 299792.458 / 230.0
     assert a._nresp == 29 and np.all(a.response[13:16] == 0)
     np.testing.assert_allclose(a.effective_frequency, 230.0, rtol=1e-3)
+
+
+def test_delta_passband_in_frequency_units_is_defined_here_not_parity_checked():
+    """a delta-function passband given in FREQUENCY units (`X_delta_300`, the `add_special` default) raises
+    AttributeError in the reference -- `_setup_delta` sets `_normwave` only in its THz branch (response.py:352-364) --
+    so there is nothing to pin this to.  Here it is defined as lambda = c / nu and behaves like any delta band."""
+    from mbb_emcee_amd import response, response_set
+    r = response("d")
+    r.setup("delta_300", xtype="freq", xunits="ghz")
+    np.testing.assert_allclose(r.effective_wavelength, 299792.458 / 300)
+    wheel = response_set()
+    wheel.add_special("X_delta_300")
+    assert wheel["X_delta_300"].isdelta
+    np.testing.assert_allclose(wheel["X_delta_300"].effective_wavelength, 299792.458 / 300)
+    np.testing.assert_allclose(wheel["X_delta_300"](lambda w: np.asarray(w) * 2.0), 2.0 * 299792.458 / 300)
 
 
 # ---------------------------------------------------------------- likelihood host logic
