@@ -206,9 +206,7 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * 2 -- the default -- watches the result slots in pinned memory, which are final
  * before the kernel's completion signal is; "spin_budget" = polls before it falls back
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
- * parameter rows into device memory through the PCIe BAR), "sync_spin_us" (default 200: wherever the library waits for its stream it
- * first polls the stream's status for up to that many microseconds, then blocks -- a blocking wait wakes up 10-15 us after
- * the work has ended, as long as a short sampler run takes; 0: block at once), "launch_api" (how the likelihood launch of given rows
+ * parameter rows into device memory through the PCIe BAR), "launch_api" (how the likelihood launch of given rows
  * is handed to the runtime: 1, the default, hipModuleLaunchKernel with the argument block as one packed buffer;
  * 0 hipLaunchKernel -- 0.2 us more per call: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",

@@ -185,7 +185,6 @@ struct mbb_ctx {
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
     hipFunction_t mod_fn[40] = {};   // launch_api 1: the kernels' module handles, by variant
-    long opt_sync_spin_us = 200;   // wait_stream: microseconds of polling the stream's status before blocking on it
     long opt_launch_api = 1;     // 1 hipModuleLaunchKernel with a packed argument buffer (-0.2 us per call, profiles/r04/boundary_breakdown.txt); 0 hipLaunchKernel
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
     size_t gather_cap = 0;
@@ -494,23 +493,6 @@ static const int32_t kStatusSentinel = 0x7fffff01;
 
 static int wait_stream(mbb_ctx *c)
 {
-    // Option "sync_spin_us": poll the stream's status for up to that long before blocking on it.  A blocking wait
-    // sleeps until the completion interrupt has been delivered and the thread scheduled again -- 10-15 us after the
-    // kernel has ended; for what a short sampler run or a boundary call takes that is as long as the work
-    // (tools/probe_timed_region.py, profiles/r04/timed_region.txt).  Runs that last longer than the budget block as
-    // before, so a long run does not burn a host core.
-    if (c->opt_sync_spin_us > 0 && c->opt_spin != 1) {
-        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
-        const long budget_ns = c->opt_sync_spin_us * 1000L;
-        for (;;) {
-            hipError_t e = hipStreamQuery(c->stream);
-            if (e == hipSuccess) return MBB_OK;
-            if (e != hipErrorNotReady) return fail(MBB_ERR_HIP, "hipStreamQuery", e);
-            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > budget_ns) break;
-            __builtin_ia32_pause();
-        }
-    }
     if (c->opt_spin == 1) {
         for (;;) {
             hipError_t e = hipStreamQuery(c->stream);
@@ -1486,7 +1468,7 @@ extern "C" int mbb_sampler_run(mbb_ctx *c, void *sp, int nsteps, double stretch_
         ch.resize((size_t)nsteps * R * 6);
         HIPCHK(hipMemcpyAsync(ch.data(), s->d_chain6, ch.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     }
-    if ((rc = wait_stream(c))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (err) {
         HIPCHK(hipMemset(s->d_err, 0, sizeof(int)));
         if (err == 8) return fail(MBB_ERR_RCCL, "the exchange timed out: a peer did not post its launch");
@@ -1578,7 +1560,7 @@ extern "C" int mbb_sampler_advance_timed(mbb_ctx *c, void *sp, int nsteps, doubl
     HIPCHK(hipEventRecord(c->ev_timed[0], c->stream));
     if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, false, false))) return rc;
     HIPCHK(hipEventRecord(c->ev_timed[1], c->stream));
-    if ((rc = wait_stream(c))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
     const auto t1 = std::chrono::steady_clock::now();
     *wall_s = std::chrono::duration<double>(t1 - t0).count();
     HIPCHK(hipEventElapsedTime(stream_ms, c->ev_timed[0], c->ev_timed[1]));
@@ -1826,7 +1808,8 @@ extern "C" int mbb_sync(mbb_ctx *c)
 {
     int rc = use(c);
     if (rc) return rc;
-    return wait_stream(c);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
 }
 extern "C" void *mbb_stream(mbb_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -1894,7 +1877,6 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
-    else if (!strcmp(name, "sync_spin_us")) c->opt_sync_spin_us = value < 0 ? 0 : value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
