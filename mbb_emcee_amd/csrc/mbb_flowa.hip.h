@@ -170,14 +170,18 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             lds_wait(c_ready + bj, nC * MBB_FA_TURN(it));
             // the (unit, walker) pairs of this half-step from a counter in LDS, largest units first, a unit's
             // walkers one after the other: a wave takes the next pair when it is through with its last
-            for (;;) {
-                int q = 0;
-                if (lane == 0) q = __hip_atomic_fetch_add(c_next + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                q = __builtin_amdgcn_readfirstlane(q);
-                if (q >= nunit) break;
+            // (written as `for (q = grab(); q < nunit; q = grab())`: as `for (;;) { q = ...; if (q >= nunit) break; ... continue; ... }`
+            // the same loop came out of the compiler with a path from `continue` back to the test that skipped the
+            // atomic, and hung)
+            auto grab = [&]() {
+                int v = 0;
+                if (lane == 0) v = __hip_atomic_fetch_add(c_next + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return __builtin_amdgcn_readfirstlane(v);
+            };
+            for (int q = grab(); q < nunit; q = grab()) {
                 const int r = q / Wl, j = q - r * Wl;
                 const int4 us = a.unit_tab[nun <= kFaOrder ? s_order[r] : r];
-                if (wk[j].status != ROW_OK) continue;             // wave-uniform
+                if (wk[j].status != ROW_OK) continue;             // wave-uniform (the increment takes the next pair)
                 const WalkerK k = wk[j];
                 const int s = us.x, c0 = us.y, c1 = us.z;
                 double acc = 0.0;
