@@ -37,14 +37,13 @@
 
 constexpr int kFaMaxW = 8;      // walkers per workgroup and half
 constexpr int kFaNB = 2;        // hand-over record buffers in LDS: half-step j uses buffer j mod kFaNB
-constexpr int kFaOrder = 256;   // units per walker up to which the quadrature waves take them largest first (beyond: table order)
 constexpr int kFaRec = 10;      // doubles per proposal record besides WalkerK: proposal 0..4, (dim-1) ln z, ln u, the two penalties
 
 // dynamic LDS of a k_flowa launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t flowa_lds(size_t nb, size_t npart, bool cov_in_lds, size_t W)
 {
     return kFaNB * W * (sizeof(WalkerK) + 8 * npart + 8 * kFaRec) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64 + 4 * kFaOrder;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
 }
 
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
@@ -70,9 +69,8 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     double *s_ivar = s_flux + nb; \
     double *s_invcov = s_ivar + nb; \
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
-    int *ctl = reinterpret_cast<int *>(s_band + nb + 1);                         /* ready[2], qdone[2], edone[2], next[2] */ \
-    int *s_order = ctl + 16;                                                     /* [kFaOrder] the units, largest first */ \
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(s_order + kFaOrder) - smem_raw) + 15) & ~(size_t)15; \
+    int *ctl = reinterpret_cast<int *>(s_band + nb + 1);                         /* ready[2], qdone[2], edone[2] */ \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15; \
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
@@ -83,8 +81,8 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \
     const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22); \
     const int niter = a.persist; \
-    int *const c_ready = ctl, *const c_qdone = ctl + 2, *const c_edone = ctl + 4, *const c_next = ctl + 6; \
-    (void)c_next; (void)s_order; (void)nun; (void)nQ; (void)mflux; (void)own; (void)s_flux; (void)s_ivar; (void)s_invcov; (void)s_nu; (void)s_lnnu; (void)s_wt; \
+    int *const c_ready = ctl, *const c_qdone = ctl + 2, *const c_edone = ctl + 4; \
+    (void)nun; (void)nQ; (void)mflux; (void)own; (void)s_flux; (void)s_ivar; (void)s_invcov; (void)s_nu; (void)s_lnnu; (void)s_wt; \
     (void)Wl; (void)done_set; (void)spin_limit; (void)niter; (void)c_ready; (void)c_qdone; (void)c_edone; (void)partial0; (void)rec0
 
     // ---- set-up, once per launch (every thread): tables and data to LDS; the owned rows as the sampler holds them
@@ -103,19 +101,6 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                 own[(size_t)(hh * W + l) * 8 + e] = v;
                 fm_put(fv.row + (size_t)r * kFmWords + 2 * e, v, serial32);
             }
-        }
-        // the order the quadrature waves take a walker's units in: by chunk count, largest first (which wave sums a
-        // unit does not change the sum; with several walkers per workgroup the waves then finish together)
-        if (tid < nun && nun <= kFaOrder) {
-            const int4 me = a.unit_tab[tid];
-            const int mine = me.z - me.y;
-            int rank = 0;
-            for (int o = 0; o < nun; ++o) {
-                const int4 ot = a.unit_tab[o];
-                const int sz = ot.z - ot.y;
-                rank += (sz > mine || (sz == mine && o < tid)) ? 1 : 0;
-            }
-            s_order[rank] = tid;
         }
         if (blockIdx.x == 0 && tid < kFmRing * 16)
             __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -162,26 +147,21 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
         auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
         const SampleTabs tabs = {s_tab, s_pb, s_pc};
         const int nunit = Wl * nun;                       // (the last workgroup may own fewer walkers)
+        int4 us_first = make_int4(0, 0, 0, 0);
+        if (qi < nunit) us_first = a.unit_tab[qi % nun];
         for (int it = 0; it < niter; ++it) {
             const int bj = it & (kFaNB - 1), h = it & 1;
             const WalkerK *wk = wk0 + bj * W;
             double *partial = partial0 + (size_t)bj * W * npart;
             const double *rec = rec0 + (size_t)bj * W * kFaRec;
             lds_wait(c_ready + bj, nC * MBB_FA_TURN(it));
-            // the (unit, walker) pairs of this half-step from a counter in LDS, largest units first, a unit's
-            // walkers one after the other: a wave takes the next pair when it is through with its last
-            // (written as `for (q = grab(); q < nunit; q = grab())`: as `for (;;) { q = ...; if (q >= nunit) break; ... continue; ... }`
-            // the same loop came out of the compiler with a path from `continue` back to the test that skipped the
-            // atomic, and hung)
-            auto grab = [&]() {
-                int v = 0;
-                if (lane == 0) v = __hip_atomic_fetch_add(c_next + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return __builtin_amdgcn_readfirstlane(v);
-            };
-            for (int q = grab(); q < nunit; q = grab()) {
-                const int r = q / Wl, j = q - r * Wl;
-                const int4 us = a.unit_tab[nun <= kFaOrder ? s_order[r] : r];
-                if (wk[j].status != ROW_OK) continue;             // wave-uniform (the increment takes the next pair)
+            // (round 4 also tried taking the (unit, walker) pairs from a counter in LDS, largest units first: 9.6 against
+            // 8.6 us per step at 512 walkers, 21.6 against 21.0 at 2000 -- the counter's round trips cost more than the
+            // table's own dealing order leaves unbalanced)
+            for (int u = qi; u < nunit; u += nQ) {
+                const int j = u / nun;
+                const int4 us = (u == qi) ? us_first : a.unit_tab[u - j * nun];
+                if (wk[j].status != ROW_OK) continue;             // wave-uniform
                 const WalkerK k = wk[j];
                 const int s = us.x, c0 = us.y, c1 = us.z;
                 double acc = 0.0;
@@ -404,9 +384,6 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             }
             MBB_FM_ORDER();
             if (lane == 0) {
-                // (the unit counter of this buffer starts again: every Q wave is through with half-step j - 2 -- they
-                // count themselves after their last look at it, and this wave has waited for the walkers they decide)
-                if (ci == 0) __hip_atomic_store(c_next + bj, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(c_ready + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 // this wave has read what it needs of half-step j - 1's rows, proposals and decisions: the lag guard
                 __hip_atomic_fetch_add(done_set + (j & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
