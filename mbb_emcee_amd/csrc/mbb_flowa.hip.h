@@ -37,14 +37,13 @@
 
 constexpr int kFaMaxW = 8;      // walkers per workgroup and half
 constexpr int kFaNB = 2;        // hand-over record buffers in LDS: half-step j uses buffer j mod kFaNB
-constexpr int kFaOrder = 256;   // units per walker up to which they are dealt to the quadrature waves by size (beyond: table order)
 constexpr int kFaRec = 10;      // doubles per proposal record besides WalkerK: proposal 0..4, (dim-1) ln z, ln u, the two penalties
 
 // dynamic LDS of a k_flowa launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t flowa_lds(size_t nb, size_t npart, bool cov_in_lds, size_t W)
 {
     return kFaNB * W * (sizeof(WalkerK) + 8 * npart + 8 * kFaRec) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64 + 4 * kFaOrder;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
 }
 
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
@@ -71,8 +70,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     double *s_invcov = s_ivar + nb; \
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
     int *ctl = reinterpret_cast<int *>(s_band + nb + 1);                         /* ready[2], qdone[2], edone[2] */ \
-    int *s_order = ctl + 16;                                                     /* [kFaOrder] a walker's units, largest first */ \
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(s_order + kFaOrder) - smem_raw) + 15) & ~(size_t)15; \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15; \
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
@@ -84,7 +82,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22); \
     const int niter = a.persist; \
     int *const c_ready = ctl, *const c_qdone = ctl + 2, *const c_edone = ctl + 4; \
-    (void)s_order; (void)nun; (void)nQ; (void)mflux; (void)own; (void)s_flux; (void)s_ivar; (void)s_invcov; (void)s_nu; (void)s_lnnu; (void)s_wt; \
+    (void)nun; (void)nQ; (void)mflux; (void)own; (void)s_flux; (void)s_ivar; (void)s_invcov; (void)s_nu; (void)s_lnnu; (void)s_wt; \
     (void)Wl; (void)done_set; (void)spin_limit; (void)niter; (void)c_ready; (void)c_qdone; (void)c_edone; (void)partial0; (void)rec0
 
     // ---- set-up, once per launch (every thread): tables and data to LDS; the owned rows as the sampler holds them
@@ -106,18 +104,6 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
         }
         if (blockIdx.x == 0 && tid < kFmRing * 16)
             __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // a walker's units by chunk count, largest first: the order the (unit, walker) pairs are dealt in (below)
-        if (tid < nun && nun <= kFaOrder) {
-            const int4 me = a.unit_tab[tid];
-            const int mine = me.z - me.y;
-            int rank = 0;
-            for (int o = 0; o < nun; ++o) {
-                const int4 ot = a.unit_tab[o];
-                const int sz = ot.z - ot.y;
-                rank += (sz > mine || (sz == mine && o < tid)) ? 1 : 0;
-            }
-            s_order[rank] = tid;
-        }
         const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
         const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
         double2 *lb = reinterpret_cast<double2 *>(s_pb);
@@ -161,25 +147,22 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
         auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
         const SampleTabs tabs = {s_tab, s_pb, s_pc};
         const int nunit = Wl * nun;                       // (the last workgroup may own fewer walkers)
+        int4 us_first = make_int4(0, 0, 0, 0);
+        if (qi < nunit) us_first = a.unit_tab[qi % nun];
         for (int it = 0; it < niter; ++it) {
             const int bj = it & (kFaNB - 1), h = it & 1;
             const WalkerK *wk = wk0 + bj * W;
             double *partial = partial0 + (size_t)bj * W * npart;
             const double *rec = rec0 + (size_t)bj * W * kFaRec;
             lds_wait(c_ready + bj, nC * MBB_FA_TURN(it));
-            // The (unit, walker) pairs of the workgroup's walkers, largest units first (a unit's walkers one after the
-            // other), dealt to the Q waves there and back again: pass k gives pair k nQ + q to wave q when k is even, to
-            // wave nQ - 1 - q when it is odd.  With several walkers per workgroup the waves then carry nearly equal
-            // numbers of chunks -- cfg2, four walkers: at most 12 of 144 on 14 waves, 16 when the pairs go round in table
-            // order (which wave sums a unit does not change the sum).  (Taking the pairs from a counter in LDS instead was
-            // slower than either: the counter's round trips.)
-            const int npass = (nunit + nQ - 1) / nQ;
-            for (int kp = 0; kp < npass; ++kp) {
-                const int u = kp * nQ + ((kp & 1) ? nQ - 1 - qi : qi);
-                if (u >= nunit) continue;
-                const bool sorted = nun <= kFaOrder;
-                const int r = sorted ? u / Wl : u % nun, j = sorted ? u - r * Wl : u / nun;
-                const int4 us = a.unit_tab[sorted ? s_order[r] : r];
+            // (Round 4 tried two other deals of the (unit, walker) pairs, both to even out the chunks a WAVE carries --
+            // in table order, four walkers: 16 of 144 chunks at most on 14 waves, where 11 are possible.  From a counter in
+            // LDS, largest units first: 9.6 against 8.6 us per step at 512 walkers, 21.6 against 21.0 at 2000.  By size, there
+            // and back again over the waves (at most 12 chunks per wave): 8.95 / 26.1.  Both slower: the table's order
+            // balances the SIMDs, which is what the time follows, and keeps the waves of a pass on one walker.)
+            for (int u = qi; u < nunit; u += nQ) {
+                const int j = u / nun;
+                const int4 us = (u == qi) ? us_first : a.unit_tab[u - j * nun];
                 if (wk[j].status != ROW_OK) continue;             // wave-uniform
                 const WalkerK k = wk[j];
                 const int s = us.x, c0 = us.y, c1 = us.z;

@@ -29,14 +29,13 @@
 #pragma once
 #include "mbb_kernels.hip.h"
 
-constexpr int kFrOrder = 256;  // units per walker up to which they are dealt to the waves by size (beyond: table order)
 constexpr int kFrMaxW = 8;     // walkers per workgroup and half (two prologue waves of four rows of 16 lanes)
 
 // dynamic LDS of a k_flowr launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t flowr_lds(size_t nb, size_t npart, bool cov_in_lds, size_t W)
 {
     return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 8 + 8 * 2) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 4 * kFrOrder;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
 
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
@@ -62,8 +61,7 @@ __global__ void __launch_bounds__(1024) k_flowr(const LikeArgs a)
     double *s_ivar = s_flux + nb;                                         // [nb]
     double *s_invcov = s_ivar + nb;                                       // [nb * nb] when it fits
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));   // [nb]
-    int *s_order = reinterpret_cast<int *>(s_band + nb + 1);                  // [kFrOrder] a walker's units, largest first
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(s_order + kFrOrder) - smem_raw) + 15) & ~(size_t)15;
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(s_band + nb + 1) - smem_raw) + 15) & ~(size_t)15;
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
@@ -95,18 +93,6 @@ __global__ void __launch_bounds__(1024) k_flowr(const LikeArgs a)
         }
         if (blockIdx.x == 0 && tid < kFmRing * 16)
             __hip_atomic_store(fv.done + (size_t)((a.spec_cfg & 1) ^ 1) * kFmRing * 16 + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // a walker's units by chunk count, largest first: the order the (unit, walker) pairs are dealt in (phase 2)
-        if (tid < nun && nun <= kFrOrder) {
-            const int4 me = a.unit_tab[tid];
-            const int mine = me.z - me.y;
-            int rank = 0;
-            for (int o = 0; o < nun; ++o) {
-                const int4 ot = a.unit_tab[o];
-                const int sz = ot.z - ot.y;
-                rank += (sz > mine || (sz == mine && o < tid)) ? 1 : 0;
-            }
-            s_order[rank] = tid;
-        }
         for (int i = tid; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
         for (int i = tid; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
         if (!OPTHIN)
@@ -129,9 +115,10 @@ __global__ void __launch_bounds__(1024) k_flowr(const LikeArgs a)
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     const SampleTabs tabs = {s_tab, s_pb, s_pc};
-    const int nunit = Wl * nun;                                           // (unit, walker) pairs per half-step
-    const int npass = (nunit + nwave - 1) / nwave;
-    const bool sorted = nun <= kFrOrder;
+    // this wave's first quadrature unit (the same in every half-step)
+    const int nunit = W * nun;
+    int4 us_first = make_int4(0, 0, 0, 0);
+    if (wave < nunit) us_first = a.unit_tab[wave % nun];
 
     for (int it = 0; it < niter; ++it) {
         const int h = it & 1, buf = it & 1;
@@ -211,16 +198,10 @@ __global__ void __launch_bounds__(1024) k_flowr(const LikeArgs a)
         // this workgroup has read what it needs of the rows of half-step it - 1: counted for the lag guard
         if (tid == 0) __hip_atomic_fetch_add(done_set + (it & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-        // ---- phase 2 (k_lnlike's quadrature): the (unit, walker) pairs, largest units first (a unit's walkers one after
-        // the other), dealt to the waves there and back again -- pass k gives pair k nwave + w to wave w when k is even, to
-        // wave nwave - 1 - w when it is odd -- so that with several walkers per workgroup the waves carry nearly equal
-        // numbers of chunks (cfg2, eight walkers: 19 of 288 at most on 16 waves, 26 in table order); which wave sums a
-        // unit does not change the sum
-        for (int kp = 0; kp < npass; ++kp) {
-            const int u = kp * nwave + ((kp & 1) ? nwave - 1 - wave : wave);
-            if (u >= nunit) continue;
-            const int r = sorted ? u / Wl : u % nun, j = sorted ? u - r * Wl : u / nun;
-            const int4 us = a.unit_tab[sorted ? s_order[r] : r];
+        // ---- phase 2 (k_lnlike's): the (walker, unit) pairs dealt to the waves ---------------------
+        for (int u = wave; u < nunit; u += nwave) {
+            const int j = u / nun;
+            const int4 us = (u == wave) ? us_first : a.unit_tab[u - j * nun];
             if (wk[j].status != ROW_OK) continue;                 // wave-uniform
             const WalkerK k = wk[j];
             const int s = us.x, c0 = us.y, c1 = us.z;

@@ -74,13 +74,13 @@ MBB_FLOWA_EXT(true, true)
 static size_t flowa_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowa_lds() of mbb_flowa.hip.h
 {
     return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 10) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64 + 4 * 256;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
 }
 constexpr int kFrMaxWHost = 8;
 static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h
 {
     return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 8 + 8 * 2) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 4 * 256;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
 constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)   // = flowm_lds() of mbb_flowm.hip.h
