@@ -117,9 +117,10 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     const unsigned long long serial32 = a.flow_serial << 32; \
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \
     const int niter = a.persist;
-// One workgroup serves NP pairs of walkers (NP = 1 up to two walkers per CU; NP = 2 for the ensembles
-// beyond, up to four per CU): the roles take the pairs one after another in every half-step, each pair with
-// hand-over records and control words of its own.  Inside `for (vp ...)` these names are that pair's.
+// One workgroup serves NP pairs of walkers.  Only NP = 1 is instantiated since round 4 (up to two walkers per CU);
+// round 3's NP = 2 for ensembles of up to four per CU -- the roles taking the pairs one after another in every
+// half-step, each pair with hand-over records and control words of its own: 11.5 us per step -- was superseded by
+// k_flowa (8.2-8.6).  The loops over `vp` below are the shape that form had; with NP = 1 they are one pass.
 #define MBB_FM_PAIRS_LOOP _Pragma("clang loop unroll(disable)")      /* (one body for both pairs, not two copies) */
 #define MBB_FM_PAIR(vp) \
     const int w = wbase + (vp); \
@@ -165,6 +166,7 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
 template <bool OPTHIN, bool NOALPHA, bool STAGE, int NP>
 __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
 {
+    static_assert(NP == 1, "one pair of walkers per workgroup (the two-pair shape is not built or tested any more)");
     CLikeArgs *const ka = MBB_KERNARGS();
     extern __shared__ __align__(16) unsigned char smem_raw[];
     __shared__ Exp2Entry s_tab[kExp2N];
