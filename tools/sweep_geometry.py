@@ -16,7 +16,7 @@ WPBS = (1, 2, 3, 4, 6, 8, 16, 24, 32, 48, 64)
 
 
 def main():
-    ns = [int(a) for a in sys.argv[1:]] or [256, 500, 1000, 2048, 4096]
+    ns = [int(a) for a in sys.argv[1:]] or [256, 257, 288, 320, 384, 500, 1000, 2048, 4096]
     like, flux = make_likelihood(0)
     ctx = like._sync_device()
     for n in ns:
