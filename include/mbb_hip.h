@@ -206,7 +206,14 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * 2 -- the default -- watches the result slots in pinned memory, which are final
  * before the kernel's completion signal is; "spin_budget" = polls before it falls back
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
- * parameter rows into device memory through the PCIe BAR), "launch_api" (how the likelihood launch of given rows
+ * parameter rows into device memory through the PCIe BAR), "serve" (default 1: after "serve_after" (3) boundary calls in a row
+ * with nothing else in between -- a sampler's loop -- mbb_lnlike_call hands its rows to a kernel that STAYS on the GPU
+ * between the calls and is rung through the BAR (k_serve: no launch per call; same results bit for bit), while the
+ * context is the only one of the process on its device and a batch is at most a row per CU.  Any other entry point on
+ * the context tells it to leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
+ * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
+ * switch the feature off.  0: a launch per call; 2: also beside other contexts.  mbb_get_info "serving",
+ * "serve_requests", "serve_fallbacks"), "launch_api" (how the likelihood launch of given rows
  * is handed to the runtime: 1, the default, hipModuleLaunchKernel with the argument block as one packed buffer;
  * 0 hipLaunchKernel -- 0.2 us more per call: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",

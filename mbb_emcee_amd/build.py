@@ -32,6 +32,7 @@ DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h")
         os.path.join(HERE, "csrc", "mbb_flowm.hip.h"),
         os.path.join(HERE, "csrc", "mbb_flowr.hip.h"),
         os.path.join(HERE, "csrc", "mbb_flowa.hip.h"),
+        os.path.join(HERE, "csrc", "mbb_serve.hip.h"),
         os.path.join(os.path.dirname(HERE), "include", "mbb_hip.h")]
 LIB = os.path.join(HERE, "libmbb_hip.so")
 ARCH = "gfx950"

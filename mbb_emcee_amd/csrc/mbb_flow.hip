@@ -46,3 +46,13 @@ MBB_FLOWA_INST(false, true)
 MBB_FLOWA_INST(true, false)
 MBB_FLOWA_INST(true, true)
 #undef MBB_FLOWA_INST
+
+#include "mbb_serve.hip.h"
+#define MBB_SERVE_INST(OT, NA)                                     \
+    template __global__ void k_serve<OT, NA, false>(const LikeArgs); \
+    template __global__ void k_serve<OT, NA, true>(const LikeArgs);
+MBB_SERVE_INST(false, false)
+MBB_SERVE_INST(false, true)
+MBB_SERVE_INST(true, false)
+MBB_SERVE_INST(true, true)
+#undef MBB_SERVE_INST

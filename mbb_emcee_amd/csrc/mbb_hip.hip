@@ -76,6 +76,22 @@ static size_t flowa_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W
     return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 10) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
            (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
 }
+// ... and k_serve, the likelihood of given rows as a kernel that stays resident between boundary calls (mbb_serve.hip.h)
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void k_serve(const LikeArgs a);
+#define MBB_SERVE_EXT(OT, NA)                                               \
+    extern template __global__ void k_serve<OT, NA, false>(const LikeArgs); \
+    extern template __global__ void k_serve<OT, NA, true>(const LikeArgs);
+MBB_SERVE_EXT(false, false)
+MBB_SERVE_EXT(false, true)
+MBB_SERVE_EXT(true, false)
+MBB_SERVE_EXT(true, true)
+#undef MBB_SERVE_EXT
+constexpr unsigned long long kServeQuitHost = 0xffffull;
+static size_t serve_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)                  // = serve_lds() of mbb_serve.hip.h
+{
+    return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
+}
 constexpr int kFrMaxWHost = 8;
 static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h
 {
@@ -182,6 +198,18 @@ struct mbb_ctx {
     double *w_pars = nullptr;    // device memory the host writes through the PCIe BAR (fine-grained), or null
     double *dv_pars = nullptr, *dv_lnl = nullptr, *dv_mflux = nullptr;   // the pinned blocks as the device addresses them
     int32_t *dv_status = nullptr;
+    // the served boundary (k_serve, mbb_serve.hip.h): a kernel that stays resident between a host-driven sampler's calls
+    unsigned long long *w_door = nullptr;     // its doorbell: a word of fine-grained device memory the host writes through the BAR
+    unsigned long long *h_gone = nullptr;     // pinned: the number of the last request a server saw before it left (0: still there)
+    bool serving = false;
+    unsigned long long srv_seq = 0;           // requests so far (the doorbell word is request number << 16 | rows)
+    int srv_hot = 0;                          // boundary calls in a row with nothing else in between
+    int srv_strikes = 0;                      // servers that had to be given up in a row; three switch the feature off
+    long srv_requests = 0, srv_fallbacks = 0;
+    long opt_serve = 1;                       // 0: every boundary call is a launch; 2: a server even beside other contexts (tests)
+    long opt_serve_after = 3;                 // boundary calls in a row before a server is started
+    long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (~1 us per poll)
+    long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
     hipFunction_t mod_fn[40] = {};   // launch_api 1: the kernels' module handles, by variant
@@ -229,7 +257,7 @@ struct mbb_ctx {
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[88] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[96] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -257,10 +285,16 @@ struct mbb_ctx {
     } x;
 };
 
+static int serve_stop(mbb_ctx *c);
+
+// Every entry point but the boundary call comes through here: a resident server (k_serve) is told to leave first --
+// it holds the CUs, and its arguments were fixed at its launch -- and the streak of boundary calls ends.
 static int use(mbb_ctx *c)
 {
     if (!c) return fail(MBB_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+    c->srv_hot = 0;
+    if (c->serving) return serve_stop(c);
     return MBB_OK;
 }
 
@@ -278,6 +312,7 @@ struct DeviceStatics {
     int cu_count = 0;
     double *d_poly_b = nullptr, *d_poly_c = nullptr;
     std::vector<hipStream_t> idle_streams;
+    std::atomic<int> live{0};        // contexts of this process on the device (a server is only kept while there is one)
 };
 static std::mutex g_dev_mutex;
 static DeviceStatics g_dev[64];
@@ -327,6 +362,7 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
         hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (es != hipSuccess) { delete c; return fail(MBB_ERR_HIP, "hipStreamCreateWithFlags", es); }
     }
+    ++g_dev[device].live;
     *out = c;
     return MBB_OK;
 }
@@ -339,6 +375,8 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->serving) (void)serve_stop(c);
+    if (c->device >= 0 && c->device < 64) --g_dev[c->device].live;
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->x.base) (void)xchg_free(c);
@@ -349,6 +387,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
     free_dev(c->w_pars);
+    free_dev(c->w_door); free_host(c->h_gone);
     free_dev(c->d_gather); free_host(c->h_gather);
     free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
     free_dev(c->d_sed_wk);
@@ -1021,21 +1060,160 @@ extern "C" int mbb_boundary_buffers(mbb_ctx *c, int nmax, double **in, double **
     return MBB_OK;
 }
 
+// ---- the served boundary ----------------------------------------------------------------------------------------
+// (see mbb_serve.hip.h for what it is and why)
+static int serve_stop(mbb_ctx *c)
+{
+    if (!c->serving) return MBB_OK;
+    c->serving = false;
+    // a request number the server has not seen, with the row count that means "leave"
+    __atomic_store_n(c->w_door, (++c->srv_seq << 16) | kServeQuitHost, __ATOMIC_RELAXED);
+    __builtin_ia32_sfence();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MBB_OK;
+}
+
+// Start a server with the request in the launch itself.  The argument block is launch_lnlike's, filled in here for
+// the fields k_serve reads.
+static int serve_start(mbb_ctx *c, int n, unsigned long long word)
+{
+    if (!c->w_door) {
+        if (hipExtMallocWithFlags((void **)&c->w_door, 64, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            c->w_door = nullptr;
+            return 1;
+        }
+        HIPCHK(hipHostMalloc((void **)&c->h_gone, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    }
+    LikeArgs a;
+    memset(&a, 0, sizeof a);
+    a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
+    a.poly_b = c->d_poly_b; a.poly_c = c->d_poly_c;
+    a.unit_tab = c->d_unit_tab; a.band_rng = c->d_band_rng; a.tail_slot = c->d_tail_slot;
+    a.flux = c->d_flux; a.ivar = c->d_ivar; a.invcov = c->has_cov ? c->d_invcov : nullptr;
+    a.nb = c->nb; a.nunit = c->nunit; a.npart = c->npart; a.nchunk = c->nchunk;
+    a.nunorm = kUmToGHz / c->wavenorm;
+    a.lnunorm = log(a.nunorm);
+    for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
+    for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
+    a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
+    a.pars = c->w_pars; a.n = n; a.lnl = c->dv_lnl; a.status = c->dv_status; a.model_flux = nullptr;
+    a.wpb = 1; a.debug = (int)c->opt_debug; a.nsrc = 1;
+    int wpb, threads;
+    pick_geometry(c, 1, wpb, threads);
+    const size_t dyn_limit = dynamic_lds_limit(c);
+    const size_t table_bytes = (size_t)c->nchunk * 64 * 3 * sizeof(double);
+    a.cov_in_lds = (c->has_cov && serve_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
+    const size_t sm = serve_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
+    const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
+    const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
+    if (sm_total > dyn_limit) return 1;
+    HIPCHK(hipHostGetDevicePointer((void **)&a.chain6, c->h_gone, 0));
+    a.pos6 = reinterpret_cast<double *>(c->w_door);
+    a.seed = word;
+    a.persist = (int)std::min<long>(std::max<long>(c->opt_serve_idle_us, 20), 1000000);
+    static void (*const stable[8])(const LikeArgs) = {
+        k_serve<false, false, false>, k_serve<false, false, true>, k_serve<false, true, false>, k_serve<false, true, true>,
+        k_serve<true, false, false>, k_serve<true, false, true>, k_serve<true, true, false>, k_serve<true, true, true>};
+    const int si = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+    void (*kern)(const LikeArgs) = stable[si];
+    if (static_lds(c) + sm_total > 60 * 1024) {
+        size_t &g = c->lds_granted[88 + si];
+        if (sm_total > g) {
+            size_t want = (sm_total + 16383) & ~(size_t)16383;
+            if (want > dyn_limit) want = dyn_limit;
+            HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want));
+            g = want;
+        }
+    }
+    *c->h_gone = 0;
+    __atomic_store_n(c->w_door, word, __ATOMIC_RELAXED);
+    __builtin_ia32_sfence();
+    hipLaunchKernelGGL(kern, dim3(c->cu_count), dim3(threads), sm_total, c->stream, a);
+    HIPCHK(hipGetLastError());
+    c->last_wpb = 1; c->last_threads = threads; c->last_grid = c->cu_count; c->last_smem = (long)sm_total;
+    c->last_stage = stg ? 1 : 0; c->last_smode = 10;
+    c->serving = true;
+    return MBB_OK;
+}
+
+// One request: MBB_OK when the results are in the pinned slots, 1 when the rows have to go by a launch after all,
+// negative on error.  The parameter rows are in c->w_pars already.
+static int serve_request(mbb_ctx *c, int n)
+{
+    auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
+    const long t_a = now_ns();
+    uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
+    for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
+    const unsigned long long word = (++c->srv_seq << 16) | (unsigned long long)n;
+    __builtin_ia32_sfence();                       // the caller's rows, through the BAR, before the request
+    const long t_b = now_ns();
+    long budget_ns = c->opt_serve_budget_us * 1000L;
+    if (!c->serving) {
+        int rc = serve_start(c, n, word);
+        if (rc) return rc;
+        budget_ns += 200000L;                      // (a launch, and the tables into LDS on every CU)
+    } else {
+        __atomic_store_n(c->w_door, word, __ATOMIC_RELAXED);
+        __builtin_ia32_sfence();
+    }
+    const long t_c = now_ns();
+    ++c->srv_requests;
+    const int32_t *hs = c->h_status;
+    int i = 0;
+    bool seen = false;
+    for (long spins = 0;; ++spins) {
+        while (i < n && __atomic_load_n(&hl[i], __ATOMIC_ACQUIRE) != kLnlSentinel &&
+               __atomic_load_n(&hs[i], __ATOMIC_ACQUIRE) != kStatusSentinel) ++i;
+        if (i == n) { seen = true; break; }
+        if ((spins & 63) == 63 && (now_ns() - t_c > budget_ns || __atomic_load_n(c->h_gone, __ATOMIC_ACQUIRE) != 0)) break;
+        __builtin_ia32_pause();
+    }
+    c->last_watch_seen = seen ? 1 : 0;
+    c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
+    if (seen) { c->srv_strikes = 0; return MBB_OK; }
+    // the slots did not turn: the server had left (or was leaving) when the request came, or it is not resident.
+    // It is told to go, waited for, and the rows go by a launch; three such in a row and the feature rests.
+    ++c->srv_fallbacks;
+    c->srv_hot = 0;
+    if (++c->srv_strikes >= 3) c->opt_serve = 0;
+    int rc = serve_stop(c);
+    return rc ? rc : 1;
+}
+
 // Returns MBB_OK, a negative error, or -- positive -- the status code of the first row that the reference
 // would have raised for (alpha <= 0, beta < 0, no merge point: modified_blackbody.py:219-224, :294-316).
 extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
 {
-    int rc = use(c);
-    if (rc) return rc;
+    if (!c) return fail(MBB_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));               // (not use(): a resident server stays, the streak of calls goes on)
+    int rc;
     if (n <= 0) return n == 0 ? MBB_OK : fail(MBB_ERR_ARG, "bad row count");
     if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
     const bool push = c->opt_zero_copy && c->opt_bar_params && c->w_pars;
     if (!c->opt_zero_copy || !c->call_in || c->call_cap != c->cap || (size_t)n > c->cap ||
-        c->call_in != (push ? c->w_pars : c->h_pars))
+        c->call_in != (push ? c->w_pars : c->h_pars)) {
+        if (c->serving && (rc = serve_stop(c))) return rc;
         return fail(MBB_ERR_STATE, "mbb_boundary_buffers first (or again: the buffers or the host-path options changed)");
-    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-    if (push) __builtin_ia32_sfence();             // the caller's stores through the BAR, drained before the doorbell
-    if ((rc = lnlike_zero_copy(c, n, push, false, ts.tv_sec * 1000000000L + ts.tv_nsec))) return rc;
+    }
+    // After a few boundary calls in a row with nothing else in between -- a sampler's loop -- the rows are handed to
+    // a kernel that stays on the GPU (k_serve) instead of a launch each: while this context is the only one of the
+    // process on the device, the batch is at most a row per CU, and the host path is the default one.
+    const bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 &&
+                           c->data_nb == c->nb && (g_dev[c->device].live.load() == 1 || c->opt_serve == 2);
+    bool done = false;
+    if (can_serve && (c->serving || ++c->srv_hot >= c->opt_serve_after)) {
+        rc = serve_request(c, n);
+        if (rc < 0) return rc;
+        done = rc == MBB_OK;
+    } else if (c->serving && (rc = serve_stop(c))) {
+        return rc;
+    }
+    if (!done) {
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        if (push) __builtin_ia32_sfence();         // the caller's stores through the BAR, drained before the doorbell
+        if ((rc = lnlike_zero_copy(c, n, push, false, ts.tv_sec * 1000000000L + ts.tv_nsec))) return rc;
+    }
     const int32_t *hs = c->h_status;
     for (int i = 0; i < n; ++i)
         if (hs[i] >= 2 && hs[i] != 7) return hs[i];
@@ -1866,6 +2044,12 @@ extern "C" int mbb_stamps(mbb_ctx *c, unsigned long long *host, int nblocks)
 extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
 {
     if (!c || !name) return fail(MBB_ERR_ARG, "null argument");
+    if (c->serving) {                               // (a resident server runs with the options of its launch)
+        HIPCHK(hipSetDevice(c->device));
+        int rc = serve_stop(c);
+        if (rc) return rc;
+    }
+    c->srv_hot = 0;
     if (!strcmp(name, "walkers_per_group")) c->opt_wpb = value;
     else if (!strcmp(name, "block_threads")) c->opt_threads = value;
     else if (!strcmp(name, "zero_copy")) c->opt_zero_copy = value;
@@ -1877,6 +2061,10 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
+    else if (!strcmp(name, "serve")) { c->opt_serve = value; c->srv_strikes = 0; }
+    else if (!strcmp(name, "serve_after")) c->opt_serve_after = value < 1 ? 1 : value;
+    else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
+    else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
@@ -1903,6 +2091,10 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "nseg")) *value = c->nseg;
     else if (!strcmp(name, "nunit")) *value = c->nunit;
     else if (!strcmp(name, "last_prep_ns")) *value = c->t_prep_ns;
+    else if (!strcmp(name, "serving")) *value = c->serving ? 1 : 0;
+    else if (!strcmp(name, "serve_requests")) *value = c->srv_requests;
+    else if (!strcmp(name, "serve_fallbacks")) *value = c->srv_fallbacks;
+    else if (!strcmp(name, "serve_enabled")) *value = c->opt_serve;
     else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;
     else if (!strcmp(name, "last_wait_ns")) *value = c->t_wait_ns;
     else if (!strcmp(name, "last_watch_seen")) *value = c->last_watch_seen;

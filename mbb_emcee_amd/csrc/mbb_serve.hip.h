@@ -1,0 +1,239 @@
+// mbb_serve.hip.h -- k_serve: the likelihood of given rows (k_lnlike SMODE 0, one walker per workgroup) as a kernel
+// that STAYS on the GPU between the calls of a host-driven sampler and is rung through the PCIe BAR.
+// Included by mbb_flow.hip only.
+//
+// What a boundary call (likelihood.__call__ on host arrays: SURVEY.md 8d metric M1, the lnprob callable emcee calls
+// once per half-step, mbb_fit.py:80-81) costs beside its kernel is the launch: ~2.5 us in the runtime's launch call,
+// ~3 us from the doorbell to the first wave, the tables into LDS again -- 14 us per 125-row call of which the kernel
+// is under 7 (profiles/r04/boundary_breakdown.txt).  A sampler's calls come one after another with nothing but host
+// work in between, so after a few of them in a row the host starts THIS kernel instead: one workgroup per CU, tables
+// staged once, and then per request
+//   host:   rows -> the parameter block in device memory (through the BAR), sfence, the request word -> the doorbell
+//           (same allocation, same path: PCIe keeps posted writes in order), watches the result slots in pinned memory
+//   kernel: thread 0 of every workgroup polls the doorbell (fine-grained memory: not cached); a new request number
+//           -> workgroup b < n evaluates row b exactly as k_lnlike does (same constructor text, same units in the same
+//           order, same order of the band sums: bitwise the launch's results) and writes lnl / status into the pinned
+//           result slots, which the host sees turn.
+// The kernel leaves when told to (the doorbell says QUIT: any other use of the context, its destruction) or when
+// workgroup 0 has seen no request for `idle` polls (~1 us each; it then writes QUIT itself so that every workgroup
+// follows); every workgroup besides has a safety limit of its own (four times that).  Whatever goes wrong -- a request
+// written while the kernel was leaving, a workgroup that was not resident -- shows on the host as result slots that do
+// not turn within its budget: it then says QUIT, waits for the stream, and evaluates the rows by a launch.
+#pragma once
+#include "mbb_kernels.hip.h"
+
+constexpr unsigned long long kServeQuit = 0xffffull;           // the request's row count that means "leave"
+
+// dynamic LDS of a k_serve launch besides the staged passband tables (bytes)
+__host__ __device__ constexpr size_t serve_lds(size_t nb, size_t npart, bool cov_in_lds)
+{
+    return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
+}
+
+// Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl / status =
+// the pinned result slots, pos6 = the doorbell (one 8-byte word: request number << 16 | rows), seed = the request the
+// launch itself carries (served at once), persist = idle limit in polls, chain6 = the host's "gone" word (pinned).
+template <bool OPTHIN, bool NOALPHA, bool STAGE>
+__global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_pb[kPolyBDoubles];
+    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
+    __shared__ unsigned long long s_req[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwave = blockDim.x >> 6;
+    const int nun = a.nunit, npart = a.npart, nb = a.nb;
+    WalkerK *wk = reinterpret_cast<WalkerK *>(smem_raw);
+    double *partial = reinterpret_cast<double *>(wk + 1);                 // [npart]
+    double *mflux = partial + npart;                                      // [nb]
+    double *pen = mflux + nb;                                             // [2]
+    double *s_flux = pen + 2;
+    double *s_ivar = s_flux + nb;
+    double *s_invcov = s_ivar + nb;
+    int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(s_band + nb + 1) - smem_raw) + 15) & ~(size_t)15;
+    double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off);
+    double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
+    double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
+    const unsigned long long *door = reinterpret_cast<const unsigned long long *>(a.pos6);
+
+    // ---- once: the tables and the data to LDS
+    {
+        const int nt = (int)blockDim.x;
+        const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
+        const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
+        double2 *lb = reinterpret_cast<double2 *>(s_pb);
+        double2 *lc = reinterpret_cast<double2 *>(s_pc);
+        for (int i = tid; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+        for (int i = tid; i < kPolyBDoubles / 2; i += nt) lb[i] = gb[i];
+        if (!OPTHIN)
+            for (int i = tid; i < kPolyCDoubles / 2; i += nt) lc[i] = gc[i];
+        for (int b = tid; b < nb; b += nt) { s_flux[b] = a.flux[b]; s_ivar[b] = a.ivar[b]; s_band[b] = a.band_rng[b]; }
+        if (a.cov_in_lds)
+            for (int i = tid; i < nb * nb; i += nt) s_invcov[i] = a.invcov[i];
+        if (STAGE) {
+            const int n2 = a.nchunk * 32;
+            const double2 *g0 = reinterpret_cast<const double2 *>(a.nu), *g1 = reinterpret_cast<const double2 *>(a.lnnu),
+                          *g2 = reinterpret_cast<const double2 *>(a.wt);
+            double2 *l0 = reinterpret_cast<double2 *>(s_nu), *l1 = reinterpret_cast<double2 *>(s_lnnu),
+                    *l2 = reinterpret_cast<double2 *>(s_wt);
+            for (int i = tid; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
+        }
+    }
+    auto T_nu = [&](int i) { if constexpr (STAGE) return s_nu[i]; else return a.nu[i]; };
+    auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
+    auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
+    const SampleTabs tabs = {s_tab, s_pb, s_pc};
+    int4 us_first = make_int4(0, 0, 0, 0);
+    if (wave < nun) us_first = a.unit_tab[wave];
+    __syncthreads();
+
+    unsigned long long cur = a.seed;                 // the request the launch carries
+    const long long idle = a.persist > 0 ? (long long)a.persist : 1000;
+    for (int turn = 0;; ++turn) {
+        const int n = (int)(cur & 0xffffull);
+        const int w = (int)blockIdx.x;
+        if (w < n) {
+            // ---- phase 1 (k_lnlike's, SMODE 0): gate, constructor, parameter-only penalties on one row of 16 lanes
+            if (tid < 16) {
+                WalkerK k;
+                k.status = ROW_SKIP;
+                k.pad = 0;
+                double pen_u = 0.0, pen_g = 0.0;
+                {
+                    double p[5], lT, lL = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) p[i] = __hip_atomic_load(a.pars + (size_t)w * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (OPTHIN) {
+                        double lo[1];
+                        vlog<true>(lo, p[0]);
+                        lT = lo[0];
+                    } else {
+                        double lo[2];
+                        vlog<true>(lo, p[0], p[2]);
+                        lT = lo[0]; lL = lo[1];
+                    }
+#include "mbb_walker_consts.inc"
+                }
+                if (tid == 0) {
+                    if (k.status == ROW_OK) wk[0] = k;
+                    else { wk[0].status = k.status; wk[0].pad = k.pad; }
+                    pen[0] = pen_u;
+                    pen[1] = pen_g;
+                }
+            }
+            __syncthreads();
+            // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
+            if (wk[0].status == ROW_OK) {
+                const WalkerK k = wk[0];
+                for (int u = wave; u < nun; u += nwave) {
+                    const int4 us = (u == wave) ? us_first : a.unit_tab[u];
+                    const int s = us.x, c0 = us.y, c1 = us.z;
+                    double acc = 0.0;
+                    int c = c0;
+                    for (; c + 2 <= c1; c += 2) {                     // two chunks per step (k_lnlike, do_unit)
+                        const int i0 = c * 64 + lane, i1 = i0 + 64;
+                        const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+                        const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
+                        const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                        const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                        acc = fma(f0, q0, acc);
+                        acc = fma(f1, q1, acc);
+                    }
+                    if (c < c1) {
+                        const int i = c * 64 + lane;
+                        const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
+                        acc = fma(f, T_wt(i), acc);
+                    }
+                    if (us.w == 0) {
+                        acc = wave_sum(acc);
+                        if (lane == 0) partial[s] = acc;
+                    } else if (us.w == 2) {
+                        acc = row_sum(acc);
+                        if ((lane & 15) == 0) {
+                            const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                            if (sl >= 0) partial[sl] = acc;
+                        }
+                    } else {
+                        partial[s + lane] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- phase 3 (k_lnlike's): band sums in fixed order, lnL -> the pinned result slots
+            if (wave == 0) {
+                const int st = wk[0].status;
+                double acc = 0.0;
+                if (st == ROW_OK) {
+                    const double cbb = wk[0].cbb;
+                    auto band = [&](const int b) {
+                        double sum = 0.0;
+                        const int2 rng = s_band[b];
+                        for (int sg = rng.x; sg < rng.y; sg += 4) {
+                            const int le = rng.y - 1;
+                            const double q0 = partial[sg], q1 = partial[min(sg + 1, le)], q2 = partial[min(sg + 2, le)], q3 = partial[min(sg + 3, le)];
+                            sum += q0;
+                            if (sg + 1 < rng.y) sum += q1;
+                            if (sg + 2 < rng.y) sum += q2;
+                            if (sg + 3 < rng.y) sum += q3;
+                        }
+                        sum *= cbb;
+                        const double d = s_flux[b] - sum;              // likelihood.py:821
+                        if (a.invcov) mflux[b] = d;
+                        else acc = fma(d * d, s_ivar[b], acc);         // :825
+                    };
+                    for (int b = lane; b < nb; b += 64) band(b);
+                    if (a.invcov) {                                    // :823
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        for (int i = lane; i < nb; i += 64) {
+                            double t = 0.0;
+                            const double *crow = (a.cov_in_lds ? s_invcov : a.invcov) + (size_t)i * nb;
+                            for (int jj = 0; jj < nb; ++jj) t = fma(crow[jj], mflux[jj], t);
+                            acc = fma(mflux[i], t, acc);
+                        }
+                    }
+                    acc = (nb <= 16) ? wave_sum_row0(acc) : wave_sum(acc);
+                }
+                if (lane == 0) {
+                    double r;
+                    if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
+                    else if (st != ROW_OK) r = __builtin_nan("");
+                    else {
+                        r = fma(-0.5, acc, pen[0]);                    // :828
+                        if (a.has_gprior) r += pen[1];                 // :830-831
+                    }
+                    // lnl first, then status: the host takes a row when both have turned
+                    __hip_atomic_store(a.lnl + w, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(a.status + w, a.debug ? (st | (wk[0].pad << 8)) : st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        // ---- the next request: thread 0 watches the doorbell, the workgroup follows it
+        if (tid == 0) {
+            unsigned long long v = cur;
+            const long long limit = (blockIdx.x == 0) ? idle : 4 * idle + 64;
+            long long polls = 0;
+            for (;;) {
+                v = __hip_atomic_load(door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (v != cur) break;
+                if (++polls > limit) {
+                    v = (cur & ~0xffffull) | kServeQuit;
+                    // workgroup 0 has seen nothing for `idle` polls: it says so where everybody looks
+                    if (blockIdx.x == 0)
+                        __hip_atomic_store(const_cast<unsigned long long *>(door), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_req[turn & 1] = v;
+        }
+        __syncthreads();
+        cur = s_req[turn & 1];
+        if ((cur & 0xffffull) == kServeQuit) break;
+    }
+    // gone: the host may look here instead of asking the runtime
+    if (blockIdx.x == 0 && tid == 0 && a.chain6)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.chain6), cur >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}

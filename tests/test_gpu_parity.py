@@ -1073,6 +1073,68 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
     assert twin._fast is None and np.array_equal(twin(allp[:125]), want[:125], equal_nan=True)
 
 
+def test_served_boundary_equals_the_launches(mbb, g_lnl):
+    """After a few boundary calls in a row the rows go to a kernel that stays on the GPU and is rung through the BAR
+    (k_serve) instead of a launch per call.  Same results bit for bit, for every batch size up to a row per CU, for one
+    row, with a covariance matrix; anything else on the context makes it leave first; it leaves by itself when nothing
+    comes; a request it does not answer in time is evaluated by a launch."""
+    import time
+    for variant, cov in (("thick_walpha", False), ("thin_walpha", False), ("thick_walpha", True)):
+        opthin = variant.startswith("thin")
+        like = mbb.likelihood(response=True, opthin=opthin)
+        like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl["cfg2/%s/flux" % variant], g_lnl["cfg2/%s/unc" % variant])
+        if cov:
+            unc = g_lnl["cfg2/%s/unc" % variant]
+            like.set_cov(np.diag(unc ** 2) + 0.2 * np.outer(unc, unc))
+        ctx = like._sync_device()
+        cus = ctx.info("cu_count")
+        allp = np.tile(g_lnl["cfg2/%s/pars" % variant], (2, 1))
+        ctx.set_option("serve", 0)
+        want = like(allp[:cus]).copy()
+        w1 = like(allp[3])
+        ctx.set_option("serve", 2)                                   # (also beside the test session's other contexts)
+        assert ctx.info("serving") == 0
+        for n in (125, 125, 125, 125, 7, cus, 1, 125, 64):
+            got = like(allp[:n])
+            assert np.array_equal(got, want[:n], equal_nan=True), (variant, cov, n)
+        assert ctx.info("serving") == 1 and ctx.info("serve_requests") >= 6 and ctx.info("serve_fallbacks") == 0
+        assert like(allp[3]) == w1 and type(like(allp[3])) is float and ctx.info("serving") == 1
+        # more rows than CUs: by a launch (the server leaves), then served again after a few calls in a row
+        big = like(allp[:cus + 8])
+        assert ctx.info("serving") == 0 and np.array_equal(big[:cus], want, equal_nan=True)
+        for _ in range(4):
+            assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        assert ctx.info("serving") == 1
+        # anything else on the context: it leaves first, and what was set is what the next calls see
+        like.set_uplim("T", 12.0)
+        changed = like(allp[:125])
+        assert ctx.info("serving") == 0 and not np.array_equal(changed, want[:125], equal_nan=True)
+        for _ in range(4):
+            assert np.array_equal(like(allp[:125]), changed, equal_nan=True)
+        assert ctx.info("serving") == 1
+        like._has_uplim[0] = False; like._dirty = True
+        assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        # it leaves by itself when nothing comes, and the next request is evaluated all the same
+        ctx.set_option("serve_idle_us", 200)
+        for _ in range(4):
+            like(allp[:125])
+        assert ctx.info("serving") == 1
+        time.sleep(0.05)
+        nf = ctx.info("serve_fallbacks")
+        assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        assert ctx.info("serve_fallbacks") == nf + 1                 # (found gone: by a launch)
+        for _ in range(4):
+            assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        assert ctx.info("serving") == 1
+        # the device sampler on the same context while a server is resident
+        s = mbb.DeviceEnsembleSampler(64, 5, like, seed=3)
+        p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(2).normal(size=(64, 5)))
+        pos, lnp, _ = s.run_mcmc(p0, 5)
+        assert ctx.info("serving") == 0 and ctx.info("flow_fallbacks") == 0
+        lnl_close(lnp, like(pos))
+        del s, like
+
+
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
     """The three ways an emcee-style sampler can call the likelihood -- row by row
     (emcee's plain map, mbb_fit.py:80-81 with threads=1), through a pool's map with a
