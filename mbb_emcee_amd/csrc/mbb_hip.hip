@@ -200,6 +200,8 @@ struct mbb_ctx {
     int32_t *dv_status = nullptr;
     // the served boundary (k_serve, mbb_serve.hip.h): a kernel that stays resident between a host-driven sampler's calls
     unsigned long long *w_door = nullptr;     // its doorbell: a word of fine-grained device memory the host writes through the BAR
+    double *h_srv = nullptr, *dv_srv = nullptr;   // pinned: a server's result records [row]{lnl, status as a 64-bit integer}
+    size_t srv_cap = 0;
     unsigned long long *h_gone = nullptr;     // pinned: the number of the last request a server saw before it left (0: still there)
     bool serving = false;
     unsigned long long srv_seq = 0;           // requests so far (the doorbell word is request number << 16 | rows)
@@ -387,7 +389,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_mflux); free_dev(c->d_status);
     free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_mflux); free_host(c->h_status);
     free_dev(c->w_pars);
-    free_dev(c->w_door); free_host(c->h_gone);
+    free_dev(c->w_door); free_host(c->h_gone); free_host(c->h_srv);
     free_dev(c->d_gather); free_host(c->h_gather);
     free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
     free_dev(c->d_sed_wk);
@@ -1085,6 +1087,7 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
         }
         HIPCHK(hipHostMalloc((void **)&c->h_gone, 64, hipHostMallocMapped | hipHostMallocCoherent));
     }
+
     LikeArgs a;
     memset(&a, 0, sizeof a);
     a.nu = c->d_nu; a.lnnu = c->d_lnnu; a.wt = c->d_wt;
@@ -1097,7 +1100,7 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     for (int i = 0; i < 5; ++i) a.lowlim[i] = c->lowlim[i];
     for (int i = 0; i < 6; ++i) { a.uplim[i] = c->uplim[i]; a.gmean[i] = c->gmean[i]; a.givar[i] = c->givar[i]; }
     a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
-    a.pars = c->w_pars; a.n = n; a.lnl = c->dv_lnl; a.status = c->dv_status; a.model_flux = nullptr;
+    a.pars = c->w_pars; a.n = n; a.lnl = c->dv_srv; a.status = nullptr; a.model_flux = nullptr;
     a.wpb = 1; a.debug = (int)c->opt_debug; a.nsrc = 1;
     int wpb, threads;
     pick_geometry(c, 1, wpb, threads);
@@ -1143,8 +1146,14 @@ static int serve_request(mbb_ctx *c, int n)
 {
     auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
     const long t_a = now_ns();
-    uint64_t *hl = reinterpret_cast<uint64_t *>(c->h_lnl);
-    for (int i = 0; i < n; ++i) { hl[i] = kLnlSentinel; c->h_status[i] = kStatusSentinel; }
+    // (the records exist once a server has been started; before that serve_start makes them)
+    if (!c->h_srv) {
+        HIPCHK(hipHostMalloc((void **)&c->h_srv, (size_t)c->cu_count * 16, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostGetDevicePointer((void **)&c->dv_srv, c->h_srv, 0));
+        c->srv_cap = (size_t)c->cu_count;
+    }
+    uint64_t *hr = reinterpret_cast<uint64_t *>(c->h_srv);
+    for (int i = 0; i < n; ++i) hr[2 * i + 1] = (uint64_t)kStatusSentinel;
     const unsigned long long word = (++c->srv_seq << 16) | (unsigned long long)n;
     __builtin_ia32_sfence();                       // the caller's rows, through the BAR, before the request
     const long t_b = now_ns();
@@ -1159,12 +1168,15 @@ static int serve_request(mbb_ctx *c, int n)
     }
     const long t_c = now_ns();
     ++c->srv_requests;
-    const int32_t *hs = c->h_status;
     int i = 0;
     bool seen = false;
     for (long spins = 0;; ++spins) {
-        while (i < n && __atomic_load_n(&hl[i], __ATOMIC_ACQUIRE) != kLnlSentinel &&
-               __atomic_load_n(&hs[i], __ATOMIC_ACQUIRE) != kStatusSentinel) ++i;
+        // a record is one 16-byte store: when its status word has turned, its lnl is there
+        while (i < n && __atomic_load_n(&hr[2 * i + 1], __ATOMIC_ACQUIRE) != (uint64_t)kStatusSentinel) {
+            c->h_lnl[i] = c->h_srv[2 * i];
+            c->h_status[i] = (int32_t)hr[2 * i + 1];
+            ++i;
+        }
         if (i == n) { seen = true; break; }
         if ((spins & 63) == 63 && (now_ns() - t_c > budget_ns || __atomic_load_n(c->h_gone, __ATOMIC_ACQUIRE) != 0)) break;
         __builtin_ia32_pause();

@@ -30,8 +30,8 @@ __host__ __device__ constexpr size_t serve_lds(size_t nb, size_t npart, bool cov
     return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
 
-// Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl / status =
-// the pinned result slots, pos6 = the doorbell (one 8-byte word: request number << 16 | rows), seed = the request the
+// Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl = the pinned
+// result records [row]{lnl, status as a 64-bit integer}, pos6 = the doorbell (one 8-byte word: request number << 16 | rows), seed = the request the
 // launch itself carries (served at once), persist = idle limit in polls, chain6 = the host's "gone" word (pinned).
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
 __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
@@ -103,8 +103,12 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 double pen_u = 0.0, pen_g = 0.0;
                 {
                     double p[5], lT, lL = 0.0;
+                    // the row's five values in ONE request (lane i takes element i; the block is fine-grained memory the
+                    // host has just written through the BAR: not cached, every request goes to memory -- five requests
+                    // per workgroup, one per element with all lanes on the same address, cost 125 rows 8 us)
+                    const double pe = tid < 5 ? __hip_atomic_load(a.pars + (size_t)w * 5 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) p[i] = __hip_atomic_load(a.pars + (size_t)w * 5 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    for (int i = 0; i < 5; ++i) p[i] = __shfl(pe, i);
                     if (OPTHIN) {
                         double lo[1];
                         vlog<true>(lo, p[0]);
@@ -204,9 +208,17 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                         r = fma(-0.5, acc, pen[0]);                    // :828
                         if (a.has_gprior) r += pen[1];                 // :830-831
                     }
-                    // lnl first, then status: the host takes a row when both have turned
-                    __hip_atomic_store(a.lnl + w, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(a.status + w, a.debug ? (st | (wk[0].pad << 8)) : st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // lnl and status as ONE 16-byte store into the row's result record (pinned host memory): every
+                    // store is a PCIe write of its own and they leave one after the other -- two per row cost 125 rows
+                    // ~2 us more than one.  The host takes a row when its status word has turned.
+                    // (system scope -- straight through to the host -- spelled out: there is no 16-byte atomic store to
+                    // ask the compiler for, and a non-temporal one may stay in L2 until the kernel ends)
+                    typedef int v4i __attribute__((ext_vector_type(4)));
+                    const long long rb = __double_as_longlong(r), sb = (long long)(a.debug ? (st | (wk[0].pad << 8)) : st);
+                    v4i rec;
+                    rec.x = (int)rb; rec.y = (int)(rb >> 32); rec.z = (int)sb; rec.w = (int)(sb >> 32);
+                    double *dst = a.lnl + 2 * (size_t)w;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(rec) : "memory");
                 }
             }
         }
