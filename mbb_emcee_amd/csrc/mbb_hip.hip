@@ -1184,11 +1184,13 @@ static int serve_request(mbb_ctx *c, int n)
     c->last_watch_seen = seen ? 1 : 0;
     c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
     if (seen) { c->srv_strikes = 0; return MBB_OK; }
-    // the slots did not turn: the server had left (or was leaving) when the request came, or it is not resident.
-    // It is told to go, waited for, and the rows go by a launch; three such in a row and the feature rests.
+    // the records did not turn: the server had left when the request came (it says so: nothing wrong, the sampler's
+    // calls were further apart than its patience), or it was leaving, or it is not resident.  It is told to go, waited
+    // for, and the rows go by a launch; three requests in a row lost to a server that had NOT said it was gone, and
+    // the feature rests for the life of the context.
     ++c->srv_fallbacks;
     c->srv_hot = 0;
-    if (++c->srv_strikes >= 3) c->opt_serve = 0;
+    if (__atomic_load_n(c->h_gone, __ATOMIC_ACQUIRE) == 0 && ++c->srv_strikes >= 3) c->opt_serve = 0;
     int rc = serve_stop(c);
     return rc ? rc : 1;
 }
