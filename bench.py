@@ -1125,6 +1125,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
             if hung is not None:
                 sys.stdout.flush()
                 os._exit(0)             # the measured run was valid; a wedged stream would hang teardown
+        elif rank == 0:
+            emit({"_part": "boundary_sharded", "data": {"ok": None, "why": ("not asked for" if args.no_sharded_boundary else
+                  "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev))}})
         # ---- the exchanges the timed run did not use: the same rehearsal and a short timed run each,
         # outside `value`.  The measured line is already with the supervisor; whatever happens here
         # only adds to it.
