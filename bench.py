@@ -1113,7 +1113,17 @@ def worker_body(args, rank, world, local_rank, base, fail):
         if world <= ndev and not args.no_sharded_boundary:
             if still_time():
                 try:
-                    sb = sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok)
+                    def bcast(obj):
+                        box = [obj]
+                        dist.broadcast_object_list(box, src=0)
+                        return box[0]
+
+                    def reduce_max(vals):
+                        import torch
+                        t = torch.tensor(vals, dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        return [float(x) for x in t]
+                    sb = sharded_boundary(ctx, like, rank, world, allw, nwt, barrier, all_ok, bcast, reduce_max)
                 except Hung as e:
                     sb, hung = {"ok": False, "why": str(e), "hung": True}, "boundary_sharded"
                 except Exception as e:           # noqa
@@ -1171,21 +1181,20 @@ def worker_body(args, rank, world, local_rank, base, fail):
         dist.destroy_process_group()
 
 
-def sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok):
+def sharded_boundary(ctx, like, rank, world, allw, nwt, barrier, all_ok, bcast, reduce_max):
     """SURVEY.md 8d M1 at N > 1 (see the call site): parallel.ShardedLikelihood over parallel.RcclComm.  Every
     rank makes the same calls in the same order (a collective inside each); times are this rank's wall clock
-    around a call, the figure reported is the slowest rank's median."""
-    import torch
+    around a call, the figure reported is the slowest rank's median.  bcast(obj) -> rank 0's obj on every rank and
+    reduce_max([floats]) -> their maxima over the ranks are the caller's (gloo in bench.py; nothing of torch here)."""
     from mbb_emcee_amd import parallel
     res = {"ok": False,
            "what": "likelihood.__call__ of the moving half-ensemble sharded over %d ranks: this rank's block through the "
                    "fused kernel, one in-place ncclAllGather of the blocks' lnprob (RCCL), the gathered vector back on "
                    "the host; host arrays in and out, median of 200 synchronous calls, slowest rank" % world}
-    uid = [ctx.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
+    uid = bcast(ctx.comm_unique_id() if rank == 0 else None)
     comm, why = None, ""
     try:
-        comm = guarded(lambda: parallel.RcclComm(ctx, rank, world, uid[0]), GUARD_S)
+        comm = guarded(lambda: parallel.RcclComm(ctx, rank, world, uid), GUARD_S)
     except Watchdog:
         raise Hung("boundary_sharded: ncclCommInitRank did not return within %.0f s" % GUARD_S)
     except Exception as e:           # noqa
@@ -1218,8 +1227,7 @@ def sharded_boundary(ctx, like, dist, rank, world, allw, nwt, barrier, all_ok):
             if not all_ok(same):
                 res["why"] = "the gathered lnprob of %d rows differs from the unsharded evaluation on some rank" % n
                 return res
-            t = torch.tensor([float(np.median(ts)), float(np.percentile(ts, 90))], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = reduce_max([float(np.median(ts)), float(np.percentile(ts, 90))])
             res["rows_%d" % n] = {"rows_per_rank": -(-n // world), "median_us": float(t[0]) * 1e6, "p90_us": float(t[1]) * 1e6,
                                   "evals_per_s": n / float(t[0]), "calls": len(ts),
                                   "equals_unsharded_bitwise": True}

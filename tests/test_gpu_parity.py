@@ -584,25 +584,14 @@ def test_rccl_single_rank_allgather(mbb, g_lnl):
 def test_bench_sharded_boundary_leg_with_one_rank(mbb, g_lnl):
     """bench.py's `boundary_sharded` leg (the host-driven split of north_star: ShardedLikelihood over RcclComm, one
     ncclAllGather of lnprob per call) has never seen more than one GPU; here its code runs end to end with one rank
-    and a stand-in for torch.distributed: set-up, the timed loop, the bitwise check against the unsharded evaluation,
+    and the side channel's two operations as identities (no torch in the test process): set-up, the timed loop, the bitwise check against the unsharded evaluation,
     the reduction of the medians, tear-down."""
     import bench
 
-    class OneRank(object):                       # what sharded_boundary uses of torch.distributed
-        class ReduceOp(object):
-            MAX = "max"
-
-        @staticmethod
-        def broadcast_object_list(objs, src=0):
-            pass
-
-        @staticmethod
-        def all_reduce(t, op=None):
-            pass
     like = _cfg2_like(mbb, g_lnl)
     ctx = like._sync_device()
     allw = bench.walkers(1)
-    res = bench.sharded_boundary(ctx, like, OneRank, 0, 1, allw, 250, lambda: None, lambda ok: bool(ok))
+    res = bench.sharded_boundary(ctx, like, 0, 1, allw, 250, lambda: None, lambda ok: bool(ok), lambda obj: obj, lambda v: v)
     assert res["ok"] is True, res
     for key, n in (("rows_125", 125), ("rows_250", 250)):
         r = res[key]
