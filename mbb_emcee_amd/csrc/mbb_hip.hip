@@ -148,7 +148,11 @@ static RcclApi g_rccl;
 static int load_rccl()
 {
     if (g_rccl.handle) return MBB_OK;
-    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // A copy that is in the process already first (by its soname): a launcher that has imported torch brings torch's
+    // own librccl / libamdhip64 / libhsa-runtime64 along, this library then runs on THAT HIP runtime (same soname), and
+    // a second RCCL from the system path would bring a second HSA runtime with it.
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(MBB_ERR_RCCL, "cannot load librccl.so");
