@@ -70,6 +70,7 @@ ONE_LAUNCH_FORMS = (7, 8, 9)   # sampler forms whose launches cover many half-st
 # N > 1: what the supervisor allows the whole run, what a rank allows any one step that may wedge (communicator
 # set-up, a rehearsal, a timed run), and the age of the run beyond which nothing optional is started any more
 SUPERVISOR_DEADLINE_S, GUARD_S, OPTIONAL_UNTIL_S = 480.0, 45.0, 240.0
+PRECONDITION_S = 0.05      # one GPU: a scratch ensemble is stepped this long right before the W warm-up steps (GPU clocks)
 CLOCK_HZ = 2.4e9
 # tools/issue_cost.hip, profiles/r02/issue_cost_v1.txt: cycles one wave64 VALU
 # instruction holds its SIMD, four waves per SIMD
@@ -958,13 +959,28 @@ def worker_body(args, rank, world, local_rank, base, fail):
 
         # ---- the timed region: K dependent MCMC steps ----------------------------
         def timed():
+            if dist is None:
+                # one GPU: clock, event, launch, event, stream wait, clock -- inside one native call
+                # (mbb_sampler_advance_timed), so that the harness around a 20-step region is not four Python-to-C
+                # round trips; the stream is idle before and after (the wait inside).  This function runs on a thread
+                # of its own (guarded), possibly on a core that has been asleep, and the W warm-up steps go through the
+                # very call that is timed next.  The GPU: a process that has run a millisecond of kernels so far (the rehearsal) finds it ~6 % slower
+                # than one that has kept it busy for 20 ms (profiles/r04/timed_region.txt: 141 against 133 us on the
+                # stream for the same 20 steps) -- a scratch ensemble is stepped for 50 ms first, said on the line.
+                scratch = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=12)
+                scratch.run_mcmc(allw[:nwt], 2, storechain=False)
+                t_end = time.perf_counter() + PRECONDITION_S
+                while time.perf_counter() < t_end:
+                    scratch.advance_timed(200)
+                smp.advance_timed(warmup)
+                first = smp.advance_timed(steps)
+                # (the line's value is that ONE region; eight more of the same right behind it, reported beside it,
+                # say how far the single shot is from the typical one)
+                state["again"] = [smp.advance_timed(steps) for _ in range(8)]
+                del scratch
+                return first
             smp.advance_async(warmup)
             ctx.sync(); barrier()
-            if dist is None:
-                # one GPU: clock, event, enqueue, event, stream wait, clock -- inside one native call
-                # (mbb_sampler_advance_timed), so that the harness around a 20-step region is not four
-                # Python-to-C round trips; the stream is idle before (sync above) and after (the wait inside)
-                return smp.advance_timed(steps)
             e0, e1 = ctx.event(), ctx.event()
             t0 = time.perf_counter()
             ctx.record(e0)
@@ -1000,7 +1016,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
                                             if fine else (state["err"] or "non-finite state"))
             teardown()
             return res
-        res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, form=ctx.info("last_kernel_form"),
+        res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, again=state.get("again"), form=ctx.info("last_kernel_form"),
                    us_per_step=1e6 * elapsed / steps,
                    # which instantiation that was (form 7: last_wpb = pairs of walkers per workgroup)
                    pairs=ctx.info("last_wpb"), staged=bool(ctx.info("last_stage")))
@@ -1043,12 +1059,19 @@ def worker_body(args, rank, world, local_rank, base, fail):
         out.update({"value": nwt * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
                     "mcmc_steps_per_s": args.steps / elapsed,
                     "stream_us_per_step": stream_ms * 1e3 / args.steps,
+                    **({"same_region_again_us": {"wall": [round(w * 1e6, 2) for w, _ in run["again"]],
+                                                 "stream": [round(m * 1e3, 2) for _, m in run["again"]],
+                                                 "note": "eight more timed regions of the same K steps right behind the reported one"}}
+                       if run.get("again") else {}),
                     # (sharded: the counts of this rank's own walkers)
-                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps),
+                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps * (1 + len(run.get("again") or []))),
                     "ranks_agree": True})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = run["form"]
         out["config"] = dict(out["config"])
+        if world == 1:
+            out["config"]["preconditioning"] = ("%.0f ms of sampler steps on a scratch ensemble right before the W warm-up steps: "
+                                                "the GPU's clocks, not the chain that is timed" % (PRECONDITION_S * 1e3))
         if form in (6,) + ONE_LAUNCH_FORMS:
             nlaunch = (args.steps + 4095) // 4096
             if form == 7:

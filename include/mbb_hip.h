@@ -151,10 +151,10 @@ int mbb_sampler_run(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a, d
                     double *lnprob, double *pos_out, double *lnprob_out, double *naccepted);
 int mbb_sampler_advance_async(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a);
 /* Measurement helper (bench.py's timed region on one GPU): nsteps steps as mbb_sampler_advance_async
- * enqueues them, bracketed inside ONE call by the host clock and by two events on the context's stream:
- * clock; event; enqueue; event; stream wait; clock.  The stream must be idle on entry (mbb_sync before).
- * wall_s = host seconds from before the first event to after the wait; stream_ms = between the events.
- * No reference counterpart. */
+ * enqueues them, bracketed inside ONE call by the host clock and by two events on the context's stream,
+ * recorded right before the run's first launch and right behind its last: clock; enqueue; stream wait; clock.
+ * The stream must be idle on entry (mbb_sync before).  wall_s = host seconds from before the enqueue to after
+ * the wait; stream_ms = between the events.  No reference counterpart. */
 int mbb_sampler_advance_timed(mbb_ctx *ctx, void *sampler, int nsteps, double stretch_a, double *wall_s,
                               float *stream_ms);
 

@@ -23,6 +23,8 @@ MBB_FLOW_HD constexpr int flow_seq(int h, int m) { return m > 0 ? h + 2 * m - 1 
 
 // ---- sampler form 7 (k_flowm, mbb_flowm.hip.h): the same numbering of half-steps and moves
 constexpr int kFmSlots = 4;    // slots per row (moves filed mod this)
+constexpr int kFmMseq = kFmSlots;    // decision words per row as laid out, the stride of mseq (a 128-byte line per row, 16,
+                                     // is no faster: profiles/r04/done_counters_alignment.txt)
 constexpr int kFmLag = 4;      // a workgroup at half-step j waits until every workgroup is through with j - kFmLag
 constexpr int kFmRing = 8;     // completion counters, by half-step mod this (a power of two >= 2 kFmLag)
 // (8 slots and a lag of 8 were tried: 6.49 against 6.29 us per step -- the lag guard is not what a half-step waits for)

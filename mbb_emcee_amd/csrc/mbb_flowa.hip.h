@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                 const int m_new = flow_cnt(h, it) + 1;
                 // the decision first -- all that the constructors of the next half-step wait for
                 if (lane == 0)
-                    __hip_atomic_store(fv.mseq + (size_t)row * kFmSlots + (m_new % kFmSlots),
+                    __hip_atomic_store(fv.mseq + (size_t)row * kFmMseq + (m_new % kFmSlots),
                                        serial32 | (2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull)), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 // element (lane & 7) of the row as it is after this half-step
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, lo[4] = {0.0, 0.0, 0.0, 0.0};
             // (2) the partner's decision of half-step j - 1 says which candidate was right: asked for once towards
             // the end of the constructor, polled for afterwards if it is not there yet
-            const unsigned long long *w2 = fv.mseq + (size_t)prow * kFmSlots + (m1 % kFmSlots);
+            const unsigned long long *w2 = fv.mseq + (size_t)prow * kFmMseq + (m1 % kFmSlots);
             const bool watch2 = active && j > 0 && l16 == 0;
             unsigned long long v2 = 0;
             if (active) {

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             const double *lnp_p = fv.row + ((size_t)(m_s % kFmSlots) * a.nw + row) * kFmWords + 10;
             const unsigned long long tag_s = serial32 | (unsigned long long)flow_seq(L_half, m_s);
             const unsigned long long need_g = 2ull * (unsigned long long)a.n * (unsigned long long)(((it - kFmLag) / kFmRing) + 1);
-            const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFmSlots + (m_par % kFmSlots)
+            const unsigned long long *word = lane == 22 ? fv.mseq + (size_t)prow * kFmMseq + (m_par % kFmSlots)
                                                         : done_set + ((it - kFmLag) & (kFmRing - 1)) * 16;
             const bool watch = (lane == 22 && need_p > 0) || (lane == 23 && it >= kFmLag);
             // The band sums do not wait for the partner: as soon as Q is through they are formed, between
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                     // check word per lane; counts and chain are for the host: plain stores
                     FM_EV(it, 6);
                     if (lane == 0)
-                        __hip_atomic_store(fv.mseq + (size_t)row * kFmSlots + (m_new % kFmSlots),
+                        __hip_atomic_store(fv.mseq + (size_t)row * kFmMseq + (m_new % kFmSlots),
                                            serial32 | (2ull * (unsigned long long)(it + 1) + (accept ? 1ull : 0ull)), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                     const double lnp_new = accept ? r : lnp_cur;
@@ -615,7 +615,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 int slot = -1, kind = 0;                              // kind 1: a decision word, 2: an element
                 if (lane < 2) {
                     const int r = lane == 0 ? qr : qp;
-                    wsrc = fv.mseq + (size_t)(ob + r) * kFmSlots + (m_q % kFmSlots);
+                    wsrc = fv.mseq + (size_t)(ob + r) * kFmMseq + (m_q % kFmSlots);
                     need = (unsigned long long)flow_seq(hj ^ 1, m_q);
                     kind = (has && m_q > 0 && (lane == 0 || c1)) ? 1 : 0;
                 } else if (lane < 7) {
@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             // (2) the two decisions of half-step j - 2 say which row of lanes was right.  They are asked
             // for once towards the end of the constructor, so that the answer is there when it is through
             // (a decision that arrives later is polled for afterwards)
-            const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFmSlots + (m_s % kFmSlots);
+            const unsigned long long *w2 = fv.mseq + (size_t)(l16 == 0 ? rown : pprow) * kFmMseq + (m_s % kFmSlots);
             const bool watch2 = m_s > 0 && (l16 == 0 || (l16 == 1 && c1));
             const unsigned long long need2 = (unsigned long long)flow_seq(hj, m_s);
             unsigned long long v2 = 0;

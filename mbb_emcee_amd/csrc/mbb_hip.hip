@@ -218,7 +218,8 @@ struct mbb_ctx {
     long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
-    hipFunction_t mod_fn[40] = {};   // launch_api 1: the kernels' module handles, by variant
+    hipFunction_t mod_fn[64] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 16 k_flowr / k_flowa)
+    hipEvent_t *launch_ev = nullptr; // != nullptr: two events to record right before and right behind the next launch
     long opt_launch_api = 1;     // 1 hipModuleLaunchKernel with a packed argument buffer (-0.2 us per call, profiles/r04/boundary_breakdown.txt); 0 hipLaunchKernel
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
     size_t gather_cap = 0;
@@ -714,6 +715,32 @@ struct SamplerLaunch {
     int parity = 0;               // ... which of the two sets of completion counters it uses
 };
 
+// One launch of a kernel of the likelihood family.  launch_api 1 (default): the module-launch entry with the argument
+// block handed over as ONE packed buffer -- no per-argument marshalling in the runtime (A/B: tools/probe_boundary_breakdown.py,
+// profiles/r04/boundary_breakdown.txt); with c->launch_ev set, the launch that carries the two events itself.
+static int launch_packed(mbb_ctx *c, void (*kern)(const LikeArgs), int fn_slot, int grid, int threads, size_t smem, LikeArgs &a)
+{
+    hipEvent_t *ev = c->launch_ev;
+    if (c->opt_launch_api == 1) {
+        hipFunction_t &f = c->mod_fn[fn_slot];
+        if (!f) HIPCHK(hipGetFuncBySymbol(&f, (const void *)kern));
+        size_t sz = sizeof(a);
+        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+        // (hipExtModuleLaunchKernel would take the two events with the launch -- the dispatch's own timestamps, no marker
+        // packets: measured, it costs 8 us MORE of host time per timed region than two hipEventRecord around the launch,
+        // profiles/r04/timed_region.txt)
+        if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)smem, c->stream, nullptr, extra));
+        if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
+        return MBB_OK;
+    }
+    if (ev) HIPCHK(hipEventRecord(ev[0], c->stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem, c->stream, a);
+    HIPCHK(hipGetLastError());
+    if (ev) HIPCHK(hipEventRecord(ev[1], c->stream));
+    return MBB_OK;
+}
+
 static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                          int32_t *d_status, double *d_mflux, const SamplerLaunch *sl = nullptr)
 {
@@ -814,9 +841,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                 g = want;
             }
         }
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(thr), sm_total, c->stream, a);
-        HIPCHK(hipGetLastError());
-        return MBB_OK;
+        return launch_packed(c, kern, 40 + ri, wgs, thr, sm_total, a);
     }
     if (sl && sl->merged) {
         // sampler form 7: 2 n workgroups of (quadrature waves + 5), every one resident; its own LDS plan
@@ -858,9 +883,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
                 g = want;
             }
         }
-        hipLaunchKernelGGL(kern, dim3(wgs), dim3(thr), sm_total, c->stream, a);
-        HIPCHK(hipGetLastError());
-        return MBB_OK;
+        return launch_packed(c, kern, 32 + mi, wgs, thr, sm_total, a);
     }
     if (sl) {
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
@@ -925,19 +948,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
             g = want;
         }
     }
-    if (c->opt_launch_api == 1) {
-        // the module-launch entry with the argument block handed over as ONE packed buffer: no per-argument
-        // marshalling in the runtime (A/B: tools/probe_boundary_breakdown.py, profiles/r04/boundary_breakdown.txt)
-        hipFunction_t &f = c->mod_fn[vi_of_kernel];
-        if (!f) HIPCHK(hipGetFuncBySymbol(&f, (const void *)kern));
-        size_t sz = sizeof(a);
-        void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-        HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)threads, 1, 1, (unsigned)smem_total, c->stream, nullptr, extra));
-        return MBB_OK;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), smem_total, c->stream, a);
-    HIPCHK(hipGetLastError());
-    return MBB_OK;
+    return launch_packed(c, kern, vi_of_kernel, grid, threads, smem_total, a);
 }
 
 extern "C" int mbb_lnlike_batch_device(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
@@ -1417,7 +1428,10 @@ static int allgather_bytes(mbb_ctx *c, void *base, size_t bytes_per_rank)
     return MBB_OK;
 }
 
-static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store, bool backup = true)
+// (tev: two events for mbb_sampler_advance_timed, recorded on the stream right before the run's first launch and right
+// behind its last)
+static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double stretch_a, bool store, bool backup = true,
+                           hipEvent_t *tev = nullptr)
 {
     s->flow_used = false;
     ShardPlan p;
@@ -1425,6 +1439,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     if (rc) return rc;
     const int nw = s->nw, half = nw / 2;
     const size_t nl = (size_t)s->nsrc * p.per;              // walkers per launch
+    if (p.xchg && tev) HIPCHK(hipEventRecord(tev[0], c->stream));
     if (p.xchg) {
         // the kernel's view of the exchange for this run, in stream order before its launches
         // (pageable source: staged by the runtime before the call returns)
@@ -1485,6 +1500,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 HIPCHK(hipGetLastError());
             }
             s->steps_done += (unsigned long long)nsteps;
+            if (tev) HIPCHK(hipEventRecord(tev[1], c->stream));
             return MBB_OK;
         }
     }
@@ -1540,6 +1556,8 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 s->flowm_parity = 0;
             }
             s->spec_form = resident ? 8 : 7;
+            const bool carried = tev && nsteps <= 4096;
+            if (tev && !carried) HIPCHK(hipEventRecord(tev[0], c->stream));
             for (int t0 = 0; t0 < nsteps; t0 += 4096) {
                 const int nt = std::min(4096, nsteps - t0);
                 // one launch, nothing before or after it: it files the rows it finds and stores the last ones back
@@ -1555,13 +1573,18 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                 sl.resident = resident;
                 sl.res_w = res_w;
                 sl.res_ahead = res_ahead;
-                if ((rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl))) return rc;
+                c->launch_ev = carried ? tev : nullptr;
+                rc = launch_lnlike(c, nullptr, (int)nl, nullptr, nullptr, nullptr, &sl);
+                c->launch_ev = nullptr;
+                if (rc) return rc;
             }
+            if (tev && !carried) HIPCHK(hipEventRecord(tev[1], c->stream));
             s->steps_done += (unsigned long long)nsteps;
             return MBB_OK;
         }
     }
     sl.spec = nullptr; sl.merged = false; sl.resident = false; sl.persist = 0;
+    if (tev && !p.xchg) HIPCHK(hipEventRecord(tev[0], c->stream));
     for (int t = 0; t < nsteps; ++t)
         for (int h = 0; h < 2; ++h) {
             const int hb = h ? half : 0;
@@ -1591,6 +1614,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
         if (store && (rc = allgather_bytes(c, s->d_chain6, (size_t)nsteps * 2 * nl * 6 * sizeof(double)))) return rc;
         if ((rc = allgather_bytes(c, s->d_nacc, 2 * nl * sizeof(unsigned int)))) return rc;
     }
+    if (tev) HIPCHK(hipEventRecord(tev[1], c->stream));
     return MBB_OK;
 }
 
@@ -1739,6 +1763,7 @@ extern "C" int mbb_sampler_advance_async(mbb_ctx *c, void *sp, int nsteps, doubl
 
 // Measurement helper: the same enqueue between the host clock and two events, in one call -- the harness
 // around a short timed region is then a few hundred nanoseconds instead of four Python-to-C round trips.
+// (The events ride on the launch itself when the run is one: sampler_enqueue.)
 extern "C" int mbb_sampler_advance_timed(mbb_ctx *c, void *sp, int nsteps, double stretch_a, double *wall_s,
                                          float *stream_ms)
 {
@@ -1753,9 +1778,7 @@ extern "C" int mbb_sampler_advance_timed(mbb_ctx *c, void *sp, int nsteps, doubl
         HIPCHK(hipEventCreate(&c->ev_timed[1]));
     }
     const auto t0 = std::chrono::steady_clock::now();
-    HIPCHK(hipEventRecord(c->ev_timed[0], c->stream));
-    if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, false, false))) return rc;
-    HIPCHK(hipEventRecord(c->ev_timed[1], c->stream));
+    if ((rc = sampler_enqueue(c, s, nsteps, stretch_a, false, false, c->ev_timed))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     const auto t1 = std::chrono::steady_clock::now();
     *wall_s = std::chrono::duration<double>(t1 - t0).count();

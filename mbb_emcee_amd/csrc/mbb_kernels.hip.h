@@ -1305,7 +1305,10 @@ constexpr int kFmWords = 16;   // words per proposal / per row
 // (kFmSlots, kFmLag, kFmRing: mbb_flow_index.h)
 __host__ __device__ constexpr size_t flowm_words(size_t nw)
 {
-    return nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmSlots) + 2 * kFmRing * 16;
+    // (the completion counters begin on a 256-byte boundary: 250 atomic adds per half-step on a word that shared its
+    // 128-byte line with the last rows' decision words, which their partners poll, cost every second launch of a
+    // sampler 2 % -- profiles/r04/done_counters_alignment.txt)
+    return ((nw * ((size_t)kFmSlots * 2 * kFmWords + kFmSlots * kFmWords + kFmMseq) + 31) & ~(size_t)31) + 2 * kFmRing * 16;
 }
 static_assert(flowm_words(1000) <= spec_words(1000) && flowm_words(2) <= spec_words(2), "form 7 lives in the allocation of forms 5/6");
 __host__ __device__ __forceinline__ FlowMView flowm_view(double *spec, int nw)
@@ -1314,7 +1317,7 @@ __host__ __device__ __forceinline__ FlowMView flowm_view(double *spec, int nw)
     v.prop = spec;
     v.row = spec + (size_t)nw * kFmSlots * 2 * kFmWords;
     v.mseq = reinterpret_cast<unsigned long long *>(v.row + (size_t)nw * kFmSlots * kFmWords);
-    v.done = v.mseq + (size_t)nw * kFmSlots;
+    v.done = reinterpret_cast<unsigned long long *>(spec) + (flowm_words((size_t)nw) - 2 * kFmRing * 16);
     return v;
 }
 // SMODE 6: tells every rank that this rank's copy is set up for run `run` (which = 0) or that
