@@ -239,7 +239,7 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * "lookahead_rows" / "lookahead_waves" (the sharded one-launch run: 0 = the host's choice of candidates per wave and
  * waves per workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the
  * one-hop exchange is one launch per 4096 steps on every rank too; 0: one launch per half-step),
- * "flow_spin_log2" (0 = 22: log2 of the polls before a wait
+ * "flow_spin_log2" (0 = 22: log2 of the polls before a wait -- 63: no polls, the first miss, for tests --
  * inside the one-launch run gives up; mbb_sampler_run then redoes the run as a launch train and
  * counts it in mbb_get_info "flow_fallbacks"; the next run takes the one-launch form again, and only
  * three give-ups in a row rest it for the next 16 runs -- mbb_get_info "flow_resting" says how many of

@@ -23,12 +23,13 @@
 //      per lane with its check word; proposal, constructor, penalties; then the partner's decision of half-step
 //      j - 1 selects a row: its constants and proposal record go to LDS, its proposal to the run's state for the
 //      workgroups whose walkers will draw this one as partner in j + 1.
-//   Q  the others, numbered through: the (walker, unit) pairs of k_lnlike's phase 2; then Q wave q < W forms walker
-//      q's band sums and lnL, does the accept test and publishes: the decision word first, then the row (each element
-//      with its check word), chain entry, count; the owned rows stay in LDS.
-// Hand-over inside the workgroup is by counters in LDS (a wave's LDS operations execute in issue order): `ready`
-// (C waves through with the records of half-step j), `qdone` (Q waves through with its units), `edone` (walkers
-// decided).  Across workgroups: check words, decision words, and the lag guard (form 7's completion counters) --
+//   Q  the others, numbered through: the (walker, unit) pairs of k_lnlike's phase 2, a walker's as soon as its record is
+//      there; then Q wave q < W forms walker q's band sums and lnL, does the accept test and publishes: the decision word
+//      first, then the row (each element with its check word), chain entry, count; the owned rows stay in LDS.
+// Hand-over inside the workgroup is by words in LDS (a wave's LDS operations execute in issue order): `ready` (one per
+// walker: its record of half-step j is in LDS -- written the moment its partner's decision has selected the candidate),
+// `qdone` (Q waves through with the half-step's units), `edone` (walkers decided).  Across workgroups: check words,
+// decision words, and the lag guard (form 7's completion counters) --
 // a C wave enters half-step j only when every C wave of the grid is through with j - kFmLag, which keeps the four
 // slots of rows, proposals and decision words from being rewritten under a reader (tests/_flowa_model.py restates
 // the protocol on the host).  Every wait is bounded and watches the run's error flag.
@@ -43,7 +44,7 @@ constexpr int kFaRec = 10;      // doubles per proposal record besides WalkerK: 
 __host__ __device__ constexpr size_t flowa_lds(size_t nb, size_t npart, bool cov_in_lds, size_t W)
 {
     return kFaNB * W * (sizeof(WalkerK) + 8 * npart + 8 * kFaRec) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 192 + 64;
 }
 
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
@@ -69,8 +70,8 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     double *s_ivar = s_flux + nb; \
     double *s_invcov = s_ivar + nb; \
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
-    int *ctl = reinterpret_cast<int *>(s_band + nb + 1);                         /* ready[2], qdone[2], edone[2] */ \
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 16) - smem_raw) + 15) & ~(size_t)15; \
+    int *ctl = reinterpret_cast<int *>(s_band + nb + 1);                         /* edone[2] at 4; ready[kFaNB][8] at 16; qdone[kFaNB] at 32, 40 */ \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl + 48) - smem_raw) + 15) & ~(size_t)15; \
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
@@ -79,9 +80,9 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     const FlowMView fv = flowm_view(a.spec, a.nw); \
     const unsigned long long serial32 = a.flow_serial << 32; \
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \
-    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22); \
+    const long long spin_limit = flow_spin_limit(a.spec_cfg); \
     const int niter = a.persist; \
-    int *const c_ready = ctl, *const c_qdone = ctl + 2, *const c_edone = ctl + 4; \
+    int *const c_ready = ctl + 16, *const c_qdone = ctl + 32, *const c_edone = ctl + 4; \
     (void)nun; (void)nQ; (void)mflux; (void)own; (void)s_flux; (void)s_ivar; (void)s_invcov; (void)s_nu; (void)s_lnnu; (void)s_wt; \
     (void)Wl; (void)done_set; (void)spin_limit; (void)niter; (void)c_ready; (void)c_qdone; (void)c_edone; (void)partial0; (void)rec0
 
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
         MBB_ROLE_ARGS();
         MBB_FA_COMMON();
         const int nt = (int)blockDim.x;
-        if (tid < 16) ctl[tid] = 0;
+        if (tid < 48) ctl[tid] = 0;
         if (tid < 2 * W * 6) {
             const int hh = tid / (W * 6), l = (tid - hh * W * 6) / 6, e = tid % 6;
             if (l < Wl) {
@@ -127,6 +128,14 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
     }
     __syncthreads();
 
+    // diagnostic build: when things happened in the launch's last 64 half-steps, on the clock all CUs share (100 MHz):
+    // stamps[(workgroup * 64 + half-step mod 64) * 16 + event], tools/probe_chain_flowa.py
+#ifdef MBB_STAMPS
+#define FA_EV(jj, ev) do { if (lane == 0 && a.stamps && (jj) >= niter - 64) \
+        a.stamps[(((size_t)blockIdx.x * 64 + ((jj) & 63)) * 16 + (ev))] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FA_EV(jj, ev) do { } while (0)
+#endif
     const int W_u = ka->wpb;
     const int nC_u = (2 * W_u + 3) >> 2;
     const bool is_c = (wave & 3) == 3 && (wave >> 2) < nC_u;
@@ -146,60 +155,23 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
         auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
         auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
         const SampleTabs tabs = {s_tab, s_pb, s_pc};
-        const int nunit = Wl * nun;                       // (the last workgroup may own fewer walkers)
-        int4 us_first = make_int4(0, 0, 0, 0);
-        if (qi < nunit) us_first = a.unit_tab[qi % nun];
+        // The walkers are taken one by one, each as soon as its record is there (its partner's decision has come in), in
+        // whatever order that is; of walker l's units -- numbers l nun + i of the workgroup's list -- this wave has every
+        // nQ-th, as when the list was taken in one sweep behind one word: then the workgroup sat idle 2.4 us of a half-step's
+        // 10.5 at four walkers, waiting for the last of its four partners' decisions (tools/probe_chain_flowa.py; 21.0 -> 18.6 us
+        // per step at 2000 walkers, 17.3 -> 15.6 at 1500, 12.0 -> 11.3 at 1000).  The accept tests stay behind the whole sweep,
+        // on the first Wl waves: done walker by walker by whichever wave brought a walker's last unit in, the wave that was last
+        // once fell further behind with every test and took them all (23.2 at 2000 walkers); done by the waves with the least
+        // to do, as soon as a walker's units were in, 19.5 (profiles/r04/walker_sweep.txt).
         for (int it = 0; it < niter; ++it) {
             const int bj = it & (kFaNB - 1), h = it & 1;
             const WalkerK *wk = wk0 + bj * W;
             double *partial = partial0 + (size_t)bj * W * npart;
             const double *rec = rec0 + (size_t)bj * W * kFaRec;
-            lds_wait(c_ready + bj, nC * MBB_FA_TURN(it));
-            // (Round 4 tried two other deals of the (unit, walker) pairs, both to even out the chunks a WAVE carries --
-            // in table order, four walkers: 16 of 144 chunks at most on 14 waves, where 11 are possible.  From a counter in
-            // LDS, largest units first: 9.6 against 8.6 us per step at 512 walkers, 21.6 against 21.0 at 2000.  By size, there
-            // and back again over the waves (at most 12 chunks per wave): 8.95 / 26.1.  Both slower: the table's order
-            // balances the SIMDs, which is what the time follows, and keeps the waves of a pass on one walker.)
-            for (int u = qi; u < nunit; u += nQ) {
-                const int j = u / nun;
-                const int4 us = (u == qi) ? us_first : a.unit_tab[u - j * nun];
-                if (wk[j].status != ROW_OK) continue;             // wave-uniform
-                const WalkerK k = wk[j];
-                const int s = us.x, c0 = us.y, c1 = us.z;
-                double acc = 0.0;
-                int c = c0;
-                for (; c + 2 <= c1; c += 2) {                     // two chunks per step (k_lnlike, do_unit)
-                    const int i0 = c * 64 + lane, i1 = i0 + 64;
-                    const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
-                    const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-                    const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
-                    const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
-                    acc = fma(f0, q0, acc);
-                    acc = fma(f1, q1, acc);
-                }
-                if (c < c1) {
-                    const int i = c * 64 + lane;
-                    const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
-                    acc = fma(f, T_wt(i), acc);
-                }
-                if (us.w == 0) {
-                    acc = wave_sum(acc);
-                    if (lane == 0) partial[j * npart + s] = acc;
-                } else if (us.w == 2) {
-                    acc = row_sum(acc);
-                    if ((lane & 15) == 0) {
-                        const int sl = a.tail_slot[4 * s + (lane >> 4)];
-                        if (sl >= 0) partial[j * npart + sl] = acc;
-                    }
-                } else {
-                    partial[j * npart + s + lane] = acc;
-                }
-            }
-            MBB_FM_ORDER();
-            if (lane == 0) __hip_atomic_fetch_add(c_qdone + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // ---- walker qi's band sums, lnL and move (k_lnlike, phase 3, SAMPLER)
-            if (const int j = qi; j < Wl) {
-                lds_wait(c_qdone + bj, nQ * MBB_FA_TURN(it));
+            const int turn = MBB_FA_TURN(it);
+            if (qi == 0) FA_EV(it, 0);
+            // ---- a walker's band sums, lnL and move (k_lnlike, phase 3, SAMPLER): what other workgroups wait for
+            auto accept_test = [&](const int j) {
                 const int st = wk[j].status;
                 const int row = (h ? a.c_count : 0) + wbase + j;
                 const double *rj = rec + (size_t)j * kFaRec;
@@ -271,6 +243,86 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                 if (lane == 0 && accept) atomicAdd(a.nacc + (size_t)h * a.n + (wbase + j), 1u);
                 MBB_FM_ORDER();
                 if (lane == 0) __hip_atomic_fetch_add(c_edone + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            unsigned todo = (1u << Wl) - 1u;
+            int nth = 0;
+            while (todo) {
+                // the next walker whose record is there (a wave that waits here must not take issue slots from those of its
+                // SIMD that are still on a walker: lowest priority, and a longer nap between looks)
+                int j = -1;
+                {
+                    long long spins = 0;
+                    __builtin_amdgcn_s_setprio(0);
+                    for (;;) {
+                        unsigned t = todo;
+                        while (t) {
+                            const int b = __builtin_ctz(t);
+                            t &= t - 1;
+                            if (__hip_atomic_load(c_ready + bj * 8 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= turn) { j = b; break; }
+                        }
+                        if (j >= 0) break;
+                        ++spins;
+                        if (spins > spin_limit * 16 ||
+                            ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            atomicMax(a.errflag, 9);
+                            j = __builtin_ctz(todo);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    __builtin_amdgcn_s_setprio(1);
+                    MBB_FM_ORDER();
+                }
+                j = __builtin_amdgcn_readfirstlane(j);
+                todo &= ~(1u << j);
+                if (qi == 0 && nth == 0) FA_EV(it, 1);
+                for (int ui = ((qi - j * nun) % nQ + nQ) % nQ; ui < nun; ui += nQ) {
+                    const int4 us = a.unit_tab[ui];
+                    if (wk[j].status != ROW_OK) continue;             // wave-uniform
+                    const WalkerK k = wk[j];
+                    const int s = us.x, c0 = us.y, c1 = us.z;
+                    double acc = 0.0;
+                    int c = c0;
+                    for (; c + 2 <= c1; c += 2) {                     // two chunks per step (k_lnlike, do_unit)
+                        const int i0 = c * 64 + lane, i1 = i0 + 64;
+                        const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+                        const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
+                        const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                        const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                        acc = fma(f0, q0, acc);
+                        acc = fma(f1, q1, acc);
+                    }
+                    if (c < c1) {
+                        const int i = c * 64 + lane;
+                        const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
+                        acc = fma(f, T_wt(i), acc);
+                    }
+                    if (us.w == 0) {
+                        acc = wave_sum(acc);
+                        if (lane == 0) partial[j * npart + s] = acc;
+                    } else if (us.w == 2) {
+                        acc = row_sum(acc);
+                        if ((lane & 15) == 0) {
+                            const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                            if (sl >= 0) partial[j * npart + sl] = acc;
+                        }
+                    } else {
+                        partial[j * npart + s + lane] = acc;
+                    }
+                }
+                if (qi == 0 && nth == Wl - 1) FA_EV(it, 2);
+                ++nth;
+            }
+            MBB_FM_ORDER();
+            if (lane == 0) __hip_atomic_fetch_add(c_qdone + bj * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (qi < Wl) {
+                __builtin_amdgcn_s_setprio(0);
+                lds_wait(c_qdone + bj * 8, nQ * turn);
+                __builtin_amdgcn_s_setprio(2);
+                if (qi == 0) FA_EV(it, 3);
+                accept_test(qi);
+                if (qi == 0) FA_EV(it, 4);
+                __builtin_amdgcn_s_setprio(1);
             }
         }
         return;
@@ -313,6 +365,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             const bool want_e = active && l16 < 5, want_g = ci == 0 && lane == 5 && j >= kFmLag;
             const unsigned long long need_g = (unsigned long long)gridDim.x * (unsigned long long)nC * (unsigned long long)(((j - kFmLag) / kFmRing) + 1);
             const unsigned long long *gword = done_set + ((j - kFmLag) & (kFmRing - 1)) * 16;
+            if (ci == 0) FA_EV(j, 8);
             double pv = 0.0;
             {
                 bool ok = !(want_e || want_g);
@@ -330,6 +383,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            if (ci == 0) FA_EV(j, 9);
             WalkerK k;
             k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
             k.status = ROW_SKIP;
@@ -339,7 +393,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             // (2) the partner's decision of half-step j - 1 says which candidate was right: asked for once towards
             // the end of the constructor, polled for afterwards if it is not there yet
             const unsigned long long *w2 = fv.mseq + (size_t)prow * kFmMseq + (m1 % kFmSlots);
-            const bool watch2 = active && j > 0 && l16 == 0;
+            const bool watch2 = active && j > 0 && l16 == 0 && cand == 0;
             unsigned long long v2 = 0;
             if (active) {
                 const double *srow = own + (size_t)(h * W + l) * 8;
@@ -351,11 +405,41 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
 #include "mbb_walker_consts.inc"
 #undef MBB_WC_AFTER_PROLOGUE
             }
+            if (ci == 0) FA_EV(j, 10);
+            // (3) walker by walker, as the decisions come in: the row of the right candidate puts its constants and its
+            // proposal record into LDS and the proposal into the run's state, for the workgroups whose walkers draw this one
+            // as partner in half-step j + 1; then the walker's `ready` word -- the quadrature starts on it at once
             {
+                const int pbase = lane & 32;                      // first lane of the walker's two rows: the one that watches
+                bool handed = !(l < Wl);
                 long long spins = 0;
                 for (;;) {
-                    const bool ok = !watch2 || dec_ok(v2, (unsigned long long)j);
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                    const unsigned long long v2p = __shfl(v2, pbase);
+                    const bool ok = j == 0 || dec_ok(v2p, (unsigned long long)j);
+                    const bool now = !handed && ok;
+                    if (now) {
+                        const int sel = (j > 0 && (v2p & 1ull)) ? 1 : 0;
+                        if (cand == sel && l16 == 0) {
+                            WalkerK *wk = wk0 + bj * W;
+                            double *rj = rec0 + ((size_t)bj * W + l) * kFaRec;
+                            if (k.status == ROW_OK) wk[l] = k;
+                            else { wk[l].status = k.status; wk[l].pad = k.pad; }
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) rj[i] = p[i];
+                            rj[5] = 4.0 * lo[2];                  // (dim - 1) ln z, dim = 5
+                            rj[6] = lo[3];                        // ln u
+                            rj[7] = pen_u;
+                            rj[8] = pen_g;
+                            double *pr = fv.prop + (((size_t)row * kFmSlots + ((flow_cnt(h, j) + 1) % kFmSlots)) * 2) * kFmWords;
+                            const unsigned long long ptag = serial32 | (unsigned long long)(j + 1);
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) fm_put(pr + 2 * i, p[i], ptag);
+                        }
+                        handed = true;
+                    }
+                    MBB_FM_ORDER();                               // (the record's stores are issued before the word's)
+                    if (now && lane == pbase) __hip_atomic_store(c_ready + bj * 8 + l, MBB_FA_TURN(j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__builtin_amdgcn_ballot_w64(!handed) == 0) break;
                     ++spins;
                     if (spins > spin_limit ||
                         ((spins & 255) == 8 && __hip_atomic_load(a.errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -363,35 +447,17 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
-                    if (watch2 && !ok) v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (watch2 && !handed) v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            const int sel = (j > 0 && (__shfl(v2, base) & 1ull)) ? 1 : 0;
-            if (l < Wl && cand == sel && l16 == 0) {
-                WalkerK *wk = wk0 + bj * W;
-                double *rj = rec0 + ((size_t)bj * W + l) * kFaRec;
-                if (k.status == ROW_OK) wk[l] = k;
-                else { wk[l].status = k.status; wk[l].pad = k.pad; }
-#pragma unroll
-                for (int i = 0; i < 5; ++i) rj[i] = p[i];
-                rj[5] = 4.0 * lo[2];                              // (dim - 1) ln z, dim = 5
-                rj[6] = lo[3];                                    // ln u
-                rj[7] = pen_u;
-                rj[8] = pen_g;
-                // the proposal, for the workgroups whose walkers draw this one as partner in half-step j + 1
-                double *pr = fv.prop + (((size_t)row * kFmSlots + ((flow_cnt(h, j) + 1) % kFmSlots)) * 2) * kFmWords;
-                const unsigned long long ptag = serial32 | (unsigned long long)(j + 1);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) fm_put(pr + 2 * i, p[i], ptag);
-            }
+            if (ci == 0) FA_EV(j, 11);
             MBB_FM_ORDER();
-            if (lane == 0) {
-                __hip_atomic_fetch_add(c_ready + bj, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // this wave has read what it needs of half-step j - 1's rows, proposals and decisions: the lag guard
-                __hip_atomic_fetch_add(done_set + (j & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (ci == 0) FA_EV(j, 12);
+            // this wave has read what it needs of half-step j - 1's rows, proposals and decisions: the lag guard
+            if (lane == 0) __hip_atomic_fetch_add(done_set + (j & (kFmRing - 1)) * 16, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #undef MBB_FA_COMMON
 #undef MBB_FA_TURN
+#undef FA_EV
 }

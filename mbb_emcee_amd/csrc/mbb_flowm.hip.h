@@ -52,6 +52,15 @@
 #pragma once
 #include "mbb_kernels.hip.h"
 
+// polls a wait of a one-launch run may make before it gives up: 2^v for option "flow_spin_log2" = v in 1..62, 2^22 for 0,
+// and none for 63 -- the first word that is not there ends the run (the give-up tests: whether a budget of two polls is
+// ever exceeded depends on the timing of the day)
+__device__ __forceinline__ long long flow_spin_limit(int spec_cfg)
+{
+    const int v = (spec_cfg >> 24) & 0x3f;
+    return v == 63 ? 0ll : 1ll << (v ? v : 22);
+}
+
 // LDS control words (ints) of a k_flowm workgroup
 // (kFmNC C waves, kFmNB hand-over records in LDS: mbb_flow_index.h)
 constexpr int kFmReady = 0;    // [kFmNB] half-step + 1 of the record last handed to Q through buffer b
@@ -112,7 +121,7 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
-    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22); \
+    const long long spin_limit = flow_spin_limit(a.spec_cfg); \
     const FlowMView fv = flowm_view(a.spec, a.nw); \
     const unsigned long long serial32 = a.flow_serial << 32; \
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16; \

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(1024) k_flowr(const LikeArgs a)
     const FlowMView fv = flowm_view(a.spec, a.nw);
     const unsigned long long serial32 = a.flow_serial << 32;
     unsigned long long *const done_set = fv.done + (size_t)(a.spec_cfg & 1) * kFmRing * 16;
-    const long long spin_limit = 1ll << (((a.spec_cfg >> 24) & 0x3f) ? ((a.spec_cfg >> 24) & 0x3f) : 22);
+    const long long spin_limit = flow_spin_limit(a.spec_cfg);
     const int niter = a.persist;
 
     // ---- set-up, once per launch: tables and data to LDS; the owned rows as the sampler holds them into LDS

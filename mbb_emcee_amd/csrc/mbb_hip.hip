@@ -74,7 +74,7 @@ MBB_FLOWA_EXT(true, true)
 static size_t flowa_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowa_lds() of mbb_flowa.hip.h
 {
     return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 10) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64 + 64;
+           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 192 + 64;
 }
 // ... and k_serve, the likelihood of given rows as a kernel that stays resident between boundary calls (mbb_serve.hip.h)
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
@@ -1513,9 +1513,10 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     //   form 7 (k_flowm): a workgroup per (pair of walkers, candidate), quadrature and constructor ahead of the decisions
     //           they depend on -- while each has a CU of its own: 6.0-6.3 up to 256 walkers;
     //   form 9 (k_flowa): a workgroup owns W = ceil(half / CUs) walkers of each half, the constructor a half-step ahead
-    //           for both outcomes of the partner's pending move -- 8.2-8.6 from 258 to 512 walkers (round 3's forms there,
-    //           removed this round: form 5 9.6-10.2 up to 340, form 7 with two pairs per workgroup 11.5 up to 512),
-    //           11.8-12.0 up to 1000, 17.3 at 1500, 21.0 at 2000 (train: 18.9 / 19.1 / 22.4 / 25.9);
+    //           for both outcomes of the partner's pending move, a walker's quadrature starting when ITS partner has decided
+    //           -- 8.4-8.9 from 258 to 512 walkers (round 3's forms there, removed this round: form 5 9.6-10.2 up to 340,
+    //           form 7 with two pairs per workgroup 11.5 up to 512), 10.7-11.3 up to 1000, 15.6 at 1500, 18.6 at 2000
+    //           (train: 18.9 / 19.1 / 22.4 / 26.0);
     //   form 8 (k_flowr): the same ownership, nothing ahead -- from five walkers per CU and half on, where the constructor
     //           waves of form 9 cost the quadrature more than running ahead gains: 29.3 at 3000, 35.5 at 4096 (32.0 / 37.9).
     bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&

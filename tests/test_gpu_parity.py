@@ -1783,7 +1783,7 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
 
 
 def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, g_lnl):
-    """A one-launch run whose waits give up (here: a poll budget of two; in the field: a workgroup
+    """A one-launch run whose waits give up (here: no poll budget, the first word that is not there; in the field: a workgroup
     that is not resident because another process holds CUs) ends with an error flag, not a hang;
     mbb_sampler_run then restores the state the run started from and does the same steps as a train
     of launches -- the caller gets the chain it would have got, with a warning.  A give-up is a
@@ -1801,7 +1801,7 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         s1 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)
         first = s1.run_mcmc(p0, 6)[:2]
         assert ctx.info("last_kernel_form") == form and ctx.info("flow_fallbacks") == 0
-        ctx.set_option("flow_spin_log2", 1)                       # the second run gives up at once ...
+        ctx.set_option("flow_spin_log2", 63)                      # the second run gives up at once ...
         with pytest.warns(RuntimeWarning, match="redone as a train"):
             second = s1.run_mcmc(None, 5)[:2]
         assert ctx.info("flow_fallbacks") == 1 and ctx.info("last_kernel_form") == 1      # ... and was redone
@@ -1822,13 +1822,13 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         c0 = ref_run(4)
         assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         # three give-ups in a row: the form rests (16 runs on the train, no give-ups), then comes back
-        ctx.set_option("flow_spin_log2", 1)
+        ctx.set_option("flow_spin_log2", 63)
         for k in range(3):
             with pytest.warns(RuntimeWarning):
                 c1 = s1.run_mcmc(None, 2)[:2]
             ctx.set_option("flow_spin_log2", 0)
             c0 = ref_run(2)                                       # (a train: neither a give-up nor a rest)
-            ctx.set_option("flow_spin_log2", 1)
+            ctx.set_option("flow_spin_log2", 63)
             assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         assert ctx.info("flow_fallbacks") == 4 and ctx.info("flow_resting") > 0
         while ctx.info("flow_resting") > 0:
@@ -1843,7 +1843,7 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
         assert np.array_equal(c0[0], c1[0]) and np.array_equal(c0[1], c1[1])
         # an asynchronous advance keeps nothing to redo a run from: the give-up surfaces at the next
         # synchronous call as an error, and the sampler wants its state set again
-        ctx.set_option("flow_spin_log2", 1)
+        ctx.set_option("flow_spin_log2", 63)
         s1.advance_async(5); ctx.sync()
         ctx.set_option("flow_spin_log2", 0)
         nfall = ctx.info("flow_fallbacks")
