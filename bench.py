@@ -969,15 +969,21 @@ def worker_body(args, rank, world, local_rank, base, fail):
                 # stream for the same 20 steps) -- a scratch ensemble is stepped for 50 ms first, said on the line.
                 scratch = mbb.DeviceEnsembleSampler(nwt, 5, like, seed=12)
                 scratch.run_mcmc(allw[:nwt], 2, storechain=False)
+                ran = [60, 2]                                     # steps of every sampler run so far (rehearsal first)
                 t_end = time.perf_counter() + PRECONDITION_S
+                pre = min(4096, max(200, steps))                  # (launches as long as the timed one: see PRECONDITION_S)
                 while time.perf_counter() < t_end:
-                    scratch.advance_timed(200)
+                    scratch.advance_timed(pre)
+                    ran.append(pre)
                 smp.advance_timed(warmup)
                 first = smp.advance_timed(steps)
                 # (the line's value is that ONE region; eight more of the same right behind it, reported beside it,
                 # say how far the single shot is from the typical one)
                 state["again"] = [smp.advance_timed(steps) for _ in range(8)]
                 del scratch
+                # (for the profile summaries: which of the sampler kernel's launches was the timed one, and how many
+                # half-steps they cover together -- runs of fewer than two steps are not launches of that kernel)
+                state["runs"] = {"steps_of_every_run": ran + [warmup, steps] + [steps] * 8, "timed_run": len(ran) + 1}
                 return first
             smp.advance_async(warmup)
             ctx.sync(); barrier()
@@ -1016,7 +1022,8 @@ def worker_body(args, rank, world, local_rank, base, fail):
                                             if fine else (state["err"] or "non-finite state"))
             teardown()
             return res
-        res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, again=state.get("again"), form=ctx.info("last_kernel_form"),
+        res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, again=state.get("again"), runs=state.get("runs"),
+                   form=ctx.info("last_kernel_form"),
                    us_per_step=1e6 * elapsed / steps,
                    # which instantiation that was (form 7: last_wpb = pairs of walkers per workgroup)
                    pairs=ctx.info("last_wpb"), staged=bool(ctx.info("last_stage")))
@@ -1063,6 +1070,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
                                                  "stream": [round(m * 1e3, 2) for _, m in run["again"]],
                                                  "note": "eight more timed regions of the same K steps right behind the reported one"}}
                        if run.get("again") else {}),
+                    **({"sampler_runs": run["runs"]} if run.get("runs") else {}),
                     # (sharded: the counts of this rank's own walkers)
                     "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps * (1 + len(run.get("again") or []))),
                     "ranks_agree": True})

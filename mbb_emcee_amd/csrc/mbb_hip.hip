@@ -1517,8 +1517,8 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     //           -- 8.4-8.9 from 258 to 512 walkers (round 3's forms there, removed this round: form 5 9.6-10.2 up to 340,
     //           form 7 with two pairs per workgroup 11.5 up to 512), 10.7-11.3 up to 1000, 15.6 at 1500, 18.6 at 2000
     //           (train: 18.9 / 19.1 / 22.4 / 26.0);
-    //   form 8 (k_flowr): the same ownership, nothing ahead -- from five walkers per CU and half on, where the constructor
-    //           waves of form 9 cost the quadrature more than running ahead gains: 29.3 at 3000, 35.5 at 4096 (32.0 / 37.9).
+    //   form 8 (k_flowr): the same ownership, nothing ahead -- from seven walkers per CU and half on, where the constructor
+    //           waves of form 9 cost the quadrature more than running ahead gains: 32.1 at 3584, 35.5 at 4096 (train 37.9).
     bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&
                       nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps);
     const bool merged = one_launch && c->opt_flowm && c->opt_flowr != 2 && 2 * (int)nl <= c->cu_count && wpb_1 == 1;
@@ -1526,8 +1526,9 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                                          : ((int)nl + c->cu_count - 1) / c->cu_count;
     const bool res_fits = res_w >= 1 && res_w <= kFrMaxWHost && ((int)nl + res_w - 1) / res_w <= c->cu_count;
     const bool resident = one_launch && !merged && c->opt_flowr != 0 && res_fits;
-    // (the constructor ahead up to four walkers per CU and half; option "resident_ahead": 0 never, 2 always)
-    const bool res_ahead = c->opt_flowr_ahead == 2 || (c->opt_flowr_ahead == 1 && res_w <= 4);
+    // (the constructor ahead up to six walkers per CU and half -- 2560 / 3000 walkers: 23.8 / 26.8 us per step against form 8's
+    // 27.3 / 29.6; at seven 32.4 against 32.1 --; option "resident_ahead": 0 never, 2 always)
+    const bool res_ahead = c->opt_flowr_ahead == 2 || (c->opt_flowr_ahead == 1 && res_w <= 6);
     one_launch = merged || resident;
     if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
     if (one_launch) {

@@ -1735,12 +1735,12 @@ def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
 
 def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
     """mbb_sampler_advance_timed (bench.py's timed region on one GPU) enqueues exactly what advance_async does --
-    the same chain afterwards, whatever form the run takes (form 7; form 9 with one, two and four walkers of each half
+    the same chain afterwards, whatever form the run takes (form 7; form 9 with one, two, four and six walkers of each half
     per workgroup; form 8 beyond; the launch train for an ensemble too large for any) -- and returns a wall time that
     covers the stream time."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
-    for nw, form in ((60, 7), (300, 9), (600, 9), (2000, 9), (2600, 8), (4200, 1)):
+    for nw, form in ((60, 7), (300, 9), (600, 9), (2000, 9), (2600, 9), (3600, 8), (4200, 1)):
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
         a = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
         b = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
@@ -1761,8 +1761,8 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
     cus = ctx.info("cu_count")
-    for nw, opts, form in ((cus, {}, 7), (cus + 2, {}, 9), (cus + 2, {"resident_sampler": 0}, 1), (8 * cus, {}, 9),
-                           (8 * cus + 2, {}, 8), (16 * cus, {}, 8), (16 * cus + 2, {}, 1), (cus, {"merged_flow_sampler": 0}, 9),
+    for nw, opts, form in ((cus, {}, 7), (cus + 2, {}, 9), (cus + 2, {"resident_sampler": 0}, 1), (12 * cus, {}, 9),
+                           (12 * cus + 2, {}, 8), (16 * cus, {}, 8), (16 * cus + 2, {}, 1), (cus, {"merged_flow_sampler": 0}, 9),
                            (60, {"resident_sampler": 2, "resident_walkers": 9}, 8)):
         for o in ("merged_flow_sampler", "resident_sampler"):
             ctx.set_option(o, 1)

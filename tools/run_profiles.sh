@@ -13,7 +13,7 @@ export TMPDIR=/tmp
 cd $R
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SHORT="--steps 300 --warmup 50 --no-extras"
-HS=$((2 * (60 + 50 + 300)))      # half-steps of the sampler in such a run: rehearsal 60 steps, warm-up, timed
+# (how many half-steps the sampler kernel covers in such a run: bench.py says on its line, the summaries read the logs)
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"
 # kernel trace + stats of the timed region alone (default K and W): the dominant kernel's three launches
@@ -29,8 +29,8 @@ timeout -k 10 400 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O
 # the same chain as a train of plain launches: the algorithmic work of a half-step (nothing computed twice)
 MBB_BENCH_PLAIN_TRAIN=1 timeout -k 10 300 rocprofv3 --pmc $VALU --kernel-trace --output-format csv -d $O/pmc_valu_plain -- python3 bench.py $SHORT > $O/valu_plain.log 2>&1 || exit 7
 echo "valu done"
-python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $HS > /dev/null
-python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "" $HS > /dev/null
+python3 tools/summarize_pmc.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/fetch.log,$O/write.log > /dev/null
+python3 tools/summarize_valu.py $O/pmc_valu_cfg2 $O/pmc_valu_cfg2.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "" $O/valu_cfg2.log > /dev/null
 python3 tools/summarize_valu.py $O/pmc_valu_plain $O/pmc_valu_plain.json "MBB_BENCH_PLAIN_TRAIN=1 rocprofv3 --pmc $VALU --kernel-trace -- python3 bench.py $SHORT" "the sampler as one plain launch per half-step" > /dev/null
 python3 tools/summarize_valu.py $O/pmc_valu $O/pmc_valu_cfg5.json "rocprofv3 --pmc $VALU --kernel-trace -- python3 tools/bench_cfg5.py --quick" > /dev/null
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv

@@ -2,8 +2,10 @@
 """Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs (two
 separate passes, MI355X_MICROARCH.md 'rocprofv3 PMC slots') into a small JSON
 summary under profiles/.  Values are KB per dispatch as rocprofv3 reports them."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _half_steps import half_steps as _hs
 
 def per_kernel(path, counter):
     out = {}
@@ -26,11 +28,13 @@ def main(fetch_dir, write_dir, out, half_steps="0"):
         if "lnlike" in k or "k_flow" in k:
             res["kernels"][k] = {"FETCH_SIZE": f[k], "WRITE_SIZE": w.get(k),
                                  "traffic_bytes_per_launch": 1024.0 * (f[k]["median_KB"] + (w[k]["median_KB"] if k in w else 0.0))}
-            if any(n in k for n in ("k_flowm", "k_flowa", "k_flowr")) and int(half_steps) > 0:
+            # half_steps: a number, or "<log of the FETCH pass>,<log of the WRITE pass>" (the passes are separate runs)
+            hs = [_hs(x) for x in (str(half_steps).split(",") * 2)[:2]]
+            if any(n in k for n in ("k_flowm", "k_flowa", "k_flowr")) and min(hs) > 0:
                 # the one-launch sampler kernel: its launches cover different numbers of half-steps
-                res["kernels"][k]["half_steps_in_all_launches"] = int(half_steps)
+                res["kernels"][k]["half_steps_in_all_launches"] = {"fetch_pass": hs[0], "write_pass": hs[1]}
                 res["kernels"][k]["traffic_bytes_per_half_step"] = \
-                    1024.0 * (f[k]["sum_KB"] + (w[k]["sum_KB"] if k in w else 0.0)) / int(half_steps)
+                    1024.0 * (f[k]["sum_KB"] / hs[0] + (w[k]["sum_KB"] / hs[1] if k in w else 0.0))
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -20,7 +20,11 @@ def main(run_dir, bench_json, out):
     trace = glob.glob(run_dir + "/*/*_kernel_trace.csv")[0]
     rows = [r for r in csv.DictReader(open(trace)) if any(n in r["Kernel_Name"] for n in ("k_flowm<", "k_flowa<", "k_flowr<"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    covered = [60, warm, steps]                       # bench.py: rehearsal, warm-up, timed region (steps)
+    # bench.py says which sampler runs it made (rehearsal, the scratch ensemble that preconditions the GPU, warm-up, the
+    # timed region, eight more of it); runs of fewer than two steps are launch trains, not launches of this kernel
+    runs = line.get("sampler_runs") or {"steps_of_every_run": [60, warm, steps], "timed_run": 2}
+    covered = [st for st in runs["steps_of_every_run"] if st >= 2]
+    timed = sum(1 for st in runs["steps_of_every_run"][:runs["timed_run"]] if st >= 2)
     launches = []
     for r, st in zip(rows, covered):
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
@@ -30,7 +34,8 @@ def main(run_dir, bench_json, out):
                          "scratch_bytes": int(r["Scratch_Size"])})
     res = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-extras --steps %d --warmup %d" % (steps, warm),
            "launches_of_the_dominant_kernel": launches, "launches_seen": len(rows),
-           "timed_launch_us_per_half_step_rocprof": launches[-1]["us_per_half_step"] if len(launches) == 3 else None,
+           "timed_launch": timed,
+           "timed_launch_us_per_half_step_rocprof": launches[timed]["us_per_half_step"] if len(launches) == len(covered) == len(rows) else None,
            "half_step_us_hip_events_same_run": line.get("half_step_us"),
            "value_same_run": line.get("value")}
     json.dump(res, open(out, "w"), indent=1)

@@ -5,12 +5,14 @@ medians per launch for every k_lnlike / k_flowm instantiation in the run, larges
 
     python tools/summarize_valu.py <rocprof output dir> <out.json> "<command that was profiled>" [note] [half_steps]
 
-half_steps: for the one-launch sampler kernels (k_lnlike<.., 5, ..>, k_flowm<..>), whose launches cover different
+half_steps (a number, or the log of the profiled bench.py run): for the one-launch sampler kernels (k_lnlike<.., 5, ..>, k_flowm<..>), whose launches cover different
 numbers of half-steps, the number of half-steps all its launches in the run add up to; the
 summary then also carries the counters summed over the launches and per half-step.
 """
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _half_steps import half_steps as _hs
 
 
 def main(run_dir, out, command="", note="", half_steps="0"):
@@ -30,10 +32,10 @@ def main(run_dir, out, command="", note="", half_steps="0"):
         fma, add, mul = (c.get("SQ_INSTS_VALU_" + x, 0.0) for x in ("FMA_F64", "ADD_F64", "MUL_F64"))
         f64 = fma + add + mul + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
         extra = {}
-        if any(n in k for n in ("k_flowm<", "k_flowa<", "k_flowr<")) and int(half_steps) > 0:
+        if any(n in k for n in ("k_flowm<", "k_flowa<", "k_flowr<")) and _hs(half_steps) > 0:
             tot = {cn: float(np.sum(v)) for cn, v in grids[g].items()}
-            extra = {"half_steps_in_all_launches": int(half_steps), "counters_all_launches": tot,
-                     "counters_per_half_step": {cn: v / int(half_steps) for cn, v in tot.items()}}
+            extra = {"half_steps_in_all_launches": _hs(half_steps), "counters_all_launches": tot,
+                     "counters_per_half_step": {cn: v / _hs(half_steps) for cn, v in tot.items()}}
         res["kernels"][k] = {
             "grid_threads": g, "dispatches": len(next(iter(grids[g].values()))),
             "counters_per_launch": c, "fp64_wave_instructions": f64,
