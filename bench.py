@@ -71,6 +71,7 @@ ONE_LAUNCH_FORMS = (7, 8, 9)   # sampler forms whose launches cover many half-st
 # set-up, a rehearsal, a timed run), and the age of the run beyond which nothing optional is started any more
 SUPERVISOR_DEADLINE_S, GUARD_S, OPTIONAL_UNTIL_S = 480.0, 45.0, 240.0
 PRECONDITION_S = 0.05      # one GPU: a scratch ensemble is stepped this long right before the W warm-up steps (GPU clocks)
+PRECONDITION_STEPS = 2000  # N > 1: that many untimed steps of the sharded sampler itself instead
 CLOCK_HZ = 2.4e9
 # tools/issue_cost.hip, profiles/r02/issue_cost_v1.txt: cycles one wave64 VALU
 # instruction holds its SIMD, four waves per SIMD
@@ -985,6 +986,11 @@ def worker_body(args, rank, world, local_rank, base, fail):
                 # half-steps they cover together -- runs of fewer than two steps are not launches of that kernel)
                 state["runs"] = {"steps_of_every_run": ran + [warmup, steps] + [steps] * 8, "timed_run": len(ran) + 1}
                 return first
+            # (N > 1: the same sharded sampler, PRECONDITION_STEPS untimed steps further first -- the GPUs as a long run leaves
+            # them, as at N = 1; a fixed count, the ranks must agree on it)
+            smp.advance_async(PRECONDITION_STEPS)
+            ctx.sync(); barrier()
+            state["pre_steps"] = PRECONDITION_STEPS
             smp.advance_async(warmup)
             ctx.sync(); barrier()
             e0, e1 = ctx.event(), ctx.event()
@@ -1023,6 +1029,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
             teardown()
             return res
         res.update(ok=True, elapsed=elapsed, stream_ms=stream_ms, again=state.get("again"), runs=state.get("runs"),
+                   pre_steps=state.get("pre_steps", 0),
                    form=ctx.info("last_kernel_form"),
                    us_per_step=1e6 * elapsed / steps,
                    # which instantiation that was (form 7: last_wpb = pairs of walkers per workgroup)
@@ -1072,11 +1079,14 @@ def worker_body(args, rank, world, local_rank, base, fail):
                        if run.get("again") else {}),
                     **({"sampler_runs": run["runs"]} if run.get("runs") else {}),
                     # (sharded: the counts of this rank's own walkers)
-                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + args.warmup + args.steps * (1 + len(run.get("again") or []))),
+                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + run.get("pre_steps", 0) + args.warmup + args.steps * (1 + len(run.get("again") or []))),
                     "ranks_agree": True})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = run["form"]
         out["config"] = dict(out["config"])
+        if world > 1:
+            out["config"]["preconditioning"] = ("%d untimed steps of the same sharded sampler before the W warm-up steps: the GPUs' "
+                                                "clocks" % run.get("pre_steps", 0))
         if world == 1:
             out["config"]["preconditioning"] = ("%.0f ms of sampler steps on a scratch ensemble right before the W warm-up steps: "
                                                 "the GPU's clocks, not the chain that is timed" % (PRECONDITION_S * 1e3))
