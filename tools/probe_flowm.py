@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sampler form 7 (k_flowm: quadrature of both candidates ahead) against the plain launch train and form 5:
+"""Sampler form 7 (k_flowm: quadrature of both candidates ahead) against the plain launch train and form 9:
 bitwise equality of a short run, then stream time per step.  MBB_PROBE_SPIN: log2 of the polls before a wait gives up."""
 import os, sys, time
 import numpy as np

@@ -8,7 +8,7 @@ import mbb_emcee_amd as mbb
 from bench import make_likelihood, TRUTH
 
 nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-# (further arguments: ensemble sizes; beyond 256 walkers form 7 serves two pairs of walkers per workgroup)
+# (further arguments: ensemble sizes; form 7 ends at 256 walkers, beyond it the option is ignored and form 9 runs)
 sizes = [int(a) for a in sys.argv[2:]] or [256, 254, 130, 64, 18, -250]
 for nw in sizes:
     like, flux = make_likelihood(0)
