@@ -245,6 +245,7 @@ struct mbb_ctx {
     long last_stage = 0;
     long opt_lookahead = 1;   // single-GPU sampler runs prepare the next half-step's proposals ahead of the decisions they depend on
     unsigned long long flow_serial = 0;   // one-launch sampler runs started on this context
+    long opt_serve_overlap = 1;    // the served kernel starts a row's quadrature beside its constructor (0: one after the other)
     long opt_flow_spin_log2 = 0;   // one-launch run: log2 of the polls before a wait gives up (0: the kernel's 22)
     hipEvent_t ev_timed[2] = {nullptr, nullptr};   // mbb_sampler_advance_timed
     long flow_fallbacks = 0;       // one-launch runs that timed out and were redone as a launch train
@@ -1124,7 +1125,11 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     a.cov_in_lds = (c->has_cov && serve_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
     const size_t sm = serve_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
     const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
-    const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
+    // (the quadrature beside the constructor: a buffer of one value per sample behind the tables, when there is room)
+    const size_t fbuf_bytes = (size_t)c->nchunk * 64 * sizeof(double);
+    const bool ovl = c->opt_serve_overlap != 0 && sm + (stg ? table_bytes + 16 : 0) + fbuf_bytes <= dyn_limit;
+    a.spec_cfg = ovl ? 1 : 0;
+    const size_t sm_total = sm + (stg ? table_bytes + 16 : 0) + (ovl ? fbuf_bytes : 0);
     if (sm_total > dyn_limit) return 1;
     HIPCHK(hipHostGetDevicePointer((void **)&a.chain6, c->h_gone, 0));
     a.pos6 = reinterpret_cast<double *>(c->w_door);
@@ -2104,6 +2109,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "pack_tails")) c->opt_pack_tails = value;
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
+    else if (!strcmp(name, "serve_overlap")) c->opt_serve_overlap = value;
     else if (!strcmp(name, "serve")) { c->opt_serve = value; c->srv_strikes = 0; }
     else if (!strcmp(name, "serve_after")) c->opt_serve_after = value < 1 ? 1 : value;
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;

@@ -14,6 +14,14 @@
 //           -> workgroup b < n evaluates row b exactly as k_lnlike does (same constructor text, same units in the same
 //           order, same order of the band sums: bitwise the launch's results) and writes lnl / status into the pinned
 //           result slots, which the host sees turn.
+// A row's evaluation is not the launch's three phases one after the other (constructor, quadrature, band sums: 2.5 + 2 + 0.5
+// us): what the quadrature needs of the constructor for every sample on the blackbody side of the merge point -- h/kT, its
+// log, beta, log x0 -- is a division and two logs away from the parameters, and what takes the constructor its time, the
+// merge point itself (a root), only says WHICH samples are on the other side.  So once those few scalars are in LDS, twelve
+// waves work out the blackbody-side value of every sample into a buffer while the first wave's row of 16 lanes finishes the
+// constructor; then the units are summed as ever -- sample by sample in the same order, each either the buffered value or,
+// beyond the merge point, the power law's -- so that every partial sum is bit for bit the launch's (spec_cfg bit 0; the
+// buffer is 512 bytes per chunk of LDS, and without room for it the phases run one after the other as in k_lnlike).
 // The kernel leaves when told to (the doorbell says QUIT: any other use of the context, its destruction) or when
 // workgroup 0 has seen no request for `idle` polls (~1 us each; it then writes QUIT itself so that every workgroup
 // follows); every workgroup besides has a safety limit of its own (four times that).  Whatever goes wrong -- a request
@@ -57,6 +65,9 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const unsigned long long *door = reinterpret_cast<const unsigned long long *>(a.pos6);
+    const bool overlap = (a.spec_cfg & 1) != 0;                           // the quadrature starts beside the constructor
+    double *fbuf = s_wt + (STAGE ? a.nchunk * 64 : 0);                    // [nchunk * 64] with `overlap`: a sample's blackbody-side value
+    __shared__ WalkerK kfin;
 
     // ---- once: the tables and the data to LDS
     {
@@ -95,42 +106,102 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
         const int n = (int)(cur & 0xffffull);
         const int w = (int)blockIdx.x;
         if (w < n) {
-            // ---- phase 1 (k_lnlike's, SMODE 0): gate, constructor, parameter-only penalties on one row of 16 lanes
+            // ---- phase 1 (k_lnlike's, SMODE 0): gate, constructor, parameter-only penalties on one row of 16 lanes --
+            // in two parts when the quadrature may start on the first
+            bool mine = false;
+            double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, lT = 0.0, lL = 0.0;
             if (tid < 16) {
+                mine = true;
+                // the row's five values in ONE request (lane i takes element i; the block is fine-grained memory the
+                // host has just written through the BAR: not cached, every request goes to memory -- five requests
+                // per workgroup, one per element with all lanes on the same address, cost 125 rows 8 us)
+                const double pe = tid < 5 ? __hip_atomic_load(a.pars + (size_t)w * 5 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) p[i] = __shfl(pe, i);
+                if (OPTHIN) {
+                    double lo[1];
+                    vlog<true>(lo, p[0]);
+                    lT = lo[0];
+                } else {
+                    double lo[2];
+                    vlog<true>(lo, p[0], p[2]);
+                    lT = lo[0]; lL = lo[1];
+                }
+                if (overlap && tid == 0) {
+                    // what a blackbody-side sample needs, exactly as sed_prologue / make_walker_k form it (the constructor
+                    // below forms them again; the record is replaced by its own behind the barrier)
+                    bool ok = true;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
+                    ok = ok && finite5(p) && !(!NOALPHA && p[3] <= 0.0) && !(p[1] < 0.0);
+                    WalkerK k0;
+                    k0.hokt9 = m_div(1e9 * kH / kK, p[0]);
+                    k0.lhokt9 = kLog1e9HoK - lT;
+                    k0.beta = p[1]; k0.bp3 = p[1] + 3.0; k0.bp2 = p[1] + 2.0;
+                    k0.alpha = NOALPHA ? 0.0 : p[3];
+                    k0.lx0 = OPTHIN ? 0.0 : k0.lhokt9 + kLogUmToGHz - lL;
+                    k0.xmerge = __builtin_inf();
+                    k0.cbb = k0.cpl = k0.kap = k0.peak = 0.0;
+                    k0.status = ok ? ROW_OK : ROW_SKIP;
+                    k0.pad = 0;
+                    wk[0] = k0;
+                }
+            }
+            if (overlap) __syncthreads();
+            const bool ahead = overlap && wk[0].status == ROW_OK;           // workgroup-uniform
+            // (the constructor is one dependent chain and runs fastest on a SIMD it has to itself: with sixteen waves its
+            // SIMD's other three -- waves 4, 8, 12 -- sit this part out)
+            const bool spare_simd = nwave == 16;
+            const int nqw = spare_simd ? 12 : nwave - 1, qw = spare_simd ? wave - 1 - (wave >> 2) : wave - 1;
+            if (ahead && wave > 0 && !(spare_simd && (wave & 3) == 0)) {
+                // ---- the blackbody-side value of every sample, two chunks per step, on waves that have no constructor
+                const WalkerK k = wk[0];
+                const int nc = a.nchunk, stride = 2 * nqw;
+                for (int c = 2 * qw; c < nc; c += stride) {
+                    const int i0 = c * 64 + lane, i1 = i0 + 64;
+                    const bool two = c + 1 < nc;
+                    const double n0 = T_nu(i0), l0 = T_ln(i0);
+                    const double n1 = two ? T_nu(i1) : 1.0, l1 = two ? T_ln(i1) : 0.0;
+                    const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                    const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                    fbuf[i0] = f0;
+                    if (two) fbuf[i1] = f1;
+                }
+            }
+            if (mine) {
+                if (ahead) __builtin_amdgcn_s_setprio(3);
                 WalkerK k;
                 k.status = ROW_SKIP;
                 k.pad = 0;
                 double pen_u = 0.0, pen_g = 0.0;
                 {
-                    double p[5], lT, lL = 0.0;
-                    // the row's five values in ONE request (lane i takes element i; the block is fine-grained memory the
-                    // host has just written through the BAR: not cached, every request goes to memory -- five requests
-                    // per workgroup, one per element with all lanes on the same address, cost 125 rows 8 us)
-                    const double pe = tid < 5 ? __hip_atomic_load(a.pars + (size_t)w * 5 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) p[i] = __shfl(pe, i);
-                    if (OPTHIN) {
-                        double lo[1];
-                        vlog<true>(lo, p[0]);
-                        lT = lo[0];
-                    } else {
-                        double lo[2];
-                        vlog<true>(lo, p[0], p[2]);
-                        lT = lo[0]; lL = lo[1];
-                    }
 #include "mbb_walker_consts.inc"
                 }
+                // (with the quadrature ahead its waves are reading the record: it is replaced behind the barrier)
                 if (tid == 0) {
-                    if (k.status == ROW_OK) wk[0] = k;
-                    else { wk[0].status = k.status; wk[0].pad = k.pad; }
+                    kfin = k;
                     pen[0] = pen_u;
                     pen[1] = pen_g;
                 }
+                if (ahead) __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if (kfin.status == ROW_OK) wk[0] = kfin;
+                else { wk[0].status = kfin.status; wk[0].pad = kfin.pad; }
             }
             __syncthreads();
             // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
             if (wk[0].status == ROW_OK) {
                 const WalkerK k = wk[0];
+                // a sample's value: the buffered one, or the power law's beyond the merge point -- as fnu_sample decides
+                auto value = [&](int i, double nu, double lnnu) {
+                    if (!ahead) return fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs);
+                    if constexpr (!NOALPHA) {
+                        if (k.hokt9 * nu > k.xmerge) return fnu_wien_tab(k, k.lhokt9 + lnnu, &tabs);
+                    }
+                    return fbuf[i];
+                };
                 for (int u = wave; u < nun; u += nwave) {
                     const int4 us = (u == wave) ? us_first : a.unit_tab[u];
                     const int s = us.x, c0 = us.y, c1 = us.z;
@@ -140,14 +211,14 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                         const int i0 = c * 64 + lane, i1 = i0 + 64;
                         const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
                         const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-                        const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
-                        const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                        const double f0 = value(i0, n0, l0);
+                        const double f1 = value(i1, n1, l1);
                         acc = fma(f0, q0, acc);
                         acc = fma(f1, q1, acc);
                     }
                     if (c < c1) {
                         const int i = c * 64 + lane;
-                        const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
+                        const double f = value(i, T_nu(i), T_ln(i));
                         acc = fma(f, T_wt(i), acc);
                     }
                     if (us.w == 0) {

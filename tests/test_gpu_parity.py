@@ -1097,6 +1097,24 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
     row, with a covariance matrix; anything else on the context makes it leave first; it leaves by itself when nothing
     comes; a request it does not answer in time is evaluated by a launch."""
     import time
+    # every model variant (a row's quadrature starts beside its constructor, or after it: option serve_overlap), with and
+    # without the merge point's power law, priors incl. the peak wavelength's (a second root in the constructor), rows the
+    # gate rejects
+    for variant, overlap in (("thick_noalpha", 1), ("thin_noalpha", 1), ("thin_walpha", 0), ("thick_walpha", 0)):
+        like = mbb.likelihood(response=True, opthin=variant.startswith("thin"), noalpha=variant.endswith("noalpha"))
+        like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl["cfg2/%s/flux" % variant], g_lnl["cfg2/%s/unc" % variant])
+        if variant == "thin_walpha":
+            like.set_gaussian_prior("peaklam", 250.0, 20.0)
+            like.set_uplim("lambda_peak", 265.0)
+        ctx = like._sync_device()
+        pars = np.tile(g_lnl["cfg2/%s/pars" % variant], (2, 1))[:125]
+        ctx.set_option("serve", 0)
+        want = like(pars).copy()
+        ctx.set_option("serve", 2); ctx.set_option("serve_overlap", overlap)
+        for n in (125, 125, 125, 125, 9, 125):
+            assert np.array_equal(like(pars[:n]), want[:n], equal_nan=True), (variant, overlap, n)
+        assert ctx.info("serving") == 1 and ctx.info("serve_fallbacks") == 0
+        del like
     for variant, cov in (("thick_walpha", False), ("thin_walpha", False), ("thick_walpha", True)):
         opthin = variant.startswith("thin")
         like = mbb.likelihood(response=True, opthin=opthin)
