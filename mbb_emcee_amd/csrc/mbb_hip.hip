@@ -1118,6 +1118,9 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     a.has_uplim = c->has_uplim; a.has_gprior = c->has_gprior;
     a.pars = c->w_pars; a.n = n; a.lnl = c->dv_srv; a.status = nullptr; a.model_flux = nullptr;
     a.wpb = 1; a.debug = (int)c->opt_debug; a.nsrc = 1;
+#ifdef MBB_STAMPS
+    a.stamps = c->d_stamps;
+#endif
     int wpb, threads;
     pick_geometry(c, 1, wpb, threads);
     const size_t dyn_limit = dynamic_lds_limit(c);

@@ -100,6 +100,13 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     if (wave < nun) us_first = a.unit_tab[wave];
     __syncthreads();
 
+    // diagnostic build: when things happened in a workgroup's latest request, on the clock all CUs share (100 MHz):
+    // stamps[workgroup * 16 + event], tools/probe_serve_stamps.py
+#ifdef MBB_STAMPS
+#define SV_EV(ev) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (ev)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SV_EV(ev) do { } while (0)
+#endif
     unsigned long long cur = a.seed;                 // the request the launch carries
     const long long idle = a.persist > 0 ? (long long)a.persist : 1000;
     for (int turn = 0;; ++turn) {
@@ -108,6 +115,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
         if (w < n) {
             // ---- phase 1 (k_lnlike's, SMODE 0): gate, constructor, parameter-only penalties on one row of 16 lanes --
             // in two parts when the quadrature may start on the first
+            SV_EV(0);
             bool mine = false;
             double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, lT = 0.0, lL = 0.0;
             if (tid < 16) {
@@ -118,6 +126,10 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 const double pe = tid < 5 ? __hip_atomic_load(a.pars + (size_t)w * 5 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) p[i] = __shfl(pe, i);
+#ifdef MBB_STAMPS
+                asm volatile("" ::"v"(p[0]));
+#endif
+                SV_EV(1);
                 if (OPTHIN) {
                     double lo[1];
                     vlog<true>(lo, p[0]);
@@ -148,6 +160,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 }
             }
             if (overlap) __syncthreads();
+            SV_EV(2);
             const bool ahead = overlap && wk[0].status == ROW_OK;           // workgroup-uniform
             // (the constructor is one dependent chain and runs fastest on a SIMD it has to itself: with sixteen waves its
             // SIMD's other three -- waves 4, 8, 12 -- sit this part out)
@@ -183,6 +196,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     pen[0] = pen_u;
                     pen[1] = pen_g;
                 }
+                SV_EV(3);
                 if (ahead) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
@@ -192,6 +206,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             }
             __syncthreads();
             // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
+            SV_EV(4);
             if (wk[0].status == ROW_OK) {
                 const WalkerK k = wk[0];
                 // a sample's value: the buffered one, or the power law's beyond the merge point -- as fnu_sample decides
@@ -236,6 +251,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 }
             }
             __syncthreads();
+            SV_EV(5);
             // ---- phase 3 (k_lnlike's): band sums in fixed order, lnL -> the pinned result slots
             if (wave == 0) {
                 const int st = wk[0].status;
@@ -290,6 +306,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     rec.x = (int)rb; rec.y = (int)(rb >> 32); rec.z = (int)sb; rec.w = (int)(sb >> 32);
                     double *dst = a.lnl + 2 * (size_t)w;
                     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(rec) : "memory");
+                    SV_EV(6);
                 }
             }
         }
@@ -311,6 +328,9 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 __builtin_amdgcn_s_sleep(8);
             }
             s_req[turn & 1] = v;
+#ifdef MBB_STAMPS
+            if (a.stamps) a.stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime();     // (the word was seen)
+#endif
         }
         __syncthreads();
         cur = s_req[turn & 1];
