@@ -212,8 +212,11 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * context is the only one of the process on its device and a batch is at most a row per CU.  Any other entry point on
  * the context tells it to leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
- * switch the feature off.  0: a launch per call; 2: also beside other contexts.  mbb_get_info "serving",
- * "serve_requests", "serve_fallbacks"), "launch_api" (how the likelihood launch of given rows
+ * switch the feature off.  0: a launch per call; 2: also beside other contexts.  "serve_overlap" (default 1): that
+ * kernel starts a row's passband quadrature beside its SED constructor -- the blackbody-side value of every sample,
+ * which needs none of the constructor's merge point, into a buffer in LDS -- and sums the units from the buffer when
+ * the constructor is through; 0: one after the other, as a launch does it; the same results either way.
+ * mbb_get_info "serving", "serve_requests", "serve_fallbacks"), "launch_api" (how the likelihood launch of given rows
  * is handed to the runtime: 1, the default, hipModuleLaunchKernel with the argument block as one packed buffer;
  * 0 hipLaunchKernel -- 0.2 us more per call: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band
  * leftovers share chunks; takes effect at the next mbb_set_bands), "stage_tables",
