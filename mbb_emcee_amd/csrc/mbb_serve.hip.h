@@ -188,7 +188,13 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 k.pad = 0;
                 double pen_u = 0.0, pen_g = 0.0;
                 {
+#ifdef MBB_STAMPS
+                    if (tid == 0 && a.stamps) a.stamps[blockIdx.x * 32 + 8] = __builtin_amdgcn_s_memtime();      // (one row: no clash with SV_EV's)
+#endif
 #include "mbb_walker_consts.inc"
+#ifdef MBB_STAMPS
+                    if (tid == 0 && a.stamps) { asm volatile("" ::"v"(pen_u + pen_g + k.cbb)); a.stamps[blockIdx.x * 32 + 10] = __builtin_amdgcn_s_memtime(); }
+#endif
                 }
                 // (with the quadrature ahead its waves are reading the record: it is replaced behind the barrier)
                 if (tid == 0) {

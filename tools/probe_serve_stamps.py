@@ -30,4 +30,7 @@ for n in [int(a) for a in sys.argv[1:]] or [125, 1]:
         for nm, x in zip(names, d):
             print("   %-44s median %6.0f ns   max %6.0f" % (nm, np.median(x), x.max()))
         print("   %-44s median %6.0f ns   max %6.0f" % ("request seen -> result stored", np.median(ev[:, 6] - ev[:, 0]), (ev[:, 6] - ev[:, 0]).max()))
+        if n == 1:
+            raw = st.reshape(-1).astype(np.int64)
+            print("   constructor, core cycles (one row): sed_prologue %d, the rest (record, penalties) %d" % (raw[9] - raw[8], raw[10] - raw[9]))
         print("   spread of 'request seen' over the workgroups: %.0f ns; of 'result stored': %.0f ns" % (ev[:, 0].max() - ev[:, 0].min(), ev[:, 6].max() - ev[:, 6].min()))
