@@ -90,7 +90,7 @@ MBB_SERVE_EXT(true, true)
 constexpr unsigned long long kServeQuitHost = 0xffffull;
 static size_t serve_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)                  // = serve_lds() of mbb_serve.hip.h
 {
-    return sizeof(WalkerK) + 16 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
+    return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
 constexpr int kFrMaxWHost = 8;
 static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h

@@ -18,11 +18,10 @@
 // us): what the quadrature needs of the constructor for every sample on the blackbody side of the merge point -- h/kT, its
 // log, beta, log x0 -- is a division and two logs away from the parameters, and what takes the constructor its time, the
 // merge point itself (a root), only says WHICH samples are on the other side.  So once those few scalars are in LDS, twelve
-// waves sum the units as if no sample lay beyond the merge point, keeping every sample's value in a buffer, while the first
-// wave's row of 16 lanes finishes the constructor; then only the units that do have a sample beyond it (one comparison with
-// the unit's highest frequency) are summed again -- sample by sample in the same order, each either the kept value or, beyond
-// the merge point, the power law's -- so that every partial sum is bit for bit the launch's (spec_cfg bit 0; the buffer is
-// 512 bytes per chunk of LDS, and without room for it the phases run one after the other as in k_lnlike).
+// waves work out the blackbody-side value of every sample into a buffer while the first wave's row of 16 lanes finishes the
+// constructor; then the units are summed as ever -- sample by sample in the same order, each either the buffered value or,
+// beyond the merge point, the power law's -- so that every partial sum is bit for bit the launch's (spec_cfg bit 0; the
+// buffer is 512 bytes per chunk of LDS, and without room for it the phases run one after the other as in k_lnlike).
 // The kernel leaves when told to (the doorbell says QUIT: any other use of the context, its destruction) or when
 // workgroup 0 has seen no request for `idle` polls (~1 us each; it then writes QUIT itself so that every workgroup
 // follows); every workgroup besides has a safety limit of its own (four times that).  Whatever goes wrong -- a request
@@ -36,7 +35,7 @@ constexpr unsigned long long kServeQuit = 0xffffull;           // the request's 
 // dynamic LDS of a k_serve launch besides the staged passband tables (bytes)
 __host__ __device__ constexpr size_t serve_lds(size_t nb, size_t npart, bool cov_in_lds)
 {
-    return sizeof(WalkerK) + 16 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
+    return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
 
 // Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl = the pinned
@@ -57,8 +56,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     double *partial = reinterpret_cast<double *>(wk + 1);                 // [npart]
     double *mflux = partial + npart;                                      // [nb]
     double *pen = mflux + nb;                                             // [2]
-    double *unit_numax = pen + 2;                                         // [nunit <= npart]: the highest frequency among a unit's samples
-    double *s_flux = unit_numax + npart;
+    double *s_flux = pen + 2;
     double *s_ivar = s_flux + nb;
     double *s_invcov = s_ivar + nb;
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0));
@@ -100,16 +98,6 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     const SampleTabs tabs = {s_tab, s_pb, s_pc};
     int4 us_first = make_int4(0, 0, 0, 0);
     if (wave < nun) us_first = a.unit_tab[wave];
-    __syncthreads();
-    // (once: the highest frequency in every unit -- whether ANY of its samples lies beyond a row's merge point is then one
-    // comparison, since h nu / k T grows with nu)
-    for (int u = wave; u < nun; u += nwave) {
-        const int4 us = a.unit_tab[u];
-        double m = 0.0;
-        for (int c = us.y; c < us.z; ++c) m = fmax(m, T_nu(c * 64 + lane));
-        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-        if (lane == 0) unit_numax[u] = m;
-    }
     __syncthreads();
 
     // diagnostic build: when things happened in a workgroup's latest request, on the clock all CUs share (100 MHz):
@@ -178,49 +166,20 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             // SIMD's other three -- waves 4, 8, 12 -- sit this part out)
             const bool spare_simd = nwave == 16;
             const int nqw = spare_simd ? 12 : nwave - 1, qw = spare_simd ? wave - 1 - (wave >> 2) : wave - 1;
-            // a unit's samples summed in k_lnlike's order and its result where k_lnlike puts it; `val(i, nu, lnnu)` gives a
-            // sample's value
-            auto do_unit = [&](const int4 us, auto &&val) {
-                const int s = us.x, c0 = us.y, c1 = us.z;
-                double acc = 0.0;
-                int c = c0;
-                for (; c + 2 <= c1; c += 2) {                         // two chunks per step (k_lnlike, do_unit)
-                    const int i0 = c * 64 + lane, i1 = i0 + 64;
-                    const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
-                    const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-                    const double f0 = val(i0, n0, l0);
-                    const double f1 = val(i1, n1, l1);
-                    acc = fma(f0, q0, acc);
-                    acc = fma(f1, q1, acc);
-                }
-                if (c < c1) {
-                    const int i = c * 64 + lane;
-                    const double f = val(i, T_nu(i), T_ln(i));
-                    acc = fma(f, T_wt(i), acc);
-                }
-                if (us.w == 0) {
-                    acc = wave_sum(acc);
-                    if (lane == 0) partial[s] = acc;
-                } else if (us.w == 2) {
-                    acc = row_sum(acc);
-                    if ((lane & 15) == 0) {
-                        const int sl = a.tail_slot[4 * s + (lane >> 4)];
-                        if (sl >= 0) partial[sl] = acc;
-                    }
-                } else {
-                    partial[s + lane] = acc;
-                }
-            };
             if (ahead && wave > 0 && !(spare_simd && (wave & 3) == 0)) {
-                // ---- on waves that have no constructor: every unit summed as if none of its samples lay beyond the merge
-                // point (right for every unit of which that turns out true), each sample's value kept for the others
+                // ---- the blackbody-side value of every sample, two chunks per step, on waves that have no constructor
                 const WalkerK k = wk[0];
-                for (int u = qw; u < nun; u += nqw)
-                    do_unit(a.unit_tab[u], [&](int i, double nu, double lnnu) {
-                        const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs);
-                        fbuf[i] = f;
-                        return f;
-                    });
+                const int nc = a.nchunk, stride = 2 * nqw;
+                for (int c = 2 * qw; c < nc; c += stride) {
+                    const int i0 = c * 64 + lane, i1 = i0 + 64;
+                    const bool two = c + 1 < nc;
+                    const double n0 = T_nu(i0), l0 = T_ln(i0);
+                    const double n1 = two ? T_nu(i1) : 1.0, l1 = two ? T_ln(i1) : 0.0;
+                    const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
+                    const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
+                    fbuf[i0] = f0;
+                    if (two) fbuf[i1] = f1;
+                }
             }
             if (mine) {
                 if (ahead) __builtin_amdgcn_s_setprio(3);
@@ -252,21 +211,48 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 else { wk[0].status = kfin.status; wk[0].pad = kfin.pad; }
             }
             __syncthreads();
-            // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves -- with the quadrature ahead only those that
-            // have a sample beyond the merge point are summed again, from the kept values and the power law
+            // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
             SV_EV(4);
             if (wk[0].status == ROW_OK) {
                 const WalkerK k = wk[0];
+                // a sample's value: the buffered one, or the power law's beyond the merge point -- as fnu_sample decides
+                auto value = [&](int i, double nu, double lnnu) {
+                    if (!ahead) return fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs);
+                    if constexpr (!NOALPHA) {
+                        if (k.hokt9 * nu > k.xmerge) return fnu_wien_tab(k, k.lhokt9 + lnnu, &tabs);
+                    }
+                    return fbuf[i];
+                };
                 for (int u = wave; u < nun; u += nwave) {
                     const int4 us = (u == wave) ? us_first : a.unit_tab[u];
-                    if (!ahead) {
-                        do_unit(us, [&](int, double nu, double lnnu) { return fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs); });
-                    } else if (!NOALPHA && k.hokt9 * unit_numax[u] > k.xmerge) {
-                        do_unit(us, [&](int i, double nu, double lnnu) {
-                            // (as fnu_sample decides)
-                            if (k.hokt9 * nu > k.xmerge) return fnu_wien_tab(k, k.lhokt9 + lnnu, &tabs);
-                            return fbuf[i];
-                        });
+                    const int s = us.x, c0 = us.y, c1 = us.z;
+                    double acc = 0.0;
+                    int c = c0;
+                    for (; c + 2 <= c1; c += 2) {                     // two chunks per step (k_lnlike, do_unit)
+                        const int i0 = c * 64 + lane, i1 = i0 + 64;
+                        const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+                        const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
+                        const double f0 = value(i0, n0, l0);
+                        const double f1 = value(i1, n1, l1);
+                        acc = fma(f0, q0, acc);
+                        acc = fma(f1, q1, acc);
+                    }
+                    if (c < c1) {
+                        const int i = c * 64 + lane;
+                        const double f = value(i, T_nu(i), T_ln(i));
+                        acc = fma(f, T_wt(i), acc);
+                    }
+                    if (us.w == 0) {
+                        acc = wave_sum(acc);
+                        if (lane == 0) partial[s] = acc;
+                    } else if (us.w == 2) {
+                        acc = row_sum(acc);
+                        if ((lane & 15) == 0) {
+                            const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                            if (sl >= 0) partial[sl] = acc;
+                        }
+                    } else {
+                        partial[s + lane] = acc;
                     }
                 }
             }
