@@ -215,7 +215,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * switch the feature off.  0: a launch per call; 2: also beside other contexts.  "serve_overlap" (default 1): that
  * kernel starts a row's passband quadrature beside its SED constructor -- the blackbody-side value of every sample,
  * which needs none of the constructor's merge point, into a buffer in LDS -- and sums the units from the buffer when
- * the constructor is through; 0: one after the other, as a launch does it; the same results either way.
+ * the constructor is through, when the bands have at least 12 chunks of 64 samples (2: with fewer too); 0: one after
+ * the other, as a launch does it; the same results either way.
  * mbb_get_info "serving", "serve_requests", "serve_fallbacks"), "launch_api" (how the likelihood launch of given rows
  * is handed to the runtime: 1, the default, hipModuleLaunchKernel with the argument block as one packed buffer;
  * 0 hipLaunchKernel -- 0.2 us more per call: profiles/r04/boundary_breakdown.txt), "seg_chunks", "pack_tails" (band

@@ -1130,7 +1130,10 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
     // (the quadrature beside the constructor: a buffer of one value per sample behind the tables, when there is room)
     const size_t fbuf_bytes = (size_t)c->nchunk * 64 * sizeof(double);
-    const bool ovl = c->opt_serve_overlap != 0 && sm + (stg ? table_bytes + 16 : 0) + fbuf_bytes <= dyn_limit;
+    // -- and a chunk of samples at least for each of the twelve waves that work ahead: with fewer the extra barrier costs more
+    // than there is to gain (cfg1's one chunk: 8.5-8.7 -> 8.9 us per 25-row call; option 2: regardless)
+    const bool ovl = c->opt_serve_overlap != 0 && (c->nchunk >= 12 || c->opt_serve_overlap == 2) &&
+                     sm + (stg ? table_bytes + 16 : 0) + fbuf_bytes <= dyn_limit;
     a.spec_cfg = ovl ? 1 : 0;
     const size_t sm_total = sm + (stg ? table_bytes + 16 : 0) + (ovl ? fbuf_bytes : 0);
     if (sm_total > dyn_limit) return 1;

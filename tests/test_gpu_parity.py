@@ -1110,7 +1110,7 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
         pars = np.tile(g_lnl["cfg2/%s/pars" % variant], (2, 1))[:125]
         ctx.set_option("serve", 0)
         want = like(pars).copy()
-        ctx.set_option("serve", 2); ctx.set_option("serve_overlap", overlap)
+        ctx.set_option("serve", 2); ctx.set_option("serve_overlap", 2 * overlap)
         for n in (125, 125, 125, 125, 9, 125):
             assert np.array_equal(like(pars[:n]), want[:n], equal_nan=True), (variant, overlap, n)
         assert ctx.info("serving") == 1 and ctx.info("serve_fallbacks") == 0
