@@ -972,7 +972,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
                 scratch.run_mcmc(allw[:nwt], 2, storechain=False)
                 ran = [60, 2]                                     # steps of every sampler run so far (rehearsal first)
                 t_end = time.perf_counter() + PRECONDITION_S
-                pre = min(4096, max(200, steps))                  # (launches as long as the timed one: see PRECONDITION_S)
+                pre = min(4096, max(2, steps))                    # (launches exactly as long as the timed one: see PRECONDITION_S)
                 while time.perf_counter() < t_end:
                     scratch.advance_timed(pre)
                     ran.append(pre)
