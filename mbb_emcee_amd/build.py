@@ -107,5 +107,31 @@ def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
     return target
 
 
+SRC_FAST = os.path.join(HERE, "csrc", "mbb_fastcall.c")
+FAST = os.path.join(HERE, "_mbbfast.so")
+
+
+def build_fastcall(force=False):
+    """Builds the CPython extension `_mbbfast` (csrc/mbb_fastcall.c: likelihood.__call__'s boundary call as one C-level
+    callable) with the host compiler and returns its path, or None when that is not possible here (no compiler, no
+    Python or numpy headers): the likelihood then makes the same call through numpy and ctypes."""
+    import sysconfig
+    if not force and os.path.exists(FAST) and os.path.getmtime(FAST) >= os.path.getmtime(SRC_FAST):
+        return FAST
+    try:
+        import numpy
+        cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+        if not cc:
+            return None
+        tmp = "%s.tmp.%d" % (FAST, os.getpid())
+        subprocess.check_call([cc, "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-I" + numpy.get_include(),
+                               SRC_FAST, "-o", tmp], stderr=subprocess.DEVNULL)
+        os.replace(tmp, FAST)
+        return FAST
+    except Exception:           # noqa -- an optional accelerator of the host glue, never a reason to fail a build
+        return None
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_fastcall(force="--force" in sys.argv))

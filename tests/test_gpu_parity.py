@@ -1042,8 +1042,19 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
     for n in (125, 10, 300, 1, 125, 1000, 6620, 250, 125):           # capacity grows 256 -> 8192 on the way
         got = like(allp[:n])
         assert type(got) is np.ndarray and got.shape == (n,) and np.array_equal(got, want[:n], equal_nan=True), n
-        assert like._fast is not None and n in like._fast[2]
+        # (the call went the short way: through the C-level callable where the extension is built -- it is, on the GPU box,
+        # by __graft_entry__.build() -- else through the views of the two blocks)
+        assert like._fast is not None and like._fast[3] >= n and (like._fast[7] is not None or n in like._fast[2])
     assert got.base is None                                           # a copy, not a view of the pinned block
+    from mbb_emcee_amd import likelihood as _lk_mod
+    if _lk_mod._mbbfast is not None:
+        # the same calls with the extension out of the way: the numpy / ctypes form of the short way, bit for bit
+        fc = like._fast[7]
+        assert fc is not None
+        a = like(allp[:125]); b1 = like(allp[7])
+        like._fast = like._fast[:7] + (None,)
+        assert np.array_equal(like(allp[:125]), a, equal_nan=True) and like(allp[7]) == b1 and 125 in like._fast[2]
+        like._fast = None
     keep = like(allp[:125])
     like(allp[125:250])
     assert np.array_equal(keep, want[:125], equal_nan=True)           # ... so a later call does not change it

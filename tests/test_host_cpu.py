@@ -758,3 +758,42 @@ def test_every_option_is_documented_in_the_header():
     assert len(opts) >= 20
     assert [o for o in sorted(opts) if '"%s"' % o not in hdr] == []
 
+
+def test_fastcall_extension_with_a_stand_in_for_the_native_call():
+    """mbb_emcee_amd/csrc/mbb_fastcall.c (the `_mbbfast` extension: likelihood.__call__'s boundary call as one C-level
+    callable): rows into the block, the native entry called with the row count, results out into a fresh array -- with a
+    ctypes callback standing in for mbb_lnlike_call (no GPU here); everything it does not take gives None."""
+    import ctypes as C
+    from mbb_emcee_amd import build as B
+    if B.build_fastcall() is None:
+        pytest.skip("no host compiler or no Python / numpy headers here")
+    import importlib
+    lk = importlib.import_module("mbb_emcee_amd.likelihood")
+    ext = lk._mbbfast if lk._mbbfast is not None else importlib.import_module("mbb_emcee_amd._mbbfast")
+    rows = np.zeros((256, 5)); lnl = np.zeros(256); calls = []
+
+    def native(h, n):
+        calls.append((h, n)); lnl[:n] = rows[:n].sum(axis=1)
+        return 0 if rows[0, 0] >= 0 else 7
+    cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(native)
+    fc = ext.FastCall(C.cast(cb, C.c_void_p).value, 1234, rows.ctypes.data, lnl.ctypes.data, 256)
+    p = np.random.RandomState(0).rand(40, 5)
+    r = fc(p)
+    assert type(r) is np.ndarray and r.dtype == np.float64 and r.base is None and np.array_equal(r, p.sum(axis=1))
+    assert calls == [(1234, 40)]
+    one = fc(p[3])
+    assert type(one) is float and one == p[3].sum() and calls[-1] == (1234, 1)
+    lnl[:] = -1.0
+    assert np.array_equal(r, p.sum(axis=1))                           # (the result was a copy)
+    n_before = len(calls)
+    for other in (p.astype(np.float32), np.asfortranarray(p), p[::2], list(p[0]), np.zeros((300, 5)), np.zeros((3, 4)),
+                  np.zeros((0, 5)), np.zeros(4), p.reshape(2, 20, 5), None):
+        assert fc(other) is None
+    assert len(calls) == n_before                                     # none of them reached the native call
+    bad = p.copy(); bad[0, 0] = -1.0
+    assert fc(bad) is None and calls[-1] == (1234, 40)                # a non-zero return: the caller takes the general path
+    with pytest.raises(TypeError):
+        fc()
+    with pytest.raises(ValueError):
+        ext.FastCall(0, 1, 2, 3, 4)
+
