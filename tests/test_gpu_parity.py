@@ -1046,7 +1046,8 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
         # by __graft_entry__.build() -- else through the views of the two blocks)
         assert like._fast is not None and like._fast[3] >= n and (like._fast[7] is not None or n in like._fast[2])
     assert got.base is None                                           # a copy, not a view of the pinned block
-    from mbb_emcee_amd import likelihood as _lk_mod
+    import importlib
+    _lk_mod = importlib.import_module("mbb_emcee_amd.likelihood")      # (the module: the package exports the class under its name)
     if _lk_mod._mbbfast is not None:
         # the same calls with the extension out of the way: the numpy / ctypes form of the short way, bit for bit
         fc = like._fast[7]
