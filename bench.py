@@ -1323,7 +1323,10 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
                           "evals_per_s": bnd["rows_%d" % half]["evals_per_s"],
                           "launch_per_call_p50_us": bnd["launch_per_call"]["rows_%d" % half]["median_us"],
                           "what": "synchronous likelihood.__call__(float64[125, 5]) -> float64[125], host arrays in and out, in a "
-                                  "loop of calls (the rows are served by a kernel resident between the calls)"}
+                                  "loop of calls (the rows are served by a kernel resident between the calls)",
+                          # (how the three host steps of a call -- rows in, native call, results out -- were made)
+                          "host_glue": ("CPython extension (mbb_emcee_amd/csrc/mbb_fastcall.c)"
+                                        if like._fast is not None and like._fast[7] is not None else "numpy + ctypes")}
 
     # ---- pipelined upper bound: independent launches on pre-computed proposals
     NSETS = 8
