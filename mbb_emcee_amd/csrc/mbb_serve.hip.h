@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     if (tid == 0 && a.stamps) { asm volatile("" ::"v"(pen_u + pen_g + k.cbb)); a.stamps[blockIdx.x * 32 + 10] = __builtin_amdgcn_s_memtime(); }
 #endif
                 }
-                // (with the quadrature ahead its waves are reading the record: it is replaced behind the barrier)
+                // (a record of its own: with the quadrature ahead its waves are still reading the first one)
                 if (tid == 0) {
                     kfin = k;
                     pen[0] = pen_u;
@@ -206,15 +206,10 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 if (ahead) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
-            if (tid == 0) {
-                if (kfin.status == ROW_OK) wk[0] = kfin;
-                else { wk[0].status = kfin.status; wk[0].pad = kfin.pad; }
-            }
-            __syncthreads();
             // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
             SV_EV(4);
-            if (wk[0].status == ROW_OK) {
-                const WalkerK k = wk[0];
+            if (kfin.status == ROW_OK) {
+                const WalkerK k = kfin;
                 // a sample's value: the buffered one, or the power law's beyond the merge point -- as fnu_sample decides
                 auto value = [&](int i, double nu, double lnnu) {
                     if (!ahead) return fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs);
@@ -260,10 +255,10 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             SV_EV(5);
             // ---- phase 3 (k_lnlike's): band sums in fixed order, lnL -> the pinned result slots
             if (wave == 0) {
-                const int st = wk[0].status;
+                const int st = kfin.status;
                 double acc = 0.0;
                 if (st == ROW_OK) {
-                    const double cbb = wk[0].cbb;
+                    const double cbb = kfin.cbb;
                     auto band = [&](const int b) {
                         double sum = 0.0;
                         const int2 rng = s_band[b];
@@ -307,7 +302,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     // (system scope -- straight through to the host -- spelled out: there is no 16-byte atomic store to
                     // ask the compiler for, and a non-temporal one may stay in L2 until the kernel ends)
                     typedef int v4i __attribute__((ext_vector_type(4)));
-                    const long long rb = __double_as_longlong(r), sb = (long long)(a.debug ? (st | (wk[0].pad << 8)) : st);
+                    const long long rb = __double_as_longlong(r), sb = (long long)(a.debug ? (st | (kfin.pad << 8)) : st);
                     v4i rec;
                     rec.x = (int)rb; rec.y = (int)(rb >> 32); rec.z = (int)sb; rec.w = (int)(sb >> 32);
                     double *dst = a.lnl + 2 * (size_t)w;
