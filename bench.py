@@ -1399,13 +1399,17 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
             ctx.record(g0); sb_.advance_async(300); ctx.record(g1); ctx.sync()
             us = ctx.elapsed_ms(g0, g1) * 1e3 / 300
             row[name] = {"us_per_step": us, "evals_per_s": nwb / (us * 1e-6), "kernel_form": ctx.info("last_kernel_form"),
-                         "workgroups": ctx.info("last_grid"), "walkers_per_workgroup_and_half": ctx.info("last_wpb")}
+                         "workgroups": ctx.info("last_grid"), "walkers_per_workgroup_and_half": ctx.info("last_wpb"),
+                         # (90 flop per quadrature sample, nwb / 2 walkers per half-step, fp64 vector peak)
+                         "roofline_frac": 90.0 * nq * (nwb / 2) / (0.5 * us * 1e-6) / (FP64_VALU_PEAK_TFLOPS * 1e12)}
             assert np.all(np.isfinite(sb_.run_mcmc(None, 0, storechain=False)[1]))
             del sb_
         big["walkers_%d" % nwb] = row
     ctx.set_option("lookahead_sampler", 1)
     big["note"] = ("one ensemble of that many walkers on this GPU, 300 steps by HIP events; kernel_form 9 = resident with the "
-                   "constructor a half-step ahead (k_flowa), 8 = resident, nothing ahead (k_flowr), 1 = one launch per half-step")
+                   "constructor a half-step ahead (k_flowa), 8 = resident, nothing ahead (k_flowr), 1 = one launch per half-step; "
+                   "roofline_frac = algorithmic flops of a half-step (90 x NQ x walkers / 2) over its time, against the fp64 "
+                   "vector peak")
     out["large_ensembles"] = big
 
     # ---- the empirical roof of the sample arithmetic, measured now
