@@ -12,6 +12,9 @@ Workgroup g owns walkers [g W, g W + W) of both halves.  Actors per workgroup:
         half-step on, the proposal of that pending move (candidate 1) and then its decision; the lag guard (every
         workgroup's C through with j - kFmLag); its own E through with j - 2 (the owned rows are final, the record
         buffer is free).  Publishes the proposal of each owned walker's move and counts itself for the guard.
+        (Since round 4 the kernel publishes a walker's proposal as soon as THAT walker's partner has decided rather than
+        when all of the workgroup's have: the same store into the same slot within the same half-step, only earlier --
+        what protects the slot's previous content is the guard at the half-step's entry, which the model keeps.)
         form 8: phase 1 of the half-step: needs every partner's row AFTER its last move (half-step j - 1), the lag
         guard, its own E(j - 1).
   E(j)  quadrature, accept test and publication of half-step j for the owned walkers: needs C(j); publishes the
