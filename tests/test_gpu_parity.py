@@ -599,6 +599,27 @@ def test_bench_sharded_boundary_leg_with_one_rank(mbb, g_lnl):
     assert ctx.info("nranks") == 1
 
 
+def test_bench_with_two_ranks_sharing_this_gpu():
+    """`python bench.py --gpus 2` as the driver starts it, end to end, with the two ranks as processes on this one GPU
+    (--oversubscribe: a rehearsal, said so on the line): the supervisor, the gloo side channel, the one-hop exchange
+    through hipIpc mappings set up / rehearsed against the unsharded sampler / preconditioned / timed / validated, one
+    JSON line with a value and the ranks' copies of the ensemble agreeing.  (RCCL needs a device per rank and the
+    one-launch exchange every workgroup of both ranks resident: neither is possible here, and the line says so.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MBB_BENCH_WALKERS_PER_GPU="32")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                          "--oversubscribe"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] and d["value"] > 0 and d["ranks_agree"] is True, d
+    assert d["valid_for_scaling"] is False and "rehearsal" in d["config"]["note"]
+    assert "2000 untimed steps" in d["config"]["preconditioning"] and "rehearsal" in d["config"]
+    ev = d["exchange_validation"]
+    assert ev["ipc-launches"]["ok"] is True and ev["rccl"]["ok"] is None and ev["ipc"]["ok"] is None, ev
+
+
 # --------------------------------------------- batched multi-source mode (cfg5)
 def _multi_setup(mbb, g_lnl, ns, seed=9):
     bands = [str(b) for b in g_lnl["cfg2/bands"]]
