@@ -297,13 +297,14 @@ static int serve_stop(mbb_ctx *c);
 
 // Every entry point but the boundary call comes through here: a resident server (k_serve) is told to leave first --
 // it holds the CUs, and its arguments were fixed at its launch -- and the streak of boundary calls ends.
+static int yield_server(mbb_ctx *c);
 static int use(mbb_ctx *c)
 {
     if (!c) return fail(MBB_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
     c->srv_hot = 0;
     if (c->serving) return serve_stop(c);
-    return MBB_OK;
+    return yield_server(c);
 }
 
 extern "C" const char *mbb_last_error(void) { return g_err.c_str(); }
@@ -320,10 +321,26 @@ struct DeviceStatics {
     int cu_count = 0;
     double *d_poly_b = nullptr, *d_poly_c = nullptr;
     std::vector<hipStream_t> idle_streams;
-    std::atomic<int> live{0};        // contexts of this process on the device (a server is only kept while there is one)
+    std::atomic<int> live{0};        // contexts of this process on the device
+    struct mbb_ctx *server = nullptr;    // the context whose k_serve is resident on the device, if any (g_dev_mutex)
 };
 static std::mutex g_dev_mutex;
 static DeviceStatics g_dev[64];
+
+// Another context of this process has a server resident on c's device: it holds the CUs, so whatever c is about to put on
+// its stream would wait for it -- it is told to leave first (and starts again after its own next few calls in a row).
+static int yield_server(mbb_ctx *c)
+{
+    if (c->device < 0 || c->device >= 64) return MBB_OK;
+    mbb_ctx *o;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mutex);
+        o = g_dev[c->device].server;
+    }
+    if (!o || o == c) return MBB_OK;
+    o->srv_hot = 0;
+    return serve_stop(o);
+}
 
 extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
 {
@@ -1084,6 +1101,10 @@ static int serve_stop(mbb_ctx *c)
 {
     if (!c->serving) return MBB_OK;
     c->serving = false;
+    if (c->device >= 0 && c->device < 64) {
+        std::lock_guard<std::mutex> lk(g_dev_mutex);
+        if (g_dev[c->device].server == c) g_dev[c->device].server = nullptr;
+    }
     // a request number the server has not seen, with the row count that means "leave"
     __atomic_store_n(c->w_door, (++c->srv_seq << 16) | kServeQuitHost, __ATOMIC_RELAXED);
     __builtin_ia32_sfence();
@@ -1163,6 +1184,10 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     c->last_wpb = 1; c->last_threads = threads; c->last_grid = c->cu_count; c->last_smem = (long)sm_total;
     c->last_stage = stg ? 1 : 0; c->last_smode = 10;
     c->serving = true;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mutex);
+        g_dev[c->device].server = c;
+    }
     return MBB_OK;
 }
 
@@ -1237,10 +1262,11 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
         return fail(MBB_ERR_STATE, "mbb_boundary_buffers first (or again: the buffers or the host-path options changed)");
     }
     // After a few boundary calls in a row with nothing else in between -- a sampler's loop -- the rows are handed to
-    // a kernel that stays on the GPU (k_serve) instead of a launch each: while this context is the only one of the
-    // process on the device, the batch is at most a row per CU, and the host path is the default one.
-    const bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 &&
-                           c->data_nb == c->nb && (g_dev[c->device].live.load() == 1 || c->opt_serve == 2);
+    // a kernel that stays on the GPU (k_serve) instead of a launch each: while the batch is at most a row per CU and the
+    // host path is the default one.  One server per device and process: whichever context comes to the device tells a
+    // sibling's to leave first (use(), and the line below).
+    const bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
+    if (!c->serving && (rc = yield_server(c))) return rc;      // (a sibling context's server: this call, served or launched, needs the CUs)
     bool done = false;
     if (can_serve && (c->serving || ++c->srv_hot >= c->opt_serve_after)) {
         rc = serve_request(c, n);

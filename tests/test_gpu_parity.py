@@ -1204,6 +1204,44 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
         del s, like
 
 
+def test_served_boundary_with_several_likelihoods_alive(mbb, g_lnl):
+    """One server per device and process: a likelihood that comes to the device while a sibling's kernel is resident
+    there tells it to leave first (it holds the CUs), is evaluated, and is served itself after its own few calls in a
+    row; the sibling starts again after its next few.  Option "serve" at its default (1), other contexts of the test
+    session alive besides."""
+    a, b = _cfg2_like(mbb, g_lnl), _cfg2_like(mbb, g_lnl)
+    b.set_uplim("T", 12.0)                                            # (so that the two do not give the same numbers)
+    ca, cb = a._sync_device(), b._sync_device()
+    p = np.tile(g_lnl["cfg2/thick_walpha/pars"], (2, 1))[:125]
+    for c in (ca, cb):
+        c.set_option("serve", 0)
+    wa, wb = a(p).copy(), b(p).copy()
+    assert not np.array_equal(wa, wb, equal_nan=True)
+    for c in (ca, cb):
+        c.set_option("serve", 1)
+    for _ in range(5):
+        assert np.array_equal(a(p), wa, equal_nan=True)
+    assert ca.info("serving") == 1 and cb.info("serving") == 0
+    assert np.array_equal(b(p), wb, equal_nan=True)                   # b comes to the device: a's server leaves
+    assert ca.info("serving") == 0 and cb.info("serving") == 0
+    for _ in range(4):
+        assert np.array_equal(b(p), wb, equal_nan=True)
+    assert cb.info("serving") == 1 and ca.info("serving") == 0
+    for k in range(6):                                                # alternating callers: always right, nobody served
+        assert np.array_equal((a if k % 2 == 0 else b)(p), wa if k % 2 == 0 else wb, equal_nan=True)
+    assert ca.info("serving") == 0 and cb.info("serving") == 0
+    for _ in range(4):
+        assert np.array_equal(a(p), wa, equal_nan=True)
+    assert ca.info("serving") == 1
+    # any other entry point of a sibling does the same
+    s = mbb.DeviceEnsembleSampler(64, 5, b, seed=3)
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(2).normal(size=(64, 5)))
+    pos, lnp, _ = s.run_mcmc(p0, 3)
+    assert ca.info("serving") == 0 and np.all(np.isfinite(lnp))
+    assert ca.info("serve_fallbacks") == 0 and cb.info("serve_fallbacks") == 0
+    del s, a, b
+
+
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
     """The three ways an emcee-style sampler can call the likelihood -- row by row
     (emcee's plain map, mbb_fit.py:80-81 with threads=1), through a pool's map with a
