@@ -323,6 +323,7 @@ struct DeviceStatics {
     std::vector<hipStream_t> idle_streams;
     std::atomic<int> live{0};        // contexts of this process on the device
     struct mbb_ctx *server = nullptr;    // the context whose k_serve is resident on the device, if any (g_dev_mutex)
+    struct mbb_ctx *last_user = nullptr; // the context that came to the device last: "calls in a row" are a context's own
 };
 static std::mutex g_dev_mutex;
 static DeviceStatics g_dev[64];
@@ -336,6 +337,11 @@ static int yield_server(mbb_ctx *c)
     {
         std::lock_guard<std::mutex> lk(g_dev_mutex);
         o = g_dev[c->device].server;
+        if (g_dev[c->device].last_user != c) {
+            // (another context was here in between: this one's boundary calls are not "in a row" any more)
+            g_dev[c->device].last_user = c;
+            c->srv_hot = 0;
+        }
     }
     if (!o || o == c) return MBB_OK;
     o->srv_hot = 0;
@@ -401,7 +407,12 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->serving) (void)serve_stop(c);
-    if (c->device >= 0 && c->device < 64) --g_dev[c->device].live;
+    if (c->device >= 0 && c->device < 64) {
+        --g_dev[c->device].live;
+        std::lock_guard<std::mutex> lk(g_dev_mutex);
+        if (g_dev[c->device].last_user == c) g_dev[c->device].last_user = nullptr;
+        if (g_dev[c->device].server == c) g_dev[c->device].server = nullptr;
+    }
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->x.base) (void)xchg_free(c);
@@ -1266,7 +1277,9 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // host path is the default one.  One server per device and process: whichever context comes to the device tells a
     // sibling's to leave first (use(), and the line below).
     const bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
-    if (!c->serving && (rc = yield_server(c))) return rc;      // (a sibling context's server: this call, served or launched, needs the CUs)
+    // (a sibling context's server: this call, served or launched, needs the CUs; and a sibling's visit in between ends this
+    // context's run of calls)
+    if (!c->serving && (rc = yield_server(c))) return rc;
     bool done = false;
     if (can_serve && (c->serving || ++c->srv_hot >= c->opt_serve_after)) {
         rc = serve_request(c, n);
