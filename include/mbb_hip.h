@@ -208,11 +208,12 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * to blocking on the stream, 0 forces the fallback), "bar_params" (host path writes the
  * parameter rows into device memory through the PCIe BAR), "serve" (default 1: after "serve_after" (3) boundary calls in a row
  * with nothing else in between -- a sampler's loop -- mbb_lnlike_call hands its rows to a kernel that STAYS on the GPU
- * between the calls and is rung through the BAR (k_serve: no launch per call; same results bit for bit), while the
- * context is the only one of the process on its device and a batch is at most a row per CU.  Any other entry point on
- * the context tells it to leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
+ * between the calls and is rung through the BAR (k_serve: no launch per call; same results bit for bit), while a batch
+ * is at most a row per CU.  One such kernel per device and process: any other entry point on the context, and any entry
+ * point of ANOTHER context of the process that comes to the device (which also ends this context's run of calls), tells
+ * it to leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
- * switch the feature off.  0: a launch per call; 2: also beside other contexts.  "serve_overlap" (default 1): that
+ * switch the feature off.  0: a launch per call (2: as 1; it used to mean "also beside other contexts").  "serve_overlap" (default 1): that
  * kernel starts a row's passband quadrature beside its SED constructor -- the blackbody-side value of every sample,
  * which needs none of the constructor's merge point, into a buffer in LDS -- and sums the units from the buffer when
  * the constructor is through, when the bands have at least 12 chunks of 64 samples (2: with fewer too); 0: one after

@@ -1164,7 +1164,8 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     const size_t fbuf_bytes = (size_t)c->nchunk * 64 * sizeof(double);
     // -- and a chunk of samples at least for each of the twelve waves that work ahead: with fewer the extra barrier costs more
     // than there is to gain (cfg1's one chunk: 8.5-8.7 -> 8.9 us per 25-row call; option 2: regardless)
-    const bool ovl = c->opt_serve_overlap != 0 && (c->nchunk >= 12 || c->opt_serve_overlap == 2) &&
+    // -- and waves to work ahead with (a workgroup narrowed by option "block_threads" may have none besides the constructor's)
+    const bool ovl = c->opt_serve_overlap != 0 && (c->nchunk >= 12 || c->opt_serve_overlap == 2) && threads >= 256 &&
                      sm + (stg ? table_bytes + 16 : 0) + fbuf_bytes <= dyn_limit;
     a.spec_cfg = ovl ? 1 : 0;
     const size_t sm_total = sm + (stg ? table_bytes + 16 : 0) + (ovl ? fbuf_bytes : 0);

@@ -1147,6 +1147,12 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
         for n in (125, 125, 125, 125, 9, 125):
             assert np.array_equal(like(pars[:n]), want[:n], equal_nan=True), (variant, overlap, n)
         assert ctx.info("serving") == 1 and ctx.info("serve_fallbacks") == 0
+        # narrow workgroups (options of the launch geometry hold for the served kernel too): one wave, four waves
+        for thr in (64, 256, 0):
+            ctx.set_option("block_threads", thr)
+            for n in (125, 125, 125, 125, 7):
+                assert np.array_equal(like(pars[:n]), want[:n], equal_nan=True), (variant, overlap, thr, n)
+            assert ctx.info("serving") == 1 and ctx.info("last_threads") == (thr or ctx.info("last_threads"))
         del like
     for variant, cov in (("thick_walpha", False), ("thin_walpha", False), ("thick_walpha", True)):
         opthin = variant.startswith("thin")
