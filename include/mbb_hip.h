@@ -210,8 +210,10 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * with nothing else in between -- a sampler's loop -- mbb_lnlike_call hands its rows to a kernel that STAYS on the GPU
  * between the calls and is rung through the BAR (k_serve: no launch per call; same results bit for bit), while a batch
  * is at most a row per CU.  One such kernel per device and process: any other entry point on the context, and any entry
- * point of ANOTHER context of the process that comes to the device (which also ends this context's run of calls), tells
- * it to leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
+ * point of ANOTHER context of the process that comes to the device (which also ends this context's run of calls, and
+ * doubles, up to 64, the calls in a row it needs before its next server -- back to "serve_after" once a server has
+ * answered 256 requests: likelihoods used in turns do not spend their time starting and stopping kernels), tells it to
+ * leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
  * switch the feature off.  0: a launch per call (2: as 1; it used to mean "also beside other contexts").  "serve_overlap" (default 1): that
  * kernel starts a row's passband quadrature beside its SED constructor -- the blackbody-side value of every sample,

@@ -210,6 +210,11 @@ struct mbb_ctx {
     bool serving = false;
     unsigned long long srv_seq = 0;           // requests so far (the doorbell word is request number << 16 | rows)
     int srv_hot = 0;                          // boundary calls in a row with nothing else in between
+    long srv_need = 0;                        // ... of which a server is started (0: opt_serve_after).  Doubled, up to 64, every
+                                              // time a sibling context's visit sends this context's server away, back to
+                                              // opt_serve_after once a server has answered 256 requests: two likelihoods used
+                                              // in turns must not spend their time starting and stopping kernels
+    long srv_run = 0;                         // requests the present server has answered
     int srv_strikes = 0;                      // servers that had to be given up in a row; three switch the feature off
     long srv_requests = 0, srv_fallbacks = 0;
     long opt_serve = 1;                       // 0: every boundary call is a launch; 2: a server even beside other contexts (tests)
@@ -345,6 +350,7 @@ static int yield_server(mbb_ctx *c)
     }
     if (!o || o == c) return MBB_OK;
     o->srv_hot = 0;
+    o->srv_need = std::min<long>(64, 2 * (o->srv_need > 0 ? o->srv_need : o->opt_serve_after));
     return serve_stop(o);
 }
 
@@ -1196,6 +1202,7 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     c->last_wpb = 1; c->last_threads = threads; c->last_grid = c->cu_count; c->last_smem = (long)sm_total;
     c->last_stage = stg ? 1 : 0; c->last_smode = 10;
     c->serving = true;
+    c->srv_run = 0;
     {
         std::lock_guard<std::mutex> lk(g_dev_mutex);
         g_dev[c->device].server = c;
@@ -1246,7 +1253,11 @@ static int serve_request(mbb_ctx *c, int n)
     }
     c->last_watch_seen = seen ? 1 : 0;
     c->t_prep_ns = t_b - t_a; c->t_launch_ns = t_c - t_b; c->t_wait_ns = now_ns() - t_c;
-    if (seen) { c->srv_strikes = 0; return MBB_OK; }
+    if (seen) {
+        c->srv_strikes = 0;
+        if (++c->srv_run >= 256) c->srv_need = 0;
+        return MBB_OK;
+    }
     // the records did not turn: the server had left when the request came (it says so: nothing wrong, the sampler's
     // calls were further apart than its patience), or it was leaving, or it is not resident.  It is told to go, waited
     // for, and the rows go by a launch; three requests in a row lost to a server that had NOT said it was gone, and
@@ -1282,7 +1293,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // context's run of calls)
     if (!c->serving && (rc = yield_server(c))) return rc;
     bool done = false;
-    if (can_serve && (c->serving || ++c->srv_hot >= c->opt_serve_after)) {
+    if (can_serve && (c->serving || ++c->srv_hot >= (c->srv_need > 0 ? c->srv_need : c->opt_serve_after))) {
         rc = serve_request(c, n);
         if (rc < 0) return rc;
         done = rc == MBB_OK;
@@ -2157,7 +2168,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
     else if (!strcmp(name, "serve_overlap")) c->opt_serve_overlap = value;
     else if (!strcmp(name, "serve")) { c->opt_serve = value; c->srv_strikes = 0; }
-    else if (!strcmp(name, "serve_after")) c->opt_serve_after = value < 1 ? 1 : value;
+    else if (!strcmp(name, "serve_after")) { c->opt_serve_after = value < 1 ? 1 : value; c->srv_need = 0; }
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
     else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
