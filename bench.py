@@ -137,6 +137,7 @@ def cpu_baseline(like, flux, pars):
             "sample": "%d evals of the bench workload (250 walkers x 8 bands, NQ=2209) "
                       "tiled %dx, OpenMP over walkers; single-thread rate %.0f evals/s"
                       % (pm.shape[0], reps, rate1),
+            "sample_short": "%d evals of the bench workload, OpenMP over walkers, ~12 CPU-s" % pm.shape[0],
             "single_thread_value": rate1}, ref[:250]
 
 
@@ -511,8 +512,150 @@ def ensemble_crc(pos, lnp):
     return zlib.crc32(np.ascontiguousarray(pos).tobytes()) ^ zlib.crc32(np.ascontiguousarray(lnp).tobytes())
 
 
+LINE_LIMIT = 4096           # bytes of the ONE line on stdout (round 4's 20.7 KB line was not parsed by the driver)
+FULL_PATH = os.environ.get("MBB_BENCH_FULL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+
+
+def _num(x, sig=6):
+    """A number as it goes on the short line: `sig` significant digits, never NaN/Infinity (strict JSON)."""
+    if isinstance(x, (bool, np.bool_)):
+        return bool(x)
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if not np.isfinite(x):
+            return None
+        return float("%.*g" % (sig, x))
+    if isinstance(x, str):
+        return _txt(x, 48)          # (units, kinds, bounds: short words; the long texts are cut where they are picked)
+    if x is None:
+        return None
+    return _txt(x, 48)
+
+
+def _txt(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _pick(d, keys, sig=6):
+    """{k: d[k]} for the keys `d` has, numbers rounded."""
+    return {k: _num(d[k], sig) for k in keys if isinstance(d, dict) and k in d}
+
+
+def short_line(full):
+    """The ONE line the driver parses, from everything that was measured (`full`): the contract's keys, `roofline`,
+    `cpu_baseline`, the boundary figure M1 and the path of the side file that holds all the rest -- nothing else,
+    strings cut, numbers rounded to six digits, strict JSON (no NaN), below LINE_LIMIT bytes whatever `full` holds
+    (tests/test_host_cpu.py builds it from a fully populated line of 1 and of 8 ranks)."""
+    out = {}
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data"):
+        out[k] = _num(full.get(k), 7)
+    out["metric"] = _txt(full.get("metric", ""), 120)           # (BASELINE.json's metric, whole)
+    cfg = full.get("config") or {}
+    c = _pick(cfg, ("walkers_per_gpu", "walkers", "bands", "nq"))
+    c = dict({"workload": _txt(cfg.get("workload_short") or cfg.get("workload", ""), 200)}, **c)
+    for k, n in (("sampler_form", 140), ("preconditioning", 140), ("collective", 60), ("rehearsal", 90), ("note", 120)):
+        if (cfg.get(k + "_short") or cfg.get(k)) and cfg.get(k) != "none":
+            c[k] = _txt(cfg.get(k + "_short") or cfg[k], n)
+    if cfg.get("collective_fallback_from"):
+        c["collective_fallback_from"] = [_txt(t, 80) for t in cfg["collective_fallback_from"][:3]]
+    out["config"] = c
+    for k in ("half_step_us", "kernel_avg_us", "acceptance_fraction"):
+        if k in full:
+            out[k] = _num(full[k])
+    r = full.get("roofline")
+    if isinstance(r, dict):
+        o = _pick(r, ("bound",))
+        o["kernel"] = _txt(r.get("kernel_short") or r.get("kernel", ""), 80)
+        o.update(_pick(r, ("achieved", "peak", "unit", "frac")))
+        if isinstance(r.get("counted"), dict):
+            o["counted_frac"] = _num(r["counted"].get("frac"))
+        o.update(_pick(r, ("valu_issue_frac", "traffic", "launch_slot_us")))
+        if r.get("counters_source"):
+            o["counters_source"] = _txt(r["counters_source"], 60)
+        if r.get("definition"):
+            o["definition"] = "90 flop x NQ x walkers / half_step_us (SURVEY 8d ii)"
+        if r.get("error"):
+            o["error"] = _txt(r["error"], 160)
+        if r.get("note") and o.get("frac") is None:
+            o["note"] = _txt(r["note"], 100)
+        out["roofline"] = o
+    h = full.get("roofline_hbm")
+    if isinstance(h, dict):
+        out["roofline_hbm"] = _pick(h, ("achieved", "peak", "unit", "frac", "traffic_ratio"))
+    b = full.get("boundary_M1")
+    if isinstance(b, dict):
+        out["boundary_M1"] = _pick(b, ("rows", "p50_us", "p90_us", "evals_per_s", "launch_per_call_p50_us"))
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        o = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_value"))
+        o["sample"] = _txt(cb.get("sample_short") or cb.get("sample", ""), 80)
+        out["cpu_baseline"] = o
+    if "parity_max_err_vs_oracle" in full:
+        out["parity_max_err_vs_oracle"] = _num(full["parity_max_err_vs_oracle"], 3)
+    if isinstance(full.get("cfg5"), dict):          # BASELINE.json configs[4] asks for its roofline fraction
+        o = _pick(full["cfg5"], ("kernel_ms", "evals_per_s"))
+        if isinstance(full["cfg5"].get("roofline"), dict):
+            o["counted_frac"] = _num(full["cfg5"]["roofline"].get("frac"))
+        out["cfg5"] = o
+    # N > 1: one word per exchange (what the outcomes mean: DESIGN.md section 6), the sharded boundary's medians
+    ev = full.get("exchange_validation")
+    if isinstance(ev, dict):
+        out["exchange_validation"] = {_txt(m, 16): ("ok" if v.get("ok") else _txt(v.get("why", "failed"), 70)) if isinstance(v, dict) else _txt(v, 70)
+                                      for m, v in list(ev.items())[:4]}
+    sb = full.get("boundary_sharded")
+    if isinstance(sb, dict):
+        o = {"ok": _num(sb.get("ok"))}
+        if not sb.get("ok"):
+            o["why"] = _txt(sb.get("why", ""), 90)
+        o.update({_txt(k, 12): _num(v.get("median_us"), 5) for k, v in list(sb.items())[:8] if k.startswith("rows_") and isinstance(v, dict)})
+        out["boundary_sharded"] = o
+    for k in ("ranks_agree", "valid_for_scaling", "supervisor_timeout", "supervisor_deadline_s", "collective_hung"):
+        if k in full:
+            out[k] = _num(full[k])
+    if "ranks_ended_badly" in full:
+        out["ranks_ended_badly"] = {_txt(k, 8): _num(v) for k, v in list(full["ranks_ended_badly"].items())[:8]}
+    for k, n in (("error", 300), ("extras_error", 160), ("invalid", 120), ("collective", 160), ("hang", 100)):
+        if full.get(k):
+            out[k] = _txt(full[k], n)
+    out["full"] = _txt(os.path.relpath(FULL_PATH, ROOT), 100)
+    return out
+
+
 def emit(obj):
+    """Rank-to-supervisor traffic (a pipe, never the driver's stdout): anything goes."""
     print(json.dumps(obj), flush=True)
+
+
+def emit_final(full):
+    """What the driver reads: everything measured goes to the side file gpurun_out/bench_full.json, the short
+    line -- strict JSON, one line, below LINE_LIMIT bytes -- is the last thing on stdout."""
+    try:
+        os.makedirs(os.path.dirname(FULL_PATH), exist_ok=True)
+        with open(FULL_PATH + ".tmp", "w") as f:
+            json.dump(full, f, indent=1, default=str)
+        os.replace(FULL_PATH + ".tmp", FULL_PATH)
+    except OSError as e:
+        sys.stderr.write("bench.py: cannot write %s: %r\n" % (FULL_PATH, e))
+    line = json.dumps(short_line(full), allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) >= LINE_LIMIT:      # (cannot happen: every field above is bounded; never print a long line)
+        keep = short_line({k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "error")})
+        keep["line_cut"] = True
+        line = json.dumps(keep, allow_nan=False, separators=(",", ":"))
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
+def emit_line(full):
+    """The main line: to the supervisor whole (it prints the short one), to the driver short."""
+    if os.environ.get("MBB_BENCH_WORKER") == "1":
+        emit(full)
+    else:
+        emit_final(full)
 
 
 def parse_args(argv=None):
@@ -555,6 +698,8 @@ def base_line(args, world):
             "config": {"workload": "cfg2/cfg3: 8-band PACS+SPIRE+SCUBA2_850+Bolocam passband integration "
                                    "(NQ=2209), thick+alpha, one ensemble of 250 walkers per GPU advanced by "
                                    "the device-resident stretch move, two dependent half-steps per step",
+                       "workload_short": "cfg2/cfg3: 8 passbands (NQ 2209) with full response integration, thick+alpha, 250 walkers "
+                                         "per GPU, device-resident stretch move; 1 step = 2 dependent half-steps",
                        "walkers_per_gpu": NW_PER_GPU, "walkers": NW_PER_GPU * world, "bands": 8,
                        "nq": 2209, "half_steps_per_step": 2}}
 
@@ -584,10 +729,10 @@ def supervise(args):
     base = base_line(args, world)
     if args.gpus != world:
         if my_rank == 0:
-            emit(dict(base, error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)))
+            emit_final(dict(base, error="--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)))
         return 2
     if world < 1 or world > 64:
-        emit(dict(base, error="--gpus %d: not a rank count" % args.gpus))
+        emit_final(dict(base, error="--gpus %d: not a rank count" % args.gpus))
         return 2
     ranks = [my_rank] if launched else list(range(world))
     # The whole run -- ranks started, exchanges tried, line printed -- has to fit the driver's limit for one
@@ -612,7 +757,7 @@ def supervise(args):
         except OSError as e:
             for pr in procs.values():
                 pr.kill()
-            emit(dict(base, error="cannot start rank %d: %r" % (r, e)))
+            emit_final(dict(base, error="cannot start rank %d: %r" % (r, e)))
             return 2
 
     def collect(pipe):
@@ -685,7 +830,7 @@ def supervise(args):
         main_line["supervisor_deadline_s"] = budget
         if main_line.get("value") is None and "error" not in main_line:
             main_line["error"] = "the ranks were ended at the supervisor's deadline of %.0f s before a run was validated" % budget
-    emit(main_line)
+    emit_final(main_line)
     return worst
 
 
@@ -694,9 +839,20 @@ def fake_worker(args, how):
     told, so that the supervisor's collecting, merging, waiting and ending of ranks can be tested without a GPU."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if rank == 0 and "noline" not in how:
-        emit(dict(base_line(args, world), value=1.0e6 * world, ms_per_step=1.0))
-    if rank == 0 and "part" in how:
+        line = dict(base_line(args, world), value=1.0e6 * world, ms_per_step=1.0)
+        if "full" in how:
+            # every leg populated: round 4's whole line (20.7 KB, the one the driver could not parse)
+            line = dict(json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_v5.json"))), **line)
+        emit_line(line)
+    under_supervisor = os.environ.get("MBB_BENCH_WORKER") == "1"       # (a one-GPU run has no parts)
+    if rank == 0 and "part" in how and under_supervisor:
         emit({"_part": "exchange_validation", "data": {"rccl": {"ok": True, "us_per_step": 20.0}}})
+    if rank == 0 and "full" in how and under_supervisor:
+        long_why = "rehearsal: the ranks' copies of the ensemble differ after 60 steps " * 20
+        emit({"_part": "exchange_validation", "data": {"ipc": {"ok": False, "why": long_why}, "ipc-launches": {"ok": True, "us_per_step": 30.0, "why": long_why},
+                                                       "rccl": {"ok": True, "us_per_step": 20.0, "steps": 500, "kernel_form": 1, "why": long_why}}})
+        emit({"_part": "boundary_sharded", "data": {"ok": True, "what": long_why, "rows_%d" % (125 * world): {"median_us": 31.123456789, "p90_us": 40.0, "calls": 200},
+                                                    "rows_%d" % (250 * world): {"median_us": 35.123456789, "p90_us": 45.0, "calls": 200}}})
     if rank == 1 and "crash1" in how:
         os._exit(7)
     if rank == 1 and "hang1" in how:
@@ -711,7 +867,8 @@ def fake_worker(args, how):
 
 def main():
     args = parse_args()
-    if os.environ.get("MBB_BENCH_FAKE_WORKER") and os.environ.get("MBB_BENCH_WORKER") == "1":
+    if os.environ.get("MBB_BENCH_FAKE_WORKER") and (os.environ.get("MBB_BENCH_WORKER") == "1" or
+                                                    (args.gpus == 1 and os.environ.get("MBB_BENCH_WORKER_FAKE_TOP"))):
         sys.exit(fake_worker(args, os.environ["MBB_BENCH_FAKE_WORKER"]))
     if os.environ.get("MBB_BENCH_WORKER") == "1" or (args.gpus == 1 and "WORLD_SIZE" not in os.environ):
         return worker(args)
@@ -768,7 +925,7 @@ def worker(args):
         if rank == 0:
             out = dict(base)
             out.update(kw)
-            emit(out)
+            emit_line(out)
         sys.stdout.flush()
         os._exit(code)          # a wedged stream would also hang interpreter teardown
 
@@ -1087,9 +1244,11 @@ def worker_body(args, rank, world, local_rank, base, fail):
         if world > 1:
             out["config"]["preconditioning"] = ("%d untimed steps of the same sharded sampler before the W warm-up steps: the GPUs' "
                                                 "clocks" % run.get("pre_steps", 0))
+            out["config"]["preconditioning_short"] = "%d untimed steps of the same sampler before warm-up (clocks)" % run.get("pre_steps", 0)
         if world == 1:
             out["config"]["preconditioning"] = ("%.0f ms of sampler steps on a scratch ensemble right before the W warm-up steps: "
                                                 "the GPU's clocks, not the chain that is timed" % (PRECONDITION_S * 1e3))
+            out["config"]["preconditioning_short"] = "%.0f ms of scratch-ensemble steps before the W warm-up steps (GPU clocks)" % (PRECONDITION_S * 1e3)
         if form in (6,) + ONE_LAUNCH_FORMS:
             nlaunch = (args.steps + 4095) // 4096
             if form == 7:
@@ -1115,25 +1274,29 @@ def worker_body(args, rank, world, local_rank, base, fail):
             out["config"]["sampler_form"] = "one launch per half-step (k_lnlike SMODE %d)" % form
             out["kernel_avg_us"] = k_us
         out["half_step_us"] = k_us
+        short_kern = ({7: "k_flowm", 8: "k_flowr", 9: "k_flowa"}.get(form, "k_lnlike") + "<thick,alpha,%sform %d> %d workgroups x %d threads"
+                      % ("staged," if run["staged"] else "", form, ctx.info("last_grid"), ctx.info("last_threads")))
+        out["config"]["sampler_form_short"] = ("form %d: %s" % (form, "one launch per <=4096 steps" if form in (6,) + ONE_LAUNCH_FORMS
+                                                                  else "one launch per half-step"))
         if world == 1 and not args.no_extras:
             # (whatever goes wrong beside the timed region is said on the line; it does not take the
             # measured value with it)
             try:
                 out.update(extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form,
-                                  pairs=run["pairs"], staged=run["staged"], partial=out))
+                                  pairs=run["pairs"], staged=run["staged"], partial=out, kern_short=short_kern))
             except Exception as e:           # noqa
                 import traceback
                 traceback.print_exc()
                 out["extras_error"] = "%s: %s" % (type(e).__name__, e)
         elif world > 1:
             alg_bytes = 48.0 * half + 16.0 * nq + 16.0 * nb
-            out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "achieved": None,
+            out["roofline"] = {"bound": "fp64-valu", "kernel": kern_label, "kernel_short": short_kern, "achieved": None,
                                "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                                "note": "launch slot = kernel + exchange at N > 1; the roofline is reported at N = 1",
                                "launch_slot_us": k_us,
                                "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                                        "achieved_GBps": alg_bytes / (k_us * 1e-6) / 1e9, "peak_GBps": HBM_PEAK_GBS}}
-        emit(out)               # (N > 1: held by the supervisor until this process has ended)
+        emit_line(out)          # (N > 1: held by the supervisor until this process has ended)
     barrier()
     smp = None
     run["smp"] = None
@@ -1282,7 +1445,7 @@ def sharded_boundary(ctx, like, rank, world, allw, nwt, barrier, all_ok, bcast, 
     return res
 
 
-def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True, partial=None):
+def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True, partial=None, kern_short=None):
     """Everything on the line besides the timed region (rank 0, one GPU).  `partial`: the caller's line, filled in
     leg by leg, so that what was measured before a leg failed is kept."""
     import mbb_emcee_amd as mbb
@@ -1426,6 +1589,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
 
     roof, hbm = dominant_kernel_roofline(form, pairs, staged, k_us, args.steps, kern_label, nq, nb, half)
     roof["kernel_avg_us"] = k_us
+    roof["kernel_short"] = kern_short
     roof["sample_arithmetic"] = arith
     roof["why_far_below"] = ("a half-step of 125 walkers is a chain of latencies, not a stream: constructor (one dependent chain of "
                              "fp64 transcendentals on 16 lanes), quadrature (12 chunks of samples per SIMD, three dependent LDS "

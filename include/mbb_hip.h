@@ -109,6 +109,11 @@ int mbb_lnlike_batch(mbb_ctx *ctx, const double *pars, int n, double *lnl,
  * modified_blackbody.py:219-224, :294-316); rows below a lower limit are -inf with status 1, as ever. */
 int mbb_boundary_buffers(mbb_ctx *ctx, int nmax, double **in, double **out, int32_t **status);
 int mbb_lnlike_call(mbb_ctx *ctx, int n);
+/* The address of a word that lives as long as the context and changes whenever the blocks mbb_boundary_buffers
+ * handed out are freed (ANY entry point of the context asked to hold more rows than they do: mbb_lnlike_batch,
+ * mbb_lnlike_allgather, ...).  A binding that caches the addresses reads the word right after mbb_boundary_buffers
+ * and compares it BEFORE every write through them; a different value means: ask for the buffers again. */
+const unsigned long long *mbb_boundary_generation(mbb_ctx *ctx);
 
 /* Same computation on device-resident buffers, enqueued on the context's
  * stream, asynchronous.  d_model_flux / d_status may be NULL. */

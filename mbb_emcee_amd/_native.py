@@ -33,6 +33,7 @@ SIGNATURES = {
     "mbb_lnlike_batch": (C.c_int, [_vp, _dp, C.c_int, _dp, _ip, _dp]),
     "mbb_boundary_buffers": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "mbb_lnlike_call": (C.c_int, [_vp, C.c_int]),
+    "mbb_boundary_generation": (_vp, [_vp]),
     "mbb_lnlike_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
     "mbb_lnlike_repeat_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int]),
     "mbb_roof_probe": (C.c_int, [_vp, _dp, C.c_int, _dp, _dp, _dp]),
@@ -240,7 +241,9 @@ class Context(object):
     def boundary_views(self, nmax):
         """numpy views of the blocks the boundary call works on (mbb_boundary_buffers): `rows` [cap, 5] -- write
         parameter rows straight into it (device memory behind the BAR where there is one) -- and `lnl` [cap],
-        `status` [cap], pinned memory the kernel writes.  Valid until a later call asks for more rows."""
+        `status` [cap], pinned memory the kernel writes.  Valid until ANY call on the context needs more rows than
+        they hold (the native side then frees them): `gen`, a one-element view of the context's generation word
+        (mbb_boundary_generation), holds `gen0` exactly as long as they are -- compare before writing through them."""
         cap = 256
         while cap < nmax:
             cap *= 2
@@ -249,7 +252,8 @@ class Context(object):
         rows = np.ctypeslib.as_array(C.cast(pin, _dp), shape=(cap, 5))
         lnl = np.ctypeslib.as_array(C.cast(pout, _dp), shape=(cap,))
         st = np.ctypeslib.as_array(C.cast(pst, _ip), shape=(cap,))
-        return cap, rows, lnl, st
+        gen = np.ctypeslib.as_array(C.cast(self.lib.mbb_boundary_generation(self.h), C.POINTER(C.c_uint64)), shape=(1,))
+        return cap, rows, lnl, st, gen, int(gen[0])
 
     def lnlike_batch_device(self, d_pars, n, d_lnl, d_status=None, d_flux=None):
         _check(self.lib.mbb_lnlike_batch_device(

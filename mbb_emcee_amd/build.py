@@ -100,10 +100,12 @@ def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
         tmp = "%s.tmp.%d" % (target, os.getpid())
         subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] +
                               [obj for _, obj, _ in jobs] + ["-ldl"])
+        # the library first, then the note of its flags: a process that dies in between leaves a NEW library beside an OLD
+        # note -- at worst a mismatch, i.e. one more build, never an old library passed off as built with the new flags
+        os.replace(tmp, target)
         with open(target + ".flags.tmp.%d" % os.getpid(), "w") as f:
             f.write(flags_tag(extra_flags))
         os.replace(f.name, target + ".flags")
-        os.replace(tmp, target)
     return target
 
 
@@ -111,15 +113,31 @@ SRC_FAST = os.path.join(HERE, "csrc", "mbb_fastcall.c")
 FAST = os.path.join(HERE, "_mbbfast.so")
 
 
+def fastcall_is_current(abi=None):
+    """Is the built `_mbbfast` extension this interpreter's and this numpy's, and not older than its source?"""
+    import sysconfig
+    try:
+        if abi is None:
+            import numpy
+            abi = "%s | numpy %s" % (sysconfig.get_config_var("EXT_SUFFIX") or sys.version, numpy.__version__)
+        return (os.path.exists(FAST) and os.path.getmtime(FAST) >= os.path.getmtime(SRC_FAST)
+                and open(FAST + ".abi").read() == abi)
+    except Exception:           # noqa
+        return False
+
+
 def build_fastcall(force=False):
     """Builds the CPython extension `_mbbfast` (csrc/mbb_fastcall.c: likelihood.__call__'s boundary call as one C-level
     callable) with the host compiler and returns its path, or None when that is not possible here (no compiler, no
     Python or numpy headers): the likelihood then makes the same call through numpy and ctypes."""
     import sysconfig
-    if not force and os.path.exists(FAST) and os.path.getmtime(FAST) >= os.path.getmtime(SRC_FAST):
-        return FAST
     try:
         import numpy
+        # the extension is good for the interpreter and the numpy C-API it was compiled against: both are noted beside it
+        # (`_mbbfast.so.abi`) and another Python or numpy in the same checkout builds it anew instead of loading it
+        abi = "%s | numpy %s" % (sysconfig.get_config_var("EXT_SUFFIX") or sys.version, numpy.__version__)
+        if not force and fastcall_is_current(abi):
+            return FAST
         cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
         if not cc:
             return None
@@ -127,6 +145,9 @@ def build_fastcall(force=False):
         subprocess.check_call([cc, "-O2", "-fPIC", "-shared", "-I" + sysconfig.get_paths()["include"], "-I" + numpy.get_include(),
                                SRC_FAST, "-o", tmp], stderr=subprocess.DEVNULL)
         os.replace(tmp, FAST)
+        with open(FAST + ".abi.tmp.%d" % os.getpid(), "w") as f:
+            f.write(abi)
+        os.replace(f.name, FAST + ".abi")
         return FAST
     except Exception:           # noqa -- an optional accelerator of the host glue, never a reason to fail a build
         return None

@@ -26,6 +26,8 @@ typedef struct {
     double *rows;          /* [cap][5]: where the kernel reads its parameter rows from */
     const double *lnl;     /* [cap]: where it writes lnprob (pinned host memory) */
     Py_ssize_t cap;
+    const volatile unsigned long long *gen;   /* mbb_boundary_generation: changes when the two blocks are freed ... */
+    unsigned long long gen0;                  /* ... and what it held when their addresses were taken */
 } FastCall;
 
 static PyObject *fastcall_vectorcall(PyObject *self, PyObject *const *args, size_t nargsf, PyObject *kwnames)
@@ -45,12 +47,15 @@ static PyObject *fastcall_vectorcall(PyObject *self, PyObject *const *args, size
     else if (nd == 1 && PyArray_DIM(a, 0) == 5) n = 1;
     else Py_RETURN_NONE;
     if (n > f->cap) Py_RETURN_NONE;
+    /* another entry point of the context may have made the blocks anew since (more rows than they held): never write
+     * through stale addresses -- None sends likelihood.__call__ to ask for the buffers again */
+    if (*f->gen != f->gen0) Py_RETURN_NONE;
     memcpy(f->rows, PyArray_DATA(a), (size_t)n * 5 * sizeof(double));
     int rc;
     Py_BEGIN_ALLOW_THREADS
     rc = f->fn(f->ctx, (int)n);
     Py_END_ALLOW_THREADS
-    if (rc != 0) Py_RETURN_NONE;
+    if (rc != 0 || *f->gen != f->gen0) Py_RETURN_NONE;
     if (nd == 1) return PyFloat_FromDouble(f->lnl[0]);
     PyObject *out = PyArray_SimpleNew(1, &n, NPY_DOUBLE);
     if (!out) return NULL;
@@ -61,14 +66,15 @@ static PyObject *fastcall_vectorcall(PyObject *self, PyObject *const *args, size
 static int fastcall_init(PyObject *self, PyObject *args, PyObject *kwds)
 {
     FastCall *f = (FastCall *)self;
-    unsigned long long fn = 0, ctx = 0, rows = 0, lnl = 0;
+    unsigned long long fn = 0, ctx = 0, rows = 0, lnl = 0, gen = 0, gen0 = 0;
     Py_ssize_t cap = 0;
-    static char *names[] = {"fn", "ctx", "rows", "lnl", "cap", NULL};
-    if (!PyArg_ParseTupleAndKeywords(args, kwds, "KKKKn", names, &fn, &ctx, &rows, &lnl, &cap)) return -1;
-    if (!fn || !ctx || !rows || !lnl || cap <= 0) {
-        PyErr_SetString(PyExc_ValueError, "FastCall needs the addresses of mbb_lnlike_call, the context and the two blocks");
+    static char *names[] = {"fn", "ctx", "rows", "lnl", "cap", "gen", "gen0", NULL};
+    if (!PyArg_ParseTupleAndKeywords(args, kwds, "KKKKnKK", names, &fn, &ctx, &rows, &lnl, &cap, &gen, &gen0)) return -1;
+    if (!fn || !ctx || !rows || !lnl || cap <= 0 || !gen) {
+        PyErr_SetString(PyExc_ValueError, "FastCall needs the addresses of mbb_lnlike_call, the context, the two blocks and their generation word");
         return -1;
     }
+    f->gen = (const volatile unsigned long long *)(uintptr_t)gen; f->gen0 = gen0;
     f->fn = (call_fn)(uintptr_t)fn; f->ctx = (void *)(uintptr_t)ctx;
     f->rows = (double *)(uintptr_t)rows; f->lnl = (const double *)(uintptr_t)lnl; f->cap = cap;
     f->vectorcall = fastcall_vectorcall;
@@ -80,7 +86,7 @@ static PyTypeObject FastCallType = {
     .tp_name = "_mbbfast.FastCall",
     .tp_basicsize = sizeof(FastCall),
     .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL,
-    .tp_doc = "FastCall(fn, ctx, rows, lnl, cap)(pars) -> float64[n] | float | None (None: take the general path)",
+    .tp_doc = "FastCall(fn, ctx, rows, lnl, cap, gen, gen0)(pars) -> float64[n] | float | None (None: take the general path)",
     .tp_new = PyType_GenericNew,
     .tp_init = fastcall_init,
     .tp_call = PyVectorcall_Call,

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mbb_hip.h"
@@ -207,6 +208,13 @@ struct mbb_ctx {
     double *h_srv = nullptr, *dv_srv = nullptr;   // pinned: a server's result records [row]{lnl, status as a 64-bit integer}
     size_t srv_cap = 0;
     unsigned long long *h_gone = nullptr;     // pinned: the number of the last request a server saw before it left (0: still there)
+    // The serve state below is a context's own -- except that a SIBLING context coming to the device tells this one's
+    // server to leave (yield_server), possibly from another thread (ctypes and the _mbbfast extension release the GIL).
+    // srv_mu guards it: held by the owner for the whole of mbb_lnlike_call and of use(), taken by a visitor (try_lock
+    // under g_dev_mutex, so that a context cannot be destroyed between being found and being locked) around serve_stop.
+    // Lock order: ctx.srv_mu, then g_dev_mutex; a thread waits for another context's srv_mu only while its own context
+    // is NOT the device's server, and the server's owner never waits for a sibling: no cycle.
+    std::mutex srv_mu;
     bool serving = false;
     unsigned long long srv_seq = 0;           // requests so far (the doorbell word is request number << 16 | rows)
     int srv_hot = 0;                          // boundary calls in a row with nothing else in between
@@ -221,6 +229,7 @@ struct mbb_ctx {
     long opt_serve_after = 3;                 // boundary calls in a row before a server is started
     long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (~1 us per poll)
     long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
+    unsigned long long buf_gen = 1;   // mbb_boundary_generation: bumped whenever the blocks below are freed and made anew
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
     hipFunction_t mod_fn[64] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 16 k_flowr / k_flowa)
@@ -307,6 +316,7 @@ static int use(mbb_ctx *c)
 {
     if (!c) return fail(MBB_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> own(c->srv_mu);
     c->srv_hot = 0;
     if (c->serving) return serve_stop(c);
     return yield_server(c);
@@ -335,23 +345,36 @@ static DeviceStatics g_dev[64];
 
 // Another context of this process has a server resident on c's device: it holds the CUs, so whatever c is about to put on
 // its stream would wait for it -- it is told to leave first (and starts again after its own next few calls in a row).
+// Called with c->srv_mu held and c NOT serving.
 static int yield_server(mbb_ctx *c)
 {
     if (c->device < 0 || c->device >= 64) return MBB_OK;
-    mbb_ctx *o;
-    {
-        std::lock_guard<std::mutex> lk(g_dev_mutex);
-        o = g_dev[c->device].server;
-        if (g_dev[c->device].last_user != c) {
-            // (another context was here in between: this one's boundary calls are not "in a row" any more)
-            g_dev[c->device].last_user = c;
-            c->srv_hot = 0;
+    for (long tries = 0;; ++tries) {
+        mbb_ctx *o;
+        {
+            std::lock_guard<std::mutex> lk(g_dev_mutex);
+            o = g_dev[c->device].server;
+            if (g_dev[c->device].last_user != c) {
+                // (another context was here in between: this one's boundary calls are not "in a row" any more)
+                g_dev[c->device].last_user = c;
+                c->srv_hot = 0;
+            }
+            if (!o || o == c) return MBB_OK;
+            // found and locked inside one critical section: mbb_ctx_destroy takes the server's name off the device
+            // under g_dev_mutex after its own serve_stop, so `o` is alive here and stays so while its srv_mu is held
+            if (!o->srv_mu.try_lock()) o = nullptr;
         }
+        if (!o) {
+            // its owner is inside a call (at most the serve budget, ~0.4 ms): come back
+            if ((tries & 15) == 15) std::this_thread::yield(); else __builtin_ia32_pause();
+            continue;
+        }
+        std::lock_guard<std::mutex> theirs(o->srv_mu, std::adopt_lock);
+        if (!o->serving) return MBB_OK;            // (it left by itself, or its owner sent it away, in between)
+        o->srv_hot = 0;
+        o->srv_need = std::min<long>(64, 2 * (o->srv_need > 0 ? o->srv_need : o->opt_serve_after));
+        return serve_stop(o);
     }
-    if (!o || o == c) return MBB_OK;
-    o->srv_hot = 0;
-    o->srv_need = std::min<long>(64, 2 * (o->srv_need > 0 ? o->srv_need : o->opt_serve_after));
-    return serve_stop(o);
 }
 
 extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
@@ -412,7 +435,11 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->serving) (void)serve_stop(c);
+    {
+        // (a sibling's visit -- yield_server on another thread -- is either over or has not found this context yet)
+        std::lock_guard<std::mutex> own(c->srv_mu);
+        if (c->serving) (void)serve_stop(c);
+    }
     if (c->device >= 0 && c->device < 64) {
         --g_dev[c->device].live;
         std::lock_guard<std::mutex> lk(g_dev_mutex);
@@ -591,6 +618,8 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
         size_t cap = c->cap ? c->cap : 256;
         while (cap < n) cap *= 2;
         HIPCHK(hipStreamSynchronize(c->stream));
+        // whoever holds addresses from mbb_boundary_buffers must see this BEFORE it writes through them again
+        __atomic_store_n(&c->buf_gen, c->buf_gen + 1, __ATOMIC_RELEASE);
         free_dev(c->d_pars); free_dev(c->d_lnl); free_dev(c->d_status);
         free_host(c->h_pars); free_host(c->h_lnl); free_host(c->h_status);
         c->d_pars = c->d_lnl = nullptr; c->d_status = nullptr;
@@ -1098,6 +1127,11 @@ extern "C" int mbb_lnlike_batch(mbb_ctx *c, const double *pars, int n, double *l
 // to; mbb_lnlike_call then evaluates the first n rows of that block: no pointer arguments, no memcpy on either
 // side, the row status looked through here.  The addresses hold until a call asks for more rows than `nmax`
 // (ask again then) or the context is destroyed.
+extern "C" const unsigned long long *mbb_boundary_generation(mbb_ctx *c)
+{
+    return c ? &c->buf_gen : nullptr;
+}
+
 extern "C" int mbb_boundary_buffers(mbb_ctx *c, int nmax, double **in, double **out, int32_t **status)
 {
     int rc = use(c);
@@ -1114,6 +1148,7 @@ extern "C" int mbb_boundary_buffers(mbb_ctx *c, int nmax, double **in, double **
 
 // ---- the served boundary ----------------------------------------------------------------------------------------
 // (see mbb_serve.hip.h for what it is and why)
+// Called with c->srv_mu held (by c's owner, or by a visiting sibling: yield_server).
 static int serve_stop(mbb_ctx *c)
 {
     if (!c->serving) return MBB_OK;
@@ -1275,6 +1310,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
 {
     if (!c) return fail(MBB_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));               // (not use(): a resident server stays, the streak of calls goes on)
+    std::lock_guard<std::mutex> own(c->srv_mu);    // (uncontended: ~20 ns; a sibling's visit waits for the call to end)
     int rc;
     if (n <= 0) return n == 0 ? MBB_OK : fail(MBB_ERR_ARG, "bad row count");
     if (c->nb <= 0) return fail(MBB_ERR_STATE, "bands not set (mbb_set_bands)");
@@ -2149,6 +2185,7 @@ extern "C" int mbb_stamps(mbb_ctx *c, unsigned long long *host, int nblocks)
 extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
 {
     if (!c || !name) return fail(MBB_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> own(c->srv_mu);
     if (c->serving) {                               // (a resident server runs with the options of its launch)
         HIPCHK(hipSetDevice(c->device));
         int rc = serve_stop(c);

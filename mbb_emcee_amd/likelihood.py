@@ -18,8 +18,11 @@ import numpy as np
 
 from . import _native
 try:                                    # (optional: the boundary call in C, built by mbb_emcee_amd.build.build_fastcall)
+    from .build import fastcall_is_current as _fc_ok
+    if not _fc_ok():                    # (built for another Python / numpy, or older than its source: not loaded)
+        raise ImportError("_mbbfast is not this interpreter's")
     from . import _mbbfast
-except ImportError:
+except Exception:                       # noqa -- never a reason to fail: the same call goes through numpy and ctypes
     _mbbfast = None
 from .modified_blackbody import modified_blackbody, um_to_GHz
 from .response import response_set, special_types, read_table
@@ -27,14 +30,15 @@ from .response import response_set, special_types, read_table
 __all__ = ["likelihood"]
 
 
-def _fastcall(ctx, rows, lnl, cap):
+def _fastcall(ctx, rows, lnl, cap, gen, gen0):
     """The boundary call as one C-level callable (the `_mbbfast` extension, mbb_emcee_amd/csrc/mbb_fastcall.c), or None
     where it is not built or the native entry has been replaced by something else (a test's wrapper)."""
     raw = ctx._lnlike_call_raw
     if _mbbfast is None or not isinstance(raw, C._CFuncPtr):
         return None
     try:
-        return _mbbfast.FastCall(C.cast(raw, C.c_void_p).value, ctx.h.value, rows.ctypes.data, lnl.ctypes.data, cap)
+        return _mbbfast.FastCall(C.cast(raw, C.c_void_p).value, ctx.h.value, rows.ctypes.data, lnl.ctypes.data, cap,
+                                 gen.ctypes.data, gen0)
     except Exception:           # noqa
         return None
 
@@ -341,9 +345,13 @@ class likelihood(object):
         One native call when the capacity has to grow, a dictionary look-up afterwards."""
         ctx = self._sync_device()
         f = self._fast
-        if f is None or n > f[3] or f[6] is not ctx:
-            cap, rows, lnl, st = ctx.boundary_views(n)
-            self._fast = f = (ctx._lnlike_call_raw, ctx.h.value, {}, cap, rows, lnl, ctx, _fastcall(ctx, rows, lnl, cap))
+        # (f[8][0] != f[9]: some other call on the context -- model_flux of a chain, a list of rows through the general
+        # path, a sharded evaluation -- needed more rows than the blocks held and the native side made them anew: the
+        # views are of freed memory and must never be written through again)
+        if f is None or n > f[3] or f[6] is not ctx or f[8][0] != f[9]:
+            cap, rows, lnl, st, gen, gen0 = ctx.boundary_views(n)
+            self._fast = f = (ctx._lnlike_call_raw, ctx.h.value, {}, cap, rows, lnl, ctx,
+                              _fastcall(ctx, rows, lnl, cap, gen, gen0), gen, gen0)
         if len(f[2]) > 64:
             f[2].clear()
         v = f[2][n] = (f[4][:n], f[5][:n])
@@ -368,6 +376,8 @@ class likelihood(object):
                 r = f[7](pars)
                 if r is not None:
                     return r
+            if f is not None and f[8][0] != f[9]:
+                self._fast = f = None           # the blocks were made anew under the cached views (see _fast_views)
             if pars.ndim == 2 and pars.shape[1] == 5 and pars.shape[0] > 0:
                 n = pars.shape[0]
                 v = f[2].get(n) if f is not None else None

@@ -378,6 +378,17 @@ class response(object):
 _BUILTIN_WHEEL = {}
 
 
+def _own_arrays(resp, freeze=False):
+    """A copy of a passband object whose ndarray attributes are copies too (read-only ones when `freeze`)."""
+    new = copy.copy(resp)
+    for k, v in list(vars(new).items()):
+        if isinstance(v, np.ndarray):
+            w = v.copy()
+            w.setflags(write=not freeze)
+            setattr(new, k, w)
+    return new
+
+
 class response_set(object):
     """A named set of passbands -- the filter wheel (response.py:642-840)."""
 
@@ -402,24 +413,19 @@ class response_set(object):
                 raise IOError("No data read from {:s}".format(inputfile))
         self._responses.clear()
         if inputfile is None and _BUILTIN_WHEEL:
-            # the built-in wheel is set up once per process (18 curves: 3 ms) and handed out as shallow copies --
-            # setup() replaces a passband's arrays, it never writes into them
+            # the built-in wheel is set up once per process (18 curves: 3 ms); every wheel gets arrays of its own, writable,
+            # as in the reference (response.py:252-332) -- copies of the frozen master's, a few hundred KB
             for name, resp in _BUILTIN_WHEEL.items():
-                self._responses[name] = copy.copy(resp)
+                self._responses[name] = _own_arrays(resp)
             return
         for r in rows:
             self.add(str(r[0]), str(r[1]), str(r[2]).lower(), str(r[3]).lower(),
                      str(r[4]).lower(), str(r[5]).lower(), float(r[6]), float(r[7]),
                      dir=indir)
         if inputfile is None:
-            # the arrays the shallow copies share are frozen: `rs[name].response[:] *= k` on one wheel raises
-            # instead of silently changing every later wheel of the process (the reference gives each wheel
-            # arrays of its own, response.py:252-332)
-            for resp in self._responses.values():
-                for v in vars(resp).values():
-                    if isinstance(v, np.ndarray):
-                        v.setflags(write=False)
-            _BUILTIN_WHEEL.update((name, copy.copy(resp)) for name, resp in self._responses.items())
+            # the master keeps frozen copies of its own: what a user does to the arrays of THIS wheel (the reference's
+            # pattern `rs[name].response[:] *= k` works on it) never reaches a later wheel of the process
+            _BUILTIN_WHEEL.update((name, _own_arrays(resp, freeze=True)) for name, resp in self._responses.items())
 
     def add(self, name, spec, xtype, xunits, senstype, normtype, xnorm, normparam, dir=None):
         resp = response(name)

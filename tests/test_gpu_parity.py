@@ -607,7 +607,9 @@ def test_bench_with_two_ranks_sharing_this_gpu():
     one-launch exchange every workgroup of both ranks resident: neither is possible here, and the line says so.)"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MBB_BENCH_WALKERS_PER_GPU="32")
+    import tempfile
+    side = os.path.join(tempfile.mkdtemp(), "bench_full.json")
+    env = dict(os.environ, MBB_BENCH_WALKERS_PER_GPU="32", MBB_BENCH_FULL=side)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
                           "--oversubscribe"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -616,8 +618,14 @@ def test_bench_with_two_ranks_sharing_this_gpu():
     assert d["n_gpus"] == 2 and d["value"] and d["value"] > 0 and d["ranks_agree"] is True, d
     assert d["valid_for_scaling"] is False and "rehearsal" in d["config"]["note"]
     assert "2000 untimed steps" in d["config"]["preconditioning"] and "rehearsal" in d["config"]
+    # the line is the short one (below 4 KB: one word per exchange), the detail is in the side file
+    assert len(lines[0]) < 4096
     ev = d["exchange_validation"]
+    assert ev["ipc-launches"] == "ok" and ev["rccl"].startswith("skipped") and ev["ipc"].startswith("skipped"), ev
+    full = json.load(open(side))
+    ev = full["exchange_validation"]
     assert ev["ipc-launches"]["ok"] is True and ev["rccl"]["ok"] is None and ev["ipc"]["ok"] is None, ev
+    assert ev["ipc-launches"]["us_per_step"] > 0 and full["value"] == pytest.approx(d["value"], rel=1e-5)
 
 
 # --------------------------------------------- batched multi-source mode (cfg5)
@@ -1074,7 +1082,7 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
         fc = like._fast[7]
         assert fc is not None
         a = like(allp[:125]); b1 = like(allp[7])
-        like._fast = like._fast[:7] + (None,)
+        like._fast = like._fast[:7] + (None,) + like._fast[8:]
         assert np.array_equal(like(allp[:125]), a, equal_nan=True) and like(allp[7]) == b1 and 125 in like._fast[2]
         like._fast = None
     keep = like(allp[:125])
@@ -1122,6 +1130,55 @@ def test_boundary_fast_path_equals_the_general_path(mbb, g_lnl):
     # a pickled copy builds its own context and buffers
     twin = pickle.loads(pickle.dumps(like))
     assert twin._fast is None and np.array_equal(twin(allp[:125]), want[:125], equal_nan=True)
+
+
+@pytest.mark.parametrize("glue", ["extension", "numpy"])
+def test_boundary_call_survives_the_blocks_being_made_anew(mbb, g_lnl, glue):
+    """likelihood.__call__ caches addresses of the blocks the boundary call works on; any OTHER
+    call on the context that needs more rows than they hold -- model_flux of a chain, a list of rows through the general
+    path, a 3-D array, the sharded evaluation, ctx.lnlike_batch -- frees them natively.  The next boundary call must see
+    that (the context's generation word) before it writes anything: right results, no write into freed memory."""
+    import importlib
+    lk_mod = importlib.import_module("mbb_emcee_amd.likelihood")
+    if glue == "extension" and lk_mod._mbbfast is None:
+        pytest.skip("the _mbbfast extension is not built here")
+    allp = np.tile(g_lnl["cfg2/thick_walpha/pars"], (20, 1))          # 6620 rows
+    a64 = np.ascontiguousarray(allp[:64])
+
+    def fresh():
+        like = _cfg2_like(mbb, g_lnl)
+        like._sync_device()
+        if glue == "numpy":
+            saved = lk_mod._mbbfast
+            lk_mod._mbbfast = None
+            try:
+                like(a64)
+            finally:
+                lk_mod._mbbfast = saved
+            assert like._fast[7] is None
+        return like
+    like0 = _cfg2_like(mbb, g_lnl)
+    want = like0._sync_device().lnlike_batch(allp)[0]
+    growers = {
+        "model_flux": lambda like: like.model_flux(allp),
+        "list": lambda like: like([list(r) for r in allp[:3000]]),
+        "lnlike_batch": lambda like: like._sync_device().lnlike_batch(allp),
+        "3d": lambda like: like(allp[None, :, :]),
+    }
+    for name, grow in growers.items():
+        like = fresh()
+        for _ in range(5):                                            # (a run of calls: the served path too)
+            assert np.array_equal(like(a64), want[:64], equal_nan=True)
+        f_old = like._fast
+        assert f_old is not None and f_old[3] == 256
+        gen_before = int(f_old[8][0])
+        grow(like)
+        assert int(f_old[8][0]) != gen_before, name                   # the native side says so ...
+        for _ in range(5):
+            assert np.array_equal(like(a64), want[:64], equal_nan=True), name
+        assert like._fast is not f_old and like._fast[3] >= 256, name  # ... and the cached views were dropped, not written through
+        one = like(allp[3])
+        assert type(one) is float and one == want[3]
 
 
 def test_served_boundary_equals_the_launches(mbb, g_lnl):

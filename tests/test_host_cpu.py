@@ -62,14 +62,17 @@ def test_builtin_wheel_is_cached_not_shared():
     assert a["SPIRE_350um"]._nresp != b["SPIRE_350um"]._nresp
     assert b["SPIRE_500um"] is not response_set()["SPIRE_500um"]
     np.testing.assert_allclose(b["SPIRE_250um"].normfac, 3.0796e-3, atol=1e-4)
-    # the arrays behind the copies are shared, so they are frozen: writing into one raises instead of
-    # changing every later wheel of the process
+    # every wheel has arrays of its own, writable, as in the reference (response.py:252-332): the reference's pattern of
+    # changing a curve in place works -- on the first wheel of the process (`a`) as on a later one -- and changes that
+    # wheel only, never the cached master behind the later wheels
     keep = b["SPIRE_500um"].response.copy()
-    with pytest.raises(ValueError):
-        b["SPIRE_500um"].response[:] *= 2.0
-    with pytest.raises(ValueError):
-        b["SPIRE_500um"].wavelength[0] = 1.0
-    assert np.array_equal(response_set()["SPIRE_500um"].response, keep)
+    for w in (a, b):
+        w["SPIRE_500um"].response[:] *= 2.0
+        w["SPIRE_500um"].wavelength[0] = 1.0
+        assert np.array_equal(w["SPIRE_500um"].response, 2.0 * keep)
+    fresh = response_set()
+    assert np.array_equal(fresh["SPIRE_500um"].response, keep) and fresh["SPIRE_500um"].wavelength[0] != 1.0
+    assert fresh["SPIRE_500um"].response.flags.writeable
 
 
 def test_passband_tables_match_reference(g_pb):
@@ -290,7 +293,7 @@ def test_bench_starts_its_own_ranks_and_always_prints_one_line(argv):
 
 
 @pytest.mark.parametrize("how,rc_want,checks", [
-    ("part", 0, lambda d: d["value"] == 2.0e6 and d["exchange_validation"]["rccl"]["ok"] is True and "ranks_ended_badly" not in d),
+    ("part", 0, lambda d: d["value"] == 2.0e6 and d["exchange_validation"]["rccl"] == "ok" and "ranks_ended_badly" not in d),
     ("part,crash1", 0, lambda d: d["value"] == 2.0e6 and d["ranks_ended_badly"] == {"1": 7}),
     ("hang1", 0, lambda d: d["value"] == 2.0e6 and d["ranks_ended_badly"] == {"1": -9}),
     ("noline,fail0", 3, lambda d: d["value"] is None and "without a line" in d["error"]),
@@ -313,7 +316,7 @@ def test_bench_supervisor_collects_merges_and_ends_ranks(how, rc_want, checks):
     # a peer wedged after the measurement: the value stands
     ("hang1", True, lambda d: d["value"] == 2.0e6 and d["supervisor_timeout"] and d["ranks_ended_badly"] == {"1": -9}),
     # rank 0 itself wedged in something optional after its line (the parts it had printed are kept)
-    ("part,hang0", True, lambda d: d["value"] == 2.0e6 and d["supervisor_timeout"] and d["exchange_validation"]["rccl"]["ok"]),
+    ("part,hang0", True, lambda d: d["value"] == 2.0e6 and d["supervisor_timeout"] and d["exchange_validation"]["rccl"] == "ok"),
     # wedged before anything was measured: an error line, not silence
     ("noline,hang0", False, lambda d: d["value"] is None and d["supervisor_timeout"] and "deadline" in d["error"]),
 ])
@@ -334,6 +337,100 @@ def test_bench_supervisor_deadline_ends_the_ranks_and_still_prints_the_line(how,
     line = json.loads(out[0])
     assert (rc == 0) == rc_zero and checks(line), (rc, line)
     assert line["supervisor_deadline_s"] == 6.0
+
+
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                      "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "full")
+
+
+def _check_driver_line(raw, n_gpus):
+    """What the driver must be able to parse: ONE line, strict JSON, far below the size that lost round 4's record."""
+    import json
+    import bench
+    assert "\n" not in raw.strip() and len(raw.encode()) < bench.LINE_LIMIT, len(raw)
+
+    def strict(c):
+        raise ValueError("not strict JSON: " + c)
+    d = json.loads(raw, parse_constant=strict)
+    for k in REQUIRED_LINE_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["config"]["workload"] and d["dtype"].startswith("f64")
+    assert d["metric"].startswith(json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"])
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert len(d["roofline"]["kernel"]) <= 80
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    return d
+
+
+def test_bench_line_stays_short_whatever_was_measured():
+    """Round 4's driver record has `parsed: null`: the one JSON line had grown to 20.7 KB.  The line is now built by
+    `short_line` from everything measured and everything else goes to gpurun_out/bench_full.json.  Here: round 4's
+    two whole lines (every leg populated) and the same with every string blown up and every number made awkward come
+    out as one strict-JSON line below 4 KB with the keys the contract names."""
+    import json
+    import bench
+    for f in ("bench_v5.json", "bench_driver_command.json"):
+        full = json.load(open(os.path.join(ROOT, "profiles", "r04", f)))
+        assert len(json.dumps(full)) > 15000
+        d = _check_driver_line(json.dumps(bench.short_line(full), allow_nan=False, separators=(",", ":")), 1)
+        assert d["value"] == pytest.approx(full["value"], rel=1e-6) and d["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+        assert d["boundary_M1"]["p50_us"] == pytest.approx(full["boundary_M1"]["p50_us"], rel=1e-5)
+        assert d["cpu_baseline"]["value"] == pytest.approx(full["cpu_baseline"]["value"], rel=1e-5)
+
+        def blow(o):
+            if isinstance(o, dict):
+                return {k: blow(v) for k, v in o.items()}
+            if isinstance(o, list):
+                return [blow(v) for v in o] * 3
+            if isinstance(o, str):
+                return o * 40
+            if isinstance(o, float):
+                return o * (1.0 + 1.0 / 3.0)
+            return o
+        big = blow(full)
+        big["roofline"]["counted"]["frac"] = float("nan")           # a non-finite number must not reach the line
+        big["error"] = "x" * 100000
+        big["exchange_validation"] = {m: {"ok": False, "why": "y" * 5000} for m in ("ipc", "ipc-launches", "rccl")}
+        raw = json.dumps(bench.short_line(big), allow_nan=False, separators=(",", ":"))
+        d = _check_driver_line(raw, 1)
+        assert d["roofline"]["counted_frac"] is None
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_bench_prints_the_short_line_and_the_side_file(world, tmp_path):
+    """bench.py end to end with fake ranks that hand over a fully populated line (round 4's) and long parts: the last
+    thing on stdout is the short line; the whole record is in the side file.  8 ranks: the supervisor keeps the parts
+    out of the line (`exchange_validation` one word per exchange)."""
+    import json
+    import shutil
+    # (the side file lands under the repo copy's gpurun_out/: run a copy so a test never touches the real one)
+    root = tmp_path / "repo"
+    root.mkdir()
+    shutil.copy(os.path.join(ROOT, "bench.py"), root / "bench.py")
+    shutil.copy(os.path.join(ROOT, "BASELINE.json"), root / "BASELINE.json")
+    (root / "profiles" / "r04").mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "profiles", "r04", "bench_v5.json"), root / "profiles" / "r04" / "bench_v5.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MBB_BENCH_WORKER")}
+    env.update({"MBB_BENCH_FAKE_WORKER": "full,part", "MBB_BENCH_GRACE_S": "5", "PYTHONPATH": ROOT})
+    if world == 1:
+        env["MBB_BENCH_WORKER_FAKE_TOP"] = "1"
+    pr = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5"], env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert pr.returncode == 0, pr.stderr.decode()[-2000:]
+    out = [ln for ln in pr.stdout.decode().splitlines() if ln.strip()]
+    assert len(out) == 1, out
+    d = _check_driver_line(out[0], world)
+    assert d["full"] == "gpurun_out/bench_full.json"
+    full = json.load(open(root / "gpurun_out" / "bench_full.json"))
+    assert "large_ensembles" in full and "postprocess" in full and "user_runs" in full and "configs" in full
+    assert "large_ensembles" not in d and "postprocess" not in d
+    if world > 1:
+        assert d["exchange_validation"]["rccl"] == "ok" and d["exchange_validation"]["ipc"].startswith("rehearsal")
+        assert len(d["exchange_validation"]["ipc"]) <= 70
+        assert d["boundary_sharded"]["ok"] is True and d["boundary_sharded"]["rows_%d" % (125 * world)] == pytest.approx(31.123, rel=1e-4)
+        assert len(full["exchange_validation"]["ipc"]["why"]) > 1000          # the side file keeps the detail
 
 
 def test_bench_under_a_launcher_with_the_wrong_world_size_says_so():
@@ -776,7 +873,8 @@ def test_fastcall_extension_with_a_stand_in_for_the_native_call():
         calls.append((h, n)); lnl[:n] = rows[:n].sum(axis=1)
         return 0 if rows[0, 0] >= 0 else 7
     cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)(native)
-    fc = ext.FastCall(C.cast(cb, C.c_void_p).value, 1234, rows.ctypes.data, lnl.ctypes.data, 256)
+    gen = np.array([5], dtype=np.uint64)
+    fc = ext.FastCall(C.cast(cb, C.c_void_p).value, 1234, rows.ctypes.data, lnl.ctypes.data, 256, gen.ctypes.data, 5)
     p = np.random.RandomState(0).rand(40, 5)
     r = fc(p)
     assert type(r) is np.ndarray and r.dtype == np.float64 and r.base is None and np.array_equal(r, p.sum(axis=1))
@@ -792,8 +890,17 @@ def test_fastcall_extension_with_a_stand_in_for_the_native_call():
     assert len(calls) == n_before                                     # none of them reached the native call
     bad = p.copy(); bad[0, 0] = -1.0
     assert fc(bad) is None and calls[-1] == (1234, 40)                # a non-zero return: the caller takes the general path
+    # the blocks made anew by some other call on the context (the generation word moved): nothing is written through the
+    # stale addresses, nothing is called, None sends the caller for the buffers again
+    rows[:] = 0.0; n_before = len(calls)
+    gen[0] = 6
+    assert fc(p) is None and len(calls) == n_before and not rows.any()
+    gen[0] = 5
+    assert np.array_equal(fc(p), p.sum(axis=1))
     with pytest.raises(TypeError):
         fc()
     with pytest.raises(ValueError):
-        ext.FastCall(0, 1, 2, 3, 4)
+        ext.FastCall(0, 1, 2, 3, 4, 5, 6)
+    with pytest.raises(ValueError):
+        ext.FastCall(1, 1, 2, 3, 4, 0, 6)
 
