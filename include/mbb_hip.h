@@ -220,7 +220,13 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * answered 256 requests: likelihoods used in turns do not spend their time starting and stopping kernels), tells it to
  * leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
- * switch the feature off.  0: a launch per call (2: as 1; it used to mean "also beside other contexts").  "serve_overlap" (default 1): that
+ * switch the feature off.  One such kernel per device across PROCESSES too: nothing of another process fits beside a resident
+ * server (emcee's pool, mbb_fit.py:80-81 with threads > 1), so a server is started only while no other process of this
+ * library holds a context on the device, and a resident one leaves with the first call that finds one registered (a
+ * table in POSIX shared memory keyed by the device's PCI address: csrc/mbb_registry.h; mbb_get_info "device_peers",
+ * "serve_peer_yields", "serve_lease_yields"); and for processes that table cannot show, a server is sent away after "serve_lease_us" (50000;
+ * 0: never) in one go -- the rows of that call go by a launch, the next server starts after the next few calls in a row.
+ * 0: a launch per call; 2: a server even while other processes are registered on the device (tests).  "serve_overlap" (default 1): that
  * kernel starts a row's passband quadrature beside its SED constructor -- the blackbody-side value of every sample,
  * which needs none of the constructor's merge point, into a buffer in LDS -- and sums the units from the buffer when
  * the constructor is through, when the bands have at least 12 chunks of 64 samples (2: with fewer too); 0: one after

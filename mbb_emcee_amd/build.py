@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mbb_hip.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "mbb_host_tables.cpp")      # host-only table builders
 SRC_FLOW = os.path.join(HERE, "csrc", "mbb_flow.hip")             # the one-launch sampler kernel, own flags
+SRC_REG = os.path.join(HERE, "csrc", "mbb_registry.cpp")          # host-only: which processes are on which GPU
 # Both device translation units: no contraction of a product and a sum the source keeps apart.  The
 # sampler forms (k_lnlike SMODE 1/2/5/6, k_flowm) are held to one another bit for bit, and the shared
 # arithmetic is inlined into each of them: with the compiler free to contract, whether a given a*b+c
@@ -22,7 +23,8 @@ SRC_FLOW = os.path.join(HERE, "csrc", "mbb_flow.hip")             # the one-laun
 # the two settings: none in the sample loop; profiles/r03/fma_audit.txt).
 DEVICE_FLAGS = ["-ffp-contract=off"]
 FLOW_FLAGS = ["-mllvm", "-sink-insts-to-avoid-spills", "-mllvm", "-disable-machine-licm"]
-DEPS = [SRC, SRC_HOST, SRC_FLOW, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
+DEPS = [SRC, SRC_HOST, SRC_FLOW, SRC_REG, os.path.join(HERE, "csrc", "mbb_host_tables.h"),
+        os.path.join(HERE, "csrc", "mbb_registry.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
         os.path.join(HERE, "csrc", "mbb_walker_consts.inc"),
         os.path.join(HERE, "csrc", "mbb_flow_index.h"),
@@ -81,13 +83,14 @@ def build(force=False, verbose=False, extra_flags=(), out=None, obj_tag=""):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build(target, extra_flags):       # another process built it while we waited
             return target
-        # three objects (the two device translation units in parallel), then one link
+        # four objects (the two device translation units in parallel), then one link
         common = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + DEVICE_FLAGS + list(extra_flags)
         if verbose:
             common.append("-Rpass-analysis=kernel-resource-usage")
         jobs = [(SRC, os.path.join(objdir, "mbb_hip.o"), []),
                 (SRC_FLOW, os.path.join(objdir, "mbb_flow.o"), FLOW_FLAGS),
-                (SRC_HOST, os.path.join(objdir, "mbb_host_tables.o"), [])]
+                (SRC_HOST, os.path.join(objdir, "mbb_host_tables.o"), []),
+                (SRC_REG, os.path.join(objdir, "mbb_registry.o"), [])]
         procs = []
         for src, obj, flags in jobs:
             cmd = common + flags + ["-c", src, "-o", obj]

@@ -106,6 +106,7 @@ static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t n
            8 * (nb + 2) + 8 * (3 * 64) + 64 * np + 32;
 }
 #include "mbb_host_tables.h"
+#include "mbb_registry.h"
 
 static_assert(kPolyBDoubles == mbbh::kPolyBCount * (mbbh::kPolyDeg + 1), "poly table size");
 static_assert(kPolyCDoubles == mbbh::kPolyCCount * (mbbh::kPolyDeg + 1), "poly table size");
@@ -229,6 +230,13 @@ struct mbb_ctx {
     long opt_serve_after = 3;                 // boundary calls in a row before a server is started
     long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (~1 us per poll)
     long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
+    long opt_serve_lease_us = 50000;          // a server is sent away after this long in one go (0: never): processes this library
+                                              // cannot see (other containers, other programs) get the CUs at least that often
+    long srv_t0_ns = 0;                       // when the present server was started
+    uint32_t reg_key = 0;                     // the device's name in the cross-process registry (mbb_registry.h): PCI domain:bus:device
+    unsigned reg_tick = 0;
+    long srv_lease_yields = 0;                // servers sent away because their lease was up
+    long srv_peer_yields = 0;                 // servers not started, or sent away, because another process is on the device
     unsigned long long buf_gen = 1;   // mbb_boundary_generation: bumped whenever the blocks below are freed and made anew
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
@@ -423,6 +431,16 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
         if (es != hipSuccess) { delete c; return fail(MBB_ERR_HIP, "hipStreamCreateWithFlags", es); }
     }
     ++g_dev[device].live;
+    {
+        // the device's name for other processes: its PCI address (the HIP ordinal is renumbered by HIP_VISIBLE_DEVICES)
+        int dom = 0, bus = 0, dv = 0;
+        if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess) dom = 0;
+        if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess) bus = device;
+        if (hipDeviceGetAttribute(&dv, hipDeviceAttributePciDeviceId, device) != hipSuccess) dv = 0;
+        (void)hipGetLastError();
+        c->reg_key = 0x80000000u | ((uint32_t)(dom & 0x7fff) << 16) | ((uint32_t)(bus & 0xff) << 8) | (uint32_t)(dv & 0xff);
+        mbbh::registry_join(c->reg_key);
+    }
     *out = c;
     return MBB_OK;
 }
@@ -446,6 +464,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
         if (g_dev[c->device].last_user == c) g_dev[c->device].last_user = nullptr;
         if (g_dev[c->device].server == c) g_dev[c->device].server = nullptr;
     }
+    mbbh::registry_leave(c->reg_key);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->x.base) (void)xchg_free(c);
@@ -1238,6 +1257,7 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     c->last_stage = stg ? 1 : 0; c->last_smode = 10;
     c->serving = true;
     c->srv_run = 0;
+    { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); c->srv_t0_ns = ts.tv_sec * 1000000000L + ts.tv_nsec; }
     {
         std::lock_guard<std::mutex> lk(g_dev_mutex);
         g_dev[c->device].server = c;
@@ -1324,7 +1344,32 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // a kernel that stays on the GPU (k_serve) instead of a launch each: while the batch is at most a row per CU and the
     // host path is the default one.  One server per device and process: whichever context comes to the device tells a
     // sibling's to leave first (use(), and the line below).
-    const bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
+    bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
+    // ... and one server per device across PROCESSES: a resident server leaves no room for anything of another process
+    // (emcee's pool, mbb_fit.py:80-81 threads > 1: profiles/r05/pool_two_processes_before.txt -- one worker's call waited 42 ms
+    // for the other's whole loop).  While another process of this library is registered on the device no server is
+    // started and a resident one leaves with this call ("serve" 2: regardless -- tests).  An answer that says "somebody
+    // else" is made anew every 256 calls: a peer that died without a word is not believed for long.
+    if (can_serve && c->opt_serve != 2) {
+        const bool had_peers = c->reg_tick & 0x80000000u;
+        const int peers = mbbh::registry_peers(c->reg_key, had_peers && ((c->reg_tick & 255u) == 255u));
+        c->reg_tick = ((c->reg_tick + 1) & 0x7fffffffu) | (peers > 0 ? 0x80000000u : 0u);
+        if (peers > 0) {
+            // (counted once per run of calls that would have been served)
+            if (c->serving || ++c->srv_hot == (c->srv_need > 0 ? c->srv_need : c->opt_serve_after)) ++c->srv_peer_yields;
+            can_serve = false;
+        }
+    }
+    // ... and not for ever in one go: processes the registry cannot see get the CUs when the lease is up (the rows of this
+    // call go by a launch, a new server starts after the next few calls in a row)
+    if (can_serve && c->serving && c->opt_serve_lease_us > 0) {
+        timespec tl; clock_gettime(CLOCK_MONOTONIC, &tl);
+        if (tl.tv_sec * 1000000000L + tl.tv_nsec - c->srv_t0_ns > c->opt_serve_lease_us * 1000L) {
+            can_serve = false;
+            c->srv_hot = 0;
+            ++c->srv_lease_yields;
+        }
+    }
     // (a sibling context's server: this call, served or launched, needs the CUs; and a sibling's visit in between ends this
     // context's run of calls)
     if (!c->serving && (rc = yield_server(c))) return rc;
@@ -2208,6 +2253,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "serve_after")) { c->opt_serve_after = value < 1 ? 1 : value; c->srv_need = 0; }
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
     else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
+    else if (!strcmp(name, "serve_lease_us")) c->opt_serve_lease_us = value < 0 ? 0 : value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
@@ -2238,6 +2284,9 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "serve_requests")) *value = c->srv_requests;
     else if (!strcmp(name, "serve_fallbacks")) *value = c->srv_fallbacks;
     else if (!strcmp(name, "serve_enabled")) *value = c->opt_serve;
+    else if (!strcmp(name, "device_peers")) *value = mbbh::registry_peers(c->reg_key, true);
+    else if (!strcmp(name, "serve_peer_yields")) *value = c->srv_peer_yields;
+    else if (!strcmp(name, "serve_lease_yields")) *value = c->srv_lease_yields;
     else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;
     else if (!strcmp(name, "last_wait_ns")) *value = c->t_wait_ns;
     else if (!strcmp(name, "last_watch_seen")) *value = c->last_watch_seen;

@@ -1,0 +1,34 @@
+// mbb_registry.h -- which processes of this library are on which GPU (host-only, no HIP types).
+//
+// Why: the served boundary (k_serve, mbb_serve.hip.h) keeps one workgroup on every CU, with most of the CU's LDS,
+// between a sampler's calls.  Inside one process that is arbitrated by yield_server (mbb_hip.hip).  Across
+// processes -- emcee's pool, reference mbb_fit.py:80-81 with threads > 1: the likelihood pickled into workers that
+// share the GPU -- nothing of another process fits beside a resident server, neither its own server nor its plain
+// launches: measured, one worker's call waited 42 ms for the other's whole loop
+// (profiles/r05/pool_two_processes_before.txt).  So a process starts a server only while it is the ONLY user of this
+// library on the device, and a server that finds a second one registered leaves at its next request.
+//
+// How: a small table in POSIX shared memory (/dev/shm/mbb_hip_registry_<uid>), one slot per process: its pid and
+// the keys (PCI domain:bus:device -- not the HIP ordinal, which HIP_VISIBLE_DEVICES renumbers) of the devices it
+// holds contexts on; a generation word, bumped at every change, makes the per-call check one load of shared memory.
+// A slot whose process is gone (kill(pid, 0) == ESRCH) is reclaimed by whoever counts next; a count that says
+// "somebody else" is made again every so often, so a peer that died without a word is not believed for long.
+// Processes that do not share /dev/shm (other containers) or do not use this library are not seen: for those the
+// server's lease (option "serve_lease_us") bounds how long it holds the GPU in one go.
+// Compiled into libmbb_hip.so by hipcc and, on its own, by gcc for the CPU tests (`make -C oracle
+// libmbb_hosttables.so`, tests/test_host_cpu.py::test_device_registry_*).
+#pragma once
+#include <stdint.h>
+
+namespace mbbh {
+
+// Joins / leaves are counted per key inside the process: the key is published on the first join and withdrawn on
+// the last leave.  All three return 0 (or the count) when the registry cannot be had (no /dev/shm): nobody is seen.
+int registry_join(uint32_t key);
+int registry_leave(uint32_t key);
+// Other live processes registered on `key`.  `recount`: do not trust the cached answer.
+int registry_peers(uint32_t key, bool recount);
+// (tests) the name of the shared-memory object this process uses
+const char *registry_name();
+
+}  // namespace mbbh

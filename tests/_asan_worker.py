@@ -23,6 +23,22 @@ def main():
     b = np.zeros(nb_.value * k_.value); c = np.zeros(nc_.value * k_.value)
     lib.mbbh_poly_tables(b.ctypes.data_as(LC._dp), c.ctypes.data_as(LC._dp))
     assert b[0] == 1.0 and abs(c[0] - 1.0) < 1e-15
+    # the cross-process device registry (mbb_registry.cpp) under the sanitizers: a table of this worker's own
+    os.environ["MBB_REGISTRY_NAME"] = "/mbb_hip_registry_asan_%d" % os.getpid()
+    try:
+        for fn in (lib.mbbh_registry_join, lib.mbbh_registry_leave):
+            fn.argtypes = [C.c_uint32]
+        lib.mbbh_registry_peers.argtypes = [C.c_uint32, C.c_int]
+        for key in range(0x80000100, 0x80000100 + 20):          # (more keys than a slot holds: the rest go unseen, nothing overruns)
+            lib.mbbh_registry_join(key)
+        assert lib.mbbh_registry_peers(0x80000100, 1) == 0 and lib.mbbh_registry_peers(0x80000100 + 19, 0) == 0
+        for key in range(0x80000100, 0x80000100 + 20):
+            lib.mbbh_registry_leave(key); lib.mbbh_registry_leave(key)
+    finally:
+        try:
+            os.unlink("/dev/shm" + os.environ.pop("MBB_REGISTRY_NAME"))
+        except OSError:
+            pass
     # the oracle on a slice of its golden vectors (the full comparison is test_oracle_golden.py)
     from oracle import oracle as O
     g = np.load(os.path.join(ROOT, "tests", "golden", "lnlike.npz"))

@@ -39,6 +39,42 @@ def rel_below(kind, a, b, tol):
     assert e < tol, "%s: max relative error %g (tolerance %g)" % (kind, e, tol)
 
 
+PATHS = ["launched", "served"]
+
+
+def boundary_eval(like, pars, path):
+    """likelihood.__call__ on float64 rows by one of the two ways the boundary call is evaluated:
+    `launched` -- what a first call gets; `served` -- what a sampler's LOOP of calls gets after three in a row: the rows
+    go to the resident kernel (k_serve) and no launch is made.  The served way needs several calls before it starts, so
+    a test that calls once never sees it (round 4: a wrong-sums bug hid there): here it is switched on from the first
+    boundary call (`serve` 2, `serve_after` 1), the rows go in batches of at most a row per CU, and the counters must
+    say that every batch was answered by the resident kernel -- a silent fall-back to a launch cannot pass."""
+    pars = np.ascontiguousarray(pars, dtype=np.float64)
+    if path == "launched":
+        return like(pars)
+    ctx = like._sync_device()
+    saved_after = 3
+    ctx.set_option("serve", 2); ctx.set_option("serve_after", 1)
+    ctx.set_option("serve_budget_us", 100000)        # (a busy box must not turn a served request into a launch)
+    cus = ctx.info("cu_count")
+    req0, fb0 = ctx.info("serve_requests"), ctx.info("serve_fallbacks")
+    one = pars.ndim == 1
+    rows = pars[None, :] if one else pars
+    out, batches = [], 0
+    for i in range(0, rows.shape[0], cus):
+        chunk = np.ascontiguousarray(rows[i:i + cus])
+        got = like(chunk[0]) if one else like(chunk)
+        out.append(np.atleast_1d(got))
+        batches += 1
+        assert ctx.info("serving") == 1, "batch %d was not served" % batches
+    assert ctx.info("serve_requests") - req0 == batches and ctx.info("serve_fallbacks") == fb0, \
+        (ctx.info("serve_requests") - req0, batches, ctx.info("serve_fallbacks") - fb0)
+    assert ctx.info("last_kernel_form") == 10        # (k_serve's launch was the context's last)
+    ctx.set_option("serve", 1); ctx.set_option("serve_after", saved_after); ctx.set_option("serve_budget_us", 400)
+    res = np.concatenate(out) if out else np.zeros(0)
+    return float(res[0]) if one else res
+
+
 # ------------------------------------------------------------------ G5: KATs
 def test_kat_thick(mbb):
     """reference tests/test_modified_blackbody.py:6-20"""
@@ -153,49 +189,54 @@ def _like_cfg1(mbb, g, name, opthin, noalpha):
     return like, k
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
-def test_lnlike_cfg1_delta(mbb, g_lnl, name, opthin, noalpha):
+def test_lnlike_cfg1_delta(mbb, g_lnl, name, opthin, noalpha, path):
     like, k = _like_cfg1(mbb, g_lnl, name, opthin, noalpha)
     np.testing.assert_array_equal(like.uplims, g_lnl[k + "/uplim"])
     pars = g_lnl[k + "/pars"]
-    got = like(pars)
-    lnl_close(got, g_lnl[k + "/lnl"])
+    got = boundary_eval(like, pars, path)
+    lnl_close(got, g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (served)")
     fin = np.isfinite(g_lnl[k + "/lnl"])
     mf = like.model_flux(pars[fin])
     rel_below("band flux", mf, g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
     # scalar call returns a Python float, row by row identical to the batch
     for i in (0, 3, 50, 55):
-        v = like(pars[i])
+        v = boundary_eval(like, pars[i], path)
         assert isinstance(v, float)
         assert (v == got[i]) or (np.isneginf(v) and np.isneginf(got[i]))
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
-def test_lnlike_cfg2_passbands(mbb, g_lnl, name, opthin, noalpha):
+def test_lnlike_cfg2_passbands(mbb, g_lnl, name, opthin, noalpha, path):
     k = "cfg2/" + name
     like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
     like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
     rec_allclose(like.uplims, g_lnl[k + "/uplim"], rtol=1e-15, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
-    lnl_close(like(pars), g_lnl[k + "/lnl"])
+    lnl_close(boundary_eval(like, pars, path), g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (served)")
     fin = np.isfinite(g_lnl[k + "/lnl"])
     rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
-def test_lnlike_cfg4_covariance(mbb, g_lnl, name, opthin, noalpha):
+def test_lnlike_cfg4_covariance(mbb, g_lnl, name, opthin, noalpha, path):
     k = "cfg4/" + name
     like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
     like.set_phot([str(b) for b in g_lnl["cfg4/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
     like.set_cov(g_lnl[k + "/cov"])
     rec_allclose(like.data_wave, g_lnl[k + "/eff_wave"], rtol=1e-14, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
-    lnl_close(like(pars), g_lnl[k + "/lnl"])
+    lnl_close(boundary_eval(like, pars, path), g_lnl[k + "/lnl"],
+              kind="lnL (covariance)" if path == "launched" else "lnL (covariance, served)")
     fin = np.isfinite(g_lnl[k + "/lnl"])
     rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
 
-def test_lnlike_priors_and_peak(mbb, g_lnl):
+@pytest.mark.parametrize("path", PATHS)
+def test_lnlike_priors_and_peak(mbb, g_lnl, path):
     """Gaussian priors on all five parameters, extra upper/lower limits, and the
     lambda_peak ghost parameter (likelihood.py:672-752)."""
     bands = [str(b) for b in g_lnl["cfg2/bands"]]
@@ -210,15 +251,16 @@ def test_lnlike_priors_and_peak(mbb, g_lnl):
     like.set_uplim("fnorm", 41.0)
     like.set_lowlim("beta", 1.5)
     pars = g_lnl["cfg2/priors/pars"]
-    lnl_close(like(pars), g_lnl["cfg2/priors/lnl"])
+    kind = "lnL" if path == "launched" else "lnL (served)"
+    lnl_close(boundary_eval(like, pars, path), g_lnl["cfg2/priors/lnl"], kind=kind)
     like.set_gaussian_prior("lambda_peak", 260.0, 15.0)
     like.set_uplim("lambda_peak", 265.0)
-    lnl_close(like(pars), g_lnl["cfg2/priors_peak/lnl"])
+    lnl_close(boundary_eval(like, pars, path), g_lnl["cfg2/priors_peak/lnl"], kind=kind)
     # thin + alpha with a peak prior
     like = mbb.likelihood(response=True, opthin=True)
     like.set_phot(bands, g_lnl["cfg2/thin_walpha/flux"], g_lnl["cfg2/thin_walpha/unc"])
     like.set_gaussian_prior("peaklam", 250.0, 20.0)
-    lnl_close(like(pars), g_lnl["cfg2/thin_peak/lnl"])
+    lnl_close(boundary_eval(like, pars, path), g_lnl["cfg2/thin_peak/lnl"], kind=kind)
 
 
 def test_max_wave(mbb, g_lnl):
@@ -1248,6 +1290,7 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
         assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
         # it leaves by itself when nothing comes, and the next request is evaluated all the same
         ctx.set_option("serve_idle_us", 200)
+        ctx.set_option("serve_lease_us", 0)                          # (the lease is the next paragraph's)
         for _ in range(4):
             like(allp[:125])
         assert ctx.info("serving") == 1
@@ -1257,6 +1300,21 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
         assert ctx.info("serve_fallbacks") == nf + 1                 # (found gone: by a launch)
         for _ in range(4):
             assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        assert ctx.info("serving") == 1
+        # its lease: a server is sent away by the host after `serve_lease_us` in one go -- processes the cross-process
+        # registry cannot show get the CUs at least that often -- the rows of that call go by a launch (not a fall-back:
+        # nothing was lost), the next server starts after the next few calls in a row
+        ctx.set_option("serve_idle_us", 1000); ctx.set_option("serve_lease_us", 3000)
+        ny, nf, t0 = ctx.info("serve_lease_yields"), ctx.info("serve_fallbacks"), time.perf_counter()
+        ncalls = 0
+        while time.perf_counter() - t0 < 0.03:
+            assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+            ncalls += 1
+        assert 3 <= ctx.info("serve_lease_yields") - ny <= 12 and ctx.info("serve_fallbacks") == nf, \
+            (ctx.info("serve_lease_yields") - ny, ctx.info("serve_fallbacks") - nf, ncalls)
+        ctx.set_option("serve_lease_us", 50000)
+        for _ in range(4):
+            like(allp[:125])
         assert ctx.info("serving") == 1
         # the device sampler on the same context while a server is resident
         s = mbb.DeviceEnsembleSampler(64, 5, like, seed=3)
@@ -1306,6 +1364,69 @@ def test_served_boundary_with_several_likelihoods_alive(mbb, g_lnl):
     assert ca.info("serving") == 0 and np.all(np.isfinite(lnp))
     assert ca.info("serve_fallbacks") == 0 and cb.info("serve_fallbacks") == 0
     del s, a, b
+
+
+def _run_pool_workers(mbb, g_lnl, world, ncalls, env_extra=None):
+    """Start `world` processes that each unpickle the same likelihood and make `ncalls` boundary calls of 125 rows at
+    the same time on this one GPU (tests/_pool_worker.py); returns their reports."""
+    import json, pickle, subprocess, sys, tempfile
+    from conftest import ROOT
+    like = _cfg2_like(mbb, g_lnl)
+    pars = np.ascontiguousarray(np.tile(g_lnl["cfg2/thick_walpha/pars"], (2, 1))[:125])
+    ctx = like._sync_device()
+    ctx.set_option("serve", 0)
+    want = like(pars).copy()
+    ctx.set_option("serve", 1)
+    d = tempfile.mkdtemp()
+    pickle.dump(like, open(os.path.join(d, "like.pkl"), "wb"))
+    np.save(os.path.join(d, "pars.npy"), pars); np.save(os.path.join(d, "want.npy"), want)
+    del like
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_pool_worker.py"), d, str(r), str(world), str(ncalls)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    texts = []
+    for pr in procs:
+        try:
+            texts.append(pr.communicate(timeout=240)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()                                              # exactly the processes started above
+            raise AssertionError("a pool worker did not finish within 240 s")
+    for r, (pr, t) in enumerate(zip(procs, texts)):
+        assert pr.returncode == 0 and "POOL_OK %d" % r in t, t[-3000:]
+    return [json.load(open(os.path.join(d, "out.%d.json" % r))) for r in range(world)]
+
+
+def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
+    """emcee's pool (reference mbb_fit.py:80-81 with threads > 1: the likelihood pickled into worker processes): two
+    processes, each with its own copy of the same likelihood, each in a loop of boundary calls -- on ONE GPU.  A
+    resident server (k_serve) holds every CU with most of its LDS, so while one process is being served nothing of
+    another process's fits beside it: neither its own server nor its plain launches.  The library therefore starts a
+    server only while its process is the only one of this library's users on the device (a registry in shared memory:
+    mbb_hip.hip `DeviceRegistry`), and a server that finds a second process registered leaves at its next request.
+    Here: every result of both processes bit for bit right, both loops done in a bounded time, neither process waiting
+    long for the other (no call beyond 20 ms), and -- both being there for the whole loop -- no request answered by a
+    resident kernel."""
+    import json
+    from conftest import ROOT
+    ncalls = 3000
+    rep = _run_pool_workers(mbb, g_lnl, 2, ncalls, {"MBB_POOL_HAS_PEERS_INFO": "1"})
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "pool_two_processes.json"), "w"), indent=1)
+    except OSError:
+        pass
+    overlap = min(r["t_end"] for r in rep) - max(r["t_start"] for r in rep)
+    for r in rep:
+        assert r["first_ok"] and r["bad_calls"] == 0 and r["calls"] == ncalls, r
+        assert r["wall_s"] < 5.0 and r["max_us"] < 20000.0, r          # nobody starved: 3000 calls take ~0.05-0.1 s
+        assert r["serve_enabled_at_end"] == 1, r                       # the feature did not strike out either
+    assert overlap > 0.0, rep                                          # (the two loops did run at the same time)
+    # while both were there nobody held the GPU: at most the few requests served before the other process registered
+    # (each worker sees the other, and this test session's own process, which holds contexts on the device too)
+    assert all(r["peers_at_start"] >= 1 for r in rep), rep
+    assert sum(r["serve_requests"] for r in rep) <= 0.05 * 2 * ncalls, rep
 
 
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
@@ -1459,8 +1580,9 @@ def test_full_size_cfg3_and_cfg5_properties(mbb, g_lnl, oracle):
 
 
 # --------------------------------------------------------------- randomised configurations
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("seed", range(24))
-def test_random_configurations_vs_oracle(mbb, oracle, seed):
+def test_random_configurations_vs_oracle(mbb, oracle, seed, path):
     """Random band subsets (wheel bands, specials, repeats, a single band), random
     model variant, random limits / priors / lambda_peak terms, diagonal or full
     covariance, random batch size and launch geometry -- always the oracle's answer."""
@@ -1509,10 +1631,12 @@ def test_random_configurations_vs_oracle(mbb, oracle, seed):
     ref = orc(pars, nthreads=4)
     like.context.set_option("walkers_per_group", int(rng.choice([0, 1, 2, 5, 16])))
     like.context.set_option("block_threads", int(rng.choice([0, 64, 256, 640, 1024])))
-    got = like(pars)
+    got = boundary_eval(like, pars, path)
     like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
-    lnl_close(got, ref, kind="lnL (covariance)" if cov is not None else "lnL")
-    assert np.array_equal(got, like(pars), equal_nan=True)
+    lnl_close(got, ref, kind=("lnL (covariance%s)" % (", served" if path == "served" else "")) if cov is not None else
+              ("lnL" if path == "launched" else "lnL (served)"))
+    # (and the two ways agree bit for bit: the other one now, default geometry)
+    assert np.array_equal(got, boundary_eval(like, pars, "served" if path == "launched" else "launched"), equal_nan=True)
 
 
 @pytest.mark.parametrize("opthin,noalpha", [(False, False), (False, True), (True, False), (True, True)])

@@ -904,3 +904,89 @@ def test_fastcall_extension_with_a_stand_in_for_the_native_call():
     with pytest.raises(ValueError):
         ext.FastCall(1, 1, 2, 3, 4, 0, 6)
 
+
+
+_REGISTRY_CHILD = r"""
+import ctypes, os, sys
+lib = ctypes.CDLL(sys.argv[1])
+lib.mbbh_registry_join.argtypes = [ctypes.c_uint32]; lib.mbbh_registry_leave.argtypes = [ctypes.c_uint32]
+lib.mbbh_registry_peers.argtypes = [ctypes.c_uint32, ctypes.c_int]
+for line in sys.stdin:
+    cmd, _, arg = line.strip().partition(" ")
+    if cmd == "join": print(lib.mbbh_registry_join(int(arg)), flush=True)
+    elif cmd == "leave": print(lib.mbbh_registry_leave(int(arg)), flush=True)
+    elif cmd == "peers": print(lib.mbbh_registry_peers(int(arg), 0), flush=True)
+    elif cmd == "fork":
+        # a child of fork() starts afresh: it is a process of its own in the table
+        pid = os.fork()
+        if pid == 0:
+            lib.mbbh_registry_join(int(arg))
+            os._exit(lib.mbbh_registry_peers(int(arg), 1))
+        print(os.waitpid(pid, 0)[1] >> 8, flush=True)      # (answered once the child is gone for good: not even a zombie)
+    elif cmd == "quit": break
+"""
+
+
+def test_device_registry_sees_other_processes_and_forgets_dead_ones(tmp_path):
+    """mbb_emcee_amd/csrc/mbb_registry.cpp: which processes of this library hold contexts on which GPU, so that a
+    resident server (k_serve) is started only by a process that has the device to itself (emcee's pool pattern,
+    reference mbb_fit.py:80-81 threads > 1).  Real processes, a table of the test's own in /dev/shm: a second process
+    on the same device is seen at once (the generation word), one on another device is not, a process that leaves is
+    gone at once, one that is killed is gone at the next recount and its slot is free again, a fork()ed child is a
+    process of its own."""
+    import ctypes
+    _, _ = _hosttables_lib()
+    path = os.path.join(ROOT, "oracle", "libmbb_hosttables.so")
+    name = "/mbb_hip_registry_test_%d" % os.getpid()
+    os.environ["MBB_REGISTRY_NAME"] = name
+    try:
+        lib = ctypes.CDLL(path)
+        lib.mbbh_registry_join.argtypes = [ctypes.c_uint32]; lib.mbbh_registry_leave.argtypes = [ctypes.c_uint32]
+        lib.mbbh_registry_peers.argtypes = [ctypes.c_uint32, ctypes.c_int]
+        lib.mbbh_registry_name.restype = ctypes.c_char_p
+        K, K2 = 0x80000300, 0x80000400
+        assert lib.mbbh_registry_join(K) == 1 and lib.mbbh_registry_join(K) == 2          # (two contexts of this process)
+        assert lib.mbbh_registry_name().decode() == name and os.path.exists("/dev/shm" + name)
+        assert lib.mbbh_registry_peers(K, 0) == 0
+
+        def child():
+            pr = subprocess.Popen([sys.executable, "-c", _REGISTRY_CHILD, path], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  env=dict(os.environ), text=True)
+
+            def ask(line):
+                pr.stdin.write(line + "\n"); pr.stdin.flush()
+                return int(pr.stdout.readline())
+            return pr, ask
+        b, ask_b = child()
+        assert ask_b("join %d" % K2) == 1
+        assert lib.mbbh_registry_peers(K, 0) == 0                                         # another device: not a peer
+        assert ask_b("join %d" % K) == 1
+        assert lib.mbbh_registry_peers(K, 0) == 1 and ask_b("peers %d" % K) == 1           # seen at once, both ways
+        c, ask_c = child()
+        assert ask_c("join %d" % K) == 1
+        assert lib.mbbh_registry_peers(K, 0) == 2 and ask_b("peers %d" % K) == 2
+        assert ask_b("fork %d" % K) == 3                                                   # the child of a fork: a fourth process
+        assert lib.mbbh_registry_peers(K, 1) == 2                                          # ... and gone again when it exits
+        assert ask_b("leave %d" % K) == 0
+        assert lib.mbbh_registry_peers(K, 0) == 1                                          # left: gone at once
+        c.kill(); c.wait()                                                                 # killed: no word from it
+        assert lib.mbbh_registry_peers(K, 0) == 1                                          # (the cached answer still believes it)
+        assert lib.mbbh_registry_peers(K, 1) == 0                                          # a recount does not
+        assert lib.mbbh_registry_leave(K) == 1 and lib.mbbh_registry_leave(K) == 0 and lib.mbbh_registry_leave(K) == 0
+        assert ask_b("join %d" % K) == 1 and ask_b("peers %d" % K) == 0                    # this process has withdrawn the key
+        b.stdin.write("quit\n"); b.stdin.flush(); b.wait(timeout=30)
+        # many processes come and go: slots of the dead are taken again, the table (256 slots) does not fill up
+        for _ in range(3):
+            kids = [child() for _ in range(8)]
+            for pr, ask in kids:
+                assert ask("join %d" % K) == 1
+            assert lib.mbbh_registry_join(K) == 1 and lib.mbbh_registry_peers(K, 0) == 8
+            for pr, ask in kids:
+                pr.kill(); pr.wait()
+            assert lib.mbbh_registry_peers(K, 1) == 0 and lib.mbbh_registry_leave(K) == 0
+    finally:
+        del os.environ["MBB_REGISTRY_NAME"]
+        try:
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
