@@ -44,8 +44,12 @@ constexpr double kLog1e9HoK = -3.036713188283967;     // log(1e9 h / k)
 constexpr double kLogUmToGHz = 12.610845707563017;    // log(299792.458)
 
 // diagnostic build only: s_memtime stamps from inside the prologue (tools/probe_stamps.py)
+// (MBB_STAMPS_FINE besides: every stamp is a scalar memory read, a wait and a global store by one lane -- a few hundred
+// cycles each ON the chain they time; the coarse events of a diagnostic build are only honest without them)
 #ifdef MBB_STAMPS
 __device__ unsigned long long *g_pstamps;
+#endif
+#if defined(MBB_STAMPS) && defined(MBB_STAMPS_FINE)
 #define PSTAMP(i, dep) do { if (threadIdx.x == 0 && blockIdx.x < 65536 && g_pstamps) { \
     asm volatile("" ::"v"(dep)); g_pstamps[blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else

@@ -48,9 +48,11 @@ MBB_FLOWA_INST(true, true)
 #undef MBB_FLOWA_INST
 
 #include "mbb_serve.hip.h"
-#define MBB_SERVE_INST(OT, NA)                                     \
-    template __global__ void k_serve<OT, NA, false>(const LikeArgs); \
-    template __global__ void k_serve<OT, NA, true>(const LikeArgs);
+#define MBB_SERVE_INST(OT, NA)                                            \
+    template __global__ void k_serve<OT, NA, false, false>(const LikeArgs); \
+    template __global__ void k_serve<OT, NA, true, false>(const LikeArgs);  \
+    template __global__ void k_serve<OT, NA, false, true>(const LikeArgs);  \
+    template __global__ void k_serve<OT, NA, true, true>(const LikeArgs);
 MBB_SERVE_INST(false, false)
 MBB_SERVE_INST(false, true)
 MBB_SERVE_INST(true, false)

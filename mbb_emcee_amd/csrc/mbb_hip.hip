@@ -78,11 +78,13 @@ static size_t flowa_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W
            (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 192 + 64;
 }
 // ... and k_serve, the likelihood of given rows as a kernel that stays resident between boundary calls (mbb_serve.hip.h)
-template <bool OPTHIN, bool NOALPHA, bool STAGE>
+template <bool OPTHIN, bool NOALPHA, bool STAGE, bool OVL>
 __global__ void k_serve(const LikeArgs a);
-#define MBB_SERVE_EXT(OT, NA)                                               \
-    extern template __global__ void k_serve<OT, NA, false>(const LikeArgs); \
-    extern template __global__ void k_serve<OT, NA, true>(const LikeArgs);
+#define MBB_SERVE_EXT(OT, NA)                                                      \
+    extern template __global__ void k_serve<OT, NA, false, false>(const LikeArgs); \
+    extern template __global__ void k_serve<OT, NA, true, false>(const LikeArgs);  \
+    extern template __global__ void k_serve<OT, NA, false, true>(const LikeArgs);  \
+    extern template __global__ void k_serve<OT, NA, true, true>(const LikeArgs);
 MBB_SERVE_EXT(false, false)
 MBB_SERVE_EXT(false, true)
 MBB_SERVE_EXT(true, false)
@@ -240,7 +242,7 @@ struct mbb_ctx {
     unsigned long long buf_gen = 1;   // mbb_boundary_generation: bumped whenever the blocks below are freed and made anew
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
-    hipFunction_t mod_fn[64] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 16 k_flowr / k_flowa)
+    hipFunction_t mod_fn[80] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 16 k_flowr / k_flowa)
     hipEvent_t *launch_ev = nullptr; // != nullptr: two events to record right before and right behind the next launch
     long opt_launch_api = 1;     // 1 hipModuleLaunchKernel with a packed argument buffer (-0.2 us per call, profiles/r04/boundary_breakdown.txt); 0 hipLaunchKernel
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
@@ -287,7 +289,7 @@ struct mbb_ctx {
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
     long opt_la_rows = 0;     // ... candidates per wave of the workgroups that do so (1, 2 or 4)
-    size_t lds_granted[96] = {};   // dynamic-LDS ceiling already requested, per kernel variant
+    size_t lds_granted[112] = {};   // dynamic-LDS ceiling already requested, per kernel variant
     long last_wpb = 0, last_threads = 0, last_grid = 0, last_smem = 0, last_smode = 0, last_ahead = 0;
     unsigned long long *d_stamps = nullptr;   // diagnostic build only
     // rccl
@@ -592,7 +594,7 @@ extern "C" int mbb_set_limits(mbb_ctx *c, const double lowlim[5], const int32_t 
     c->has_uplim = 0;
     for (int i = 0; i < 5; ++i) c->lowlim[i] = lowlim[i];
     for (int i = 0; i < 6; ++i) {
-        c->uplim[i] = uplim[i];
+        c->uplim[i] = has_uplim[i] ? uplim[i] : INFINITY;      // (a wall that is not set: never a NaN in the argument block)
         if (has_uplim[i]) c->has_uplim |= (1u << i);
     }
     return MBB_OK;
@@ -1220,27 +1222,28 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     a.cov_in_lds = (c->has_cov && serve_lds_bytes(c->nb, c->npart, true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
     const size_t sm = serve_lds_bytes(c->nb, c->npart, a.cov_in_lds != 0);
     const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
-    // (the quadrature beside the constructor: a buffer of one value per sample behind the tables, when there is room)
-    const size_t fbuf_bytes = (size_t)c->nchunk * 64 * sizeof(double);
-    // -- and a chunk of samples at least for each of the twelve waves that work ahead: with fewer the extra barrier costs more
-    // than there is to gain (cfg1's one chunk: 8.5-8.7 -> 8.9 us per 25-row call; option 2: regardless)
+    // The quadrature beside the constructor (mbb_serve.hip.h): every wave but the first keeps both candidates of its own
+    // unit's samples in registers
+    // -- with a chunk of samples at least for each of twelve waves: with fewer the extra barrier costs more than there is to
+    // gain (cfg1's one chunk: 8.5-8.7 -> 8.9 us per 25-row call; option "serve_overlap" 2: regardless; 0: never)
     // -- and waves to work ahead with (a workgroup narrowed by option "block_threads" may have none besides the constructor's)
+    // -- and units of at most four chunks (option "seg_chunks")
     const bool ovl = c->opt_serve_overlap != 0 && (c->nchunk >= 12 || c->opt_serve_overlap == 2) && threads >= 256 &&
-                     sm + (stg ? table_bytes + 16 : 0) + fbuf_bytes <= dyn_limit;
+                     c->opt_seg_chunks >= 1 && c->opt_seg_chunks <= 4;
     a.spec_cfg = ovl ? 1 : 0;
-    const size_t sm_total = sm + (stg ? table_bytes + 16 : 0) + (ovl ? fbuf_bytes : 0);
+    const size_t sm_total = sm + (stg ? table_bytes + 16 : 0);
     if (sm_total > dyn_limit) return 1;
     HIPCHK(hipHostGetDevicePointer((void **)&a.chain6, c->h_gone, 0));
     a.pos6 = reinterpret_cast<double *>(c->w_door);
     a.seed = word;
     a.persist = (int)std::min<long>(std::max<long>(c->opt_serve_idle_us, 20), 1000000);
-    static void (*const stable[8])(const LikeArgs) = {
-        k_serve<false, false, false>, k_serve<false, false, true>, k_serve<false, true, false>, k_serve<false, true, true>,
-        k_serve<true, false, false>, k_serve<true, false, true>, k_serve<true, true, false>, k_serve<true, true, true>};
-    const int si = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+#define MBB_SV(OT, NA) k_serve<OT, NA, false, false>, k_serve<OT, NA, true, false>, k_serve<OT, NA, false, true>, k_serve<OT, NA, true, true>
+    static void (*const stable[16])(const LikeArgs) = {MBB_SV(false, false), MBB_SV(false, true), MBB_SV(true, false), MBB_SV(true, true)};
+#undef MBB_SV
+    const int si = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 4 + (ovl ? 2 : 0) + (stg ? 1 : 0);
     void (*kern)(const LikeArgs) = stable[si];
     if (static_lds(c) + sm_total > 60 * 1024) {
-        size_t &g = c->lds_granted[88 + si];
+        size_t &g = c->lds_granted[96 + si];
         if (sm_total > g) {
             size_t want = (sm_total + 16383) & ~(size_t)16383;
             if (want > dyn_limit) want = dyn_limit;
@@ -1251,8 +1254,10 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     *c->h_gone = 0;
     __atomic_store_n(c->w_door, word, __ATOMIC_RELAXED);
     __builtin_ia32_sfence();
-    hipLaunchKernelGGL(kern, dim3(c->cu_count), dim3(threads), sm_total, c->stream, a);
-    HIPCHK(hipGetLastError());
+    {
+        int rc = launch_packed(c, kern, 56 + si, c->cu_count, threads, sm_total, a);
+        if (rc) return rc;
+    }
     c->last_wpb = 1; c->last_threads = threads; c->last_grid = c->cu_count; c->last_smem = (long)sm_total;
     c->last_stage = stg ? 1 : 0; c->last_smode = 10;
     c->serving = true;
@@ -1273,12 +1278,12 @@ static int serve_request(mbb_ctx *c, int n)
     const long t_a = now_ns();
     // (the records exist once a server has been started; before that serve_start makes them)
     if (!c->h_srv) {
-        HIPCHK(hipHostMalloc((void **)&c->h_srv, (size_t)c->cu_count * 16, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostMalloc((void **)&c->h_srv, (size_t)c->cu_count * 8 * kSrvStride, hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer((void **)&c->dv_srv, c->h_srv, 0));
         c->srv_cap = (size_t)c->cu_count;
     }
     uint64_t *hr = reinterpret_cast<uint64_t *>(c->h_srv);
-    for (int i = 0; i < n; ++i) hr[2 * i + 1] = (uint64_t)kStatusSentinel;
+    for (int i = 0; i < n; ++i) hr[kSrvStride * i + 1] = (uint64_t)kStatusSentinel;
     const unsigned long long word = (++c->srv_seq << 16) | (unsigned long long)n;
     __builtin_ia32_sfence();                       // the caller's rows, through the BAR, before the request
     const long t_b = now_ns();
@@ -1297,9 +1302,9 @@ static int serve_request(mbb_ctx *c, int n)
     bool seen = false;
     for (long spins = 0;; ++spins) {
         // a record is one 16-byte store: when its status word has turned, its lnl is there
-        while (i < n && __atomic_load_n(&hr[2 * i + 1], __ATOMIC_ACQUIRE) != (uint64_t)kStatusSentinel) {
-            c->h_lnl[i] = c->h_srv[2 * i];
-            c->h_status[i] = (int32_t)hr[2 * i + 1];
+        while (i < n && __atomic_load_n(&hr[kSrvStride * i + 1], __ATOMIC_ACQUIRE) != (uint64_t)kStatusSentinel) {
+            c->h_lnl[i] = c->h_srv[kSrvStride * i];
+            c->h_status[i] = (int32_t)hr[kSrvStride * i + 1];
             ++i;
         }
         if (i == n) { seen = true; break; }

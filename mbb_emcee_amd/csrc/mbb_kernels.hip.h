@@ -120,6 +120,12 @@ struct LikeArgs {
         };
     };
 };
+// k_serve's result records (pinned host memory): {lnl, status} every kSrvStride doubles -- a cache line each
+// (profiles/r05/served_boundary.txt; -DMBB_SRV_STRIDE=2: packed, four to a line, for the A/B)
+#ifndef MBB_SRV_STRIDE
+#define MBB_SRV_STRIDE 8
+#endif
+constexpr int kSrvStride = MBB_SRV_STRIDE;
 #ifndef MBB_STAMPS
 static_assert(sizeof(LikeArgs) == 480, "the argument block: every launch of every variant pays for its size");
 #endif

@@ -14,14 +14,16 @@
 //           -> workgroup b < n evaluates row b exactly as k_lnlike does (same constructor text, same units in the same
 //           order, same order of the band sums: bitwise the launch's results) and writes lnl / status into the pinned
 //           result slots, which the host sees turn.
-// A row's evaluation is not the launch's three phases one after the other (constructor, quadrature, band sums: 2.5 + 2 + 0.5
-// us): what the quadrature needs of the constructor for every sample on the blackbody side of the merge point -- h/kT, its
-// log, beta, log x0 -- is a division and two logs away from the parameters, and what takes the constructor its time, the
-// merge point itself (a root), only says WHICH samples are on the other side.  So once those few scalars are in LDS, twelve
-// waves work out the blackbody-side value of every sample into a buffer while the first wave's row of 16 lanes finishes the
-// constructor; then the units are summed as ever -- sample by sample in the same order, each either the buffered value or,
-// beyond the merge point, the power law's -- so that every partial sum is bit for bit the launch's (spec_cfg bit 0; the
-// buffer is 512 bytes per chunk of LDS, and without room for it the phases run one after the other as in k_lnlike).
+// A row's evaluation is not the launch's three phases one after the other (constructor, quadrature, band sums): what the
+// quadrature needs of the constructor for a sample on the blackbody side of the merge point -- h/kT, its log, beta, log x0 --
+// and for one on the power-law side -- alpha, h/kT again: x^-alpha, without kappa -- is a division and two logs away from the
+// parameters, and what takes the constructor its time, the merge point itself (a root), only says WHICH side a sample is on.
+// So once those few scalars are in LDS every wave but the first works out BOTH candidates of every sample of ITS unit (unit
+// u is wave u + 1's) and keeps them in registers while the first wave's row of 16 lanes finishes the constructor; behind it
+// a unit is, per chunk, a comparison, a selection, the product with kappa and the fma with the weight -- sample by sample in
+// the launch's order, each value the very one fnu_sample would have formed, so that every partial sum is bit for bit the
+// launch's -- and its reduction (spec_cfg bit 0; units beyond the waves' number are evaluated behind the constructor, as in
+// k_lnlike; without the bit -- few samples, a narrow workgroup -- the phases run one after the other).
 // The kernel leaves when told to (the doorbell says QUIT: any other use of the context, its destruction) or when
 // workgroup 0 has seen no request for `idle` polls (~1 us each; it then writes QUIT itself so that every workgroup
 // follows); every workgroup besides has a safety limit of its own (four times that).  Whatever goes wrong -- a request
@@ -41,7 +43,7 @@ __host__ __device__ constexpr size_t serve_lds(size_t nb, size_t npart, bool cov
 // Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl = the pinned
 // result records [row]{lnl, status as a 64-bit integer}, pos6 = the doorbell (one 8-byte word: request number << 16 | rows), seed = the request the
 // launch itself carries (served at once), persist = idle limit in polls, chain6 = the host's "gone" word (pinned).
-template <bool OPTHIN, bool NOALPHA, bool STAGE>
+template <bool OPTHIN, bool NOALPHA, bool STAGE, bool OVL>
 __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -65,13 +67,18 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0);
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0);
     const unsigned long long *door = reinterpret_cast<const unsigned long long *>(a.pos6);
-    const bool overlap = (a.spec_cfg & 1) != 0;                           // the quadrature starts beside the constructor
-    double *fbuf = s_wt + (STAGE ? a.nchunk * 64 : 0);                    // [nchunk * 64] with `overlap`: a sample's blackbody-side value
+    // OVL: the quadrature starts beside the constructor (see above) -- a template parameter, so that each instantiation holds
+    // one of the two ways only: with both in one kernel the constructor's chain was compiled with spills to scratch
+    constexpr bool overlap = OVL;
     __shared__ WalkerK kfin;
+    __shared__ double s_row[5];          // `overlap`: the row's five values for the wave that works out the penalties
 
-    // ---- once: the tables and the data to LDS
-    {
-        const int nt = (int)blockDim.x;
+    // ---- once: the tables and the data to LDS.  By every wave but the first, which goes straight for its row: the first
+    // request is in the launch and the constructor needs none of this -- the first
+    // barrier every wave passes (behind the scalars with OVL, behind the constructor without) is also the one behind the
+    // staging.  (A workgroup narrowed to one wave stages as it did.)
+    if (wave > 0 || nwave == 1) {
+        const int nt = (int)blockDim.x - (nwave > 1 ? 64 : 0), tid = (int)threadIdx.x - (nwave > 1 ? 64 : 0);
         const double2 *gb = reinterpret_cast<const double2 *>(a.poly_b);
         const double2 *gc = reinterpret_cast<const double2 *>(a.poly_c);
         double2 *lb = reinterpret_cast<double2 *>(s_pb);
@@ -96,16 +103,33 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     auto T_ln = [&](int i) { if constexpr (STAGE) return s_lnnu[i]; else return a.lnnu[i]; };
     auto T_wt = [&](int i) { if constexpr (STAGE) return s_wt[i]; else return a.wt[i]; };
     const SampleTabs tabs = {s_tab, s_pb, s_pc};
+    // (with `overlap` unit u is wave u + 1's: wave 0 has the constructor)
     int4 us_first = make_int4(0, 0, 0, 0);
-    if (wave < nun) us_first = a.unit_tab[wave];
-    __syncthreads();
+    {
+        const int u = overlap ? wave - 1 : wave;
+        if (u >= 0 && u < nun) us_first = a.unit_tab[u];
+    }
+    if (nwave == 1) __syncthreads();
 
     // diagnostic build: when things happened in a workgroup's latest request, on the clock all CUs share (100 MHz):
     // stamps[workgroup * 16 + event], tools/probe_serve_stamps.py
 #ifdef MBB_STAMPS
+// (MBB_STAMPS_MIN: only "request seen" and "result stored" -- every stamp is a scalar memory read, a wait and a store ON
+// the path it times, ~0.1-0.3 us each: the seven together make a request a microsecond longer than it is)
+#ifdef MBB_STAMPS_MIN
+#define SV_EV(ev) do { if ((ev) == 0 || (ev) == 6) { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (ev)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
 #define SV_EV(ev) do { if (tid == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (ev)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+// ... and per wave (workgroups 0..63): stamps[4096 + workgroup * 64 + wave * 4 + k]
+#ifdef MBB_STAMPS_MIN
+#define SV_WV(k) do { } while (0)
+#else
+#define SV_WV(k) do { if (lane == 0 && a.stamps && blockIdx.x < 64) a.stamps[4096 + (size_t)blockIdx.x * 64 + wave * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
 #else
 #define SV_EV(ev) do { } while (0)
+#define SV_WV(k) do { } while (0)
 #endif
     unsigned long long cur = a.seed;                 // the request the launch carries
     const long long idle = a.persist > 0 ? (long long)a.persist : 1000;
@@ -118,6 +142,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             SV_EV(0);
             bool mine = false;
             double p[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, lT = 0.0, lL = 0.0;
+            int st0 = ROW_OK;
             if (tid < 16) {
                 mine = true;
                 // the row's five values in ONE request (lane i takes element i; the block is fine-grained memory the
@@ -139,13 +164,19 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     vlog<true>(lo, p[0], p[2]);
                     lT = lo[0]; lL = lo[1];
                 }
-                if (overlap && tid == 0) {
-                    // what a blackbody-side sample needs, exactly as sed_prologue / make_walker_k form it (the constructor
-                    // below forms them again; the record is replaced by its own behind the barrier)
-                    bool ok = true;
+                if constexpr (overlap) {
+                    // the gate (likelihood.py:643-670; NaN and +-inf: mbb_walker_consts.inc), once, here
+                    bool okl = true;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) ok = ok && !(p[i] < a.lowlim[i]);
-                    ok = ok && finite5(p) && !(!NOALPHA && p[3] <= 0.0) && !(p[1] < 0.0);
+                    for (int i = 0; i < 5; ++i) okl = okl && !(p[i] < a.lowlim[i]);
+                    st0 = !okl ? (int)ROW_BELOW_LOWLIM : (!finite5(p) ? (int)ROW_NONFINITE : (int)ROW_OK);
+                }
+                if (overlap && tid == 0) {
+                    // what a sample needs on either side of the merge point, exactly as sed_prologue / make_walker_k form it
+                    // (the constructor below forms them again, into a record of its own)
+                    const bool ok = st0 == ROW_OK && !(!NOALPHA && p[3] <= 0.0) && !(p[1] < 0.0);
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) s_row[i] = p[i];
                     WalkerK k0;
                     k0.hokt9 = m_div(1e9 * kH / kK, p[0]);
                     k0.lhokt9 = kLog1e9HoK - lT;
@@ -162,96 +193,199 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             if (overlap) __syncthreads();
             SV_EV(2);
             const bool ahead = overlap && wk[0].status == ROW_OK;           // workgroup-uniform
-            // (the constructor is one dependent chain and runs fastest on a SIMD it has to itself: with sixteen waves its
-            // SIMD's other three -- waves 4, 8, 12 -- sit this part out)
-            const bool spare_simd = nwave == 16;
-            const int nqw = spare_simd ? 12 : nwave - 1, qw = spare_simd ? wave - 1 - (wave >> 2) : wave - 1;
-            if (ahead && wave > 0 && !(spare_simd && (wave & 3) == 0)) {
-                // ---- the blackbody-side value of every sample, two chunks per step, on waves that have no constructor
-                const WalkerK k = wk[0];
-                const int nc = a.nchunk, stride = 2 * nqw;
-                for (int c = 2 * qw; c < nc; c += stride) {
+            // One unit's sum from samples evaluated now, behind the constructor (k_lnlike's do_unit): two chunks per step.
+            auto classic_unit = [&](const int4 us, const WalkerK &k) {
+                const int s = us.x, c0 = us.y, c1 = us.z;
+                double acc = 0.0;
+                int c = c0;
+                for (; c + 2 <= c1; c += 2) {
                     const int i0 = c * 64 + lane, i1 = i0 + 64;
-                    const bool two = c + 1 < nc;
-                    const double n0 = T_nu(i0), l0 = T_ln(i0);
-                    const double n1 = two ? T_nu(i1) : 1.0, l1 = two ? T_ln(i1) : 0.0;
+                    const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
+                    const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
                     const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
                     const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
-                    fbuf[i0] = f0;
-                    if (two) fbuf[i1] = f1;
+                    acc = fma(f0, q0, acc);
+                    acc = fma(f1, q1, acc);
                 }
-            }
-            if (mine) {
-                if (ahead) __builtin_amdgcn_s_setprio(3);
-                WalkerK k;
-                k.status = ROW_SKIP;
-                k.pad = 0;
-                double pen_u = 0.0, pen_g = 0.0;
-                {
-#ifdef MBB_STAMPS
-                    if (tid == 0 && a.stamps) a.stamps[blockIdx.x * 32 + 8] = __builtin_amdgcn_s_memtime();      // (one row: no clash with SV_EV's)
-#endif
-#include "mbb_walker_consts.inc"
-#ifdef MBB_STAMPS
-                    if (tid == 0 && a.stamps) { asm volatile("" ::"v"(pen_u + pen_g + k.cbb)); a.stamps[blockIdx.x * 32 + 10] = __builtin_amdgcn_s_memtime(); }
-#endif
+                if (c < c1) {
+                    const int i = c * 64 + lane;
+                    const double f = fnu_sample<OPTHIN, NOALPHA, true, false>(k, T_nu(i), T_ln(i), &tabs);
+                    acc = fma(f, T_wt(i), acc);
                 }
-                // (a record of its own: with the quadrature ahead its waves are still reading the first one)
-                if (tid == 0) {
-                    kfin = k;
+                return acc;
+            };
+            auto store_unit = [&](const int4 us, double acc) {
+                const int s = us.x;
+                if (us.w == 0) {
+                    acc = wave_sum(acc);
+                    if (lane == 0) partial[s] = acc;
+                } else if (us.w == 2) {
+                    acc = row_sum(acc);
+                    if ((lane & 15) == 0) {
+                        const int sl = a.tail_slot[4 * s + (lane >> 4)];
+                        if (sl >= 0) partial[sl] = acc;
+                    }
+                } else {
+                    partial[s + lane] = acc;
+                }
+            };
+            // Two paths that never meet inside a wave, so that neither's registers are live in the other (the candidates kept
+            // ahead are 16 registers; the constructor's chain wants most of the file): with `overlap` every wave but the first
+            // takes the first path whole -- barriers included: every wave passes two, whichever way it goes.
+            if (overlap && wave > 0) {
+                // The penalties that depend on the five parameters alone (soft upper walls, Gaussian priors: likelihood.py:672-752)
+                // are no part of the constructor's chain: the last wave -- it has the fewest units, if any -- works them out
+                // meanwhile, term by term as mbb_walker_consts.inc does (on the constructor's row of lanes they cost it 600 to
+                // 1700 cycles of comparisons against the argument block and of branches: tools/lat_ctor.hip); the peak
+                // wavelength's two terms, which follow them, are added in phase 3.
+                if (ahead && wave == nwave - 1 && lane == 0) {
+                    double pen_u = 0.0, pen_g = 0.0;
+                    if (a.has_uplim | a.has_gprior) {
+                        double q[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) q[i] = s_row[i];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+                            if (((a.has_uplim >> i) & 1u) && q[i] > a.uplim[i]) {
+                                double lw = 0.02 * (a.uplim[i] - a.lowlim[i]);
+                                double d = q[i] - a.uplim[i];
+                                pen_u -= 0.5 * d * d / (lw * lw);
+                            }
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+                            if ((a.has_gprior >> i) & 1u) {
+                                double d = q[i] - a.gmean[i];
+                                pen_g = fma(-0.5 * a.givar[i] * d, d, pen_g);
+                            }
+                    }
                     pen[0] = pen_u;
                     pen[1] = pen_g;
                 }
-                SV_EV(3);
-                if (ahead) __builtin_amdgcn_s_setprio(0);
-            }
-            __syncthreads();
-            // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
-            SV_EV(4);
-            if (kfin.status == ROW_OK) {
-                const WalkerK k = kfin;
-                // a sample's value: the buffered one, or the power law's beyond the merge point -- as fnu_sample decides
-                auto value = [&](int i, double nu, double lnnu) {
-                    if (!ahead) return fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, lnnu, &tabs);
-                    if constexpr (!NOALPHA) {
-                        if (k.hokt9 * nu > k.xmerge) return fnu_wien_tab(k, k.lhokt9 + lnnu, &tabs);
-                    }
-                    return fbuf[i];
-                };
-                for (int u = wave; u < nun; u += nwave) {
-                    const int4 us = (u == wave) ? us_first : a.unit_tab[u];
-                    const int s = us.x, c0 = us.y, c1 = us.z;
-                    double acc = 0.0;
-                    int c = c0;
-                    for (; c + 2 <= c1; c += 2) {                     // two chunks per step (k_lnlike, do_unit)
-                        const int i0 = c * 64 + lane, i1 = i0 + 64;
-                        const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
-                        const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
-                        const double f0 = value(i0, n0, l0);
-                        const double f1 = value(i1, n1, l1);
-                        acc = fma(f0, q0, acc);
-                        acc = fma(f1, q1, acc);
-                    }
-                    if (c < c1) {
-                        const int i = c * 64 + lane;
-                        const double f = value(i, T_nu(i), T_ln(i));
-                        acc = fma(f, T_wt(i), acc);
-                    }
-                    if (us.w == 0) {
-                        acc = wave_sum(acc);
-                        if (lane == 0) partial[s] = acc;
-                    } else if (us.w == 2) {
-                        acc = row_sum(acc);
-                        if ((lane & 15) == 0) {
-                            const int sl = a.tail_slot[4 * s + (lane >> 4)];
-                            if (sl >= 0) partial[sl] = acc;
+                double rg_f[4], rg_w[4];             // (h/kT nu and the weight are read again behind the barrier: registers)
+                SV_WV(0);
+                if (ahead) {
+                    const WalkerK k = wk[0];
+                    const int c0 = us_first.y, c1 = us_first.z;          // (no unit: c0 == c1 == 0)
+                    // The merge point lies between x = 2 + alpha and x = 3 + alpha + beta (thick: thick_merge_root's bracket;
+                    // thin: a - 1 < xmerge < a with a = 3 + alpha + beta).  A sample at or below the first is never on the
+                    // power-law side, one beyond the second always: each gets the one candidate it can need.  (A chunk is
+                    // 64 neighbouring frequencies of one band: the lanes mostly agree.)
+                    const double xlo = 2.0 + k.alpha, xhi = 3.0 + k.alpha + k.beta;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // (one sample at a time, in this order: two at once, as classic_unit takes them, want more registers
+                        // than there are beside the candidates kept)
+                        MBB_FENCE();
+                        if (c0 + j < c1) {
+                            const int i = (c0 + j) * 64 + lane;
+                            const double nu = T_nu(i), ln = T_ln(i);
+                            const double x = k.hokt9 * nu;
+                            rg_f[j] = 0.0;
+                            if (NOALPHA || !(x > xhi)) rg_f[j] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, ln, &tabs);
+                            if constexpr (!NOALPHA) {
+                                rg_w[j] = 0.0;
+                                if (x > xlo) rg_w[j] = m_exp_t<true, false>(-k.alpha * (k.lhokt9 + ln), tabs.e);
+                            }
                         }
-                    } else {
-                        partial[s + lane] = acc;
                     }
                 }
+                SV_WV(1);
+                __syncthreads();
+                SV_WV(2);
+                // ---- phase 2: a unit is a comparison, a selection and an fma per chunk, then its reduction
+                // (kfin.status is ROW_OK only for a row the scalars were made for: `ahead` holds)
+                if (kfin.status == ROW_OK) {
+                    const int c0 = us_first.y, c1 = us_first.z;
+                    if (c0 < c1) {
+                        // (everything asked of LDS at once -- frequencies and weights of all four chunks, clamped to the unit's
+                        // last one where it has fewer, and the record's three values: one wait, not five in a row)
+                        double nx[4], qw[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int i = min(c0 + j, c1 - 1) * 64 + lane;
+                            nx[j] = T_nu(i);
+                            qw[j] = T_wt(i);
+                        }
+                        const double xm = kfin.xmerge, kap = kfin.kap, hk = kfin.hokt9;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c0 + j < c1) {
+                                double f = rg_f[j];
+                                if constexpr (!NOALPHA) {
+                                    const double pl = kap * rg_w[j];                 // fnu_wien_tab's value
+                                    f = (hk * nx[j] > xm) ? pl : f;                  // (fnu_sample's comparison)
+                                }
+                                acc = fma(f, qw[j], acc);
+                            }
+                        store_unit(us_first, acc);
+                    }
+                    // (more units than waves to keep them: the rest as a launch does them)
+                    if (wave - 1 + (nwave - 1) < nun) {
+                        const WalkerK k = kfin;
+                        for (int u = wave - 1 + (nwave - 1); u < nun; u += nwave - 1) {
+                            const int4 us = a.unit_tab[u];
+                            store_unit(us, classic_unit(us, k));
+                        }
+                    }
+                }
+                SV_WV(3);
+                __syncthreads();
+            } else {
+                if (mine) {
+                    if (ahead) __builtin_amdgcn_s_setprio(3);
+                    WalkerK k;
+                    k.status = ROW_SKIP;
+                    k.pad = 0;
+                    double pen_u = 0.0, pen_g = 0.0;
+                    if constexpr (overlap) {
+                        // the constructor and nothing else: the gate was taken before the barrier, the parameter-only
+                        // penalties are another wave's (above), the peak wavelength's terms are added in phase 3
+                        k.status = st0;
+                        k.peak = 0.0;
+                        if (st0 == ROW_OK) {
+                            SedScalars s;
+                            k.status = sed_prologue<OPTHIN, NOALPHA, true>(p[0], p[1], p[3], p[4], lT, lL, a.nunorm, a.lnunorm, s, &k.pad);
+                            if (k.status == ROW_OK) {
+                                make_walker_k<OPTHIN, NOALPHA>(p[1], p[3], s, k);
+                                if (((a.has_uplim | a.has_gprior) >> 5) & 1u) {
+                                    int pst;
+                                    const double peak = sed_peak_wave<OPTHIN, true>(p[0], p[1], k.lx0, s.hcokt, pst);
+                                    if (pst != ROW_OK) k.status = pst;
+                                    k.peak = peak;
+                                }
+                            }
+                        }
+                        if (tid == 0) kfin = k;
+                    } else {
+#if defined(MBB_STAMPS) && defined(MBB_STAMPS_FINE)
+                        if (tid == 0 && a.stamps) a.stamps[blockIdx.x * 32 + 8] = __builtin_amdgcn_s_memtime();      // (one row: no clash with SV_EV's)
+#endif
+#include "mbb_walker_consts.inc"
+#if defined(MBB_STAMPS) && defined(MBB_STAMPS_FINE)
+                        if (tid == 0 && a.stamps) { asm volatile("" ::"v"(pen_u + pen_g + k.cbb)); a.stamps[blockIdx.x * 32 + 10] = __builtin_amdgcn_s_memtime(); }
+#endif
+                        if (tid == 0) {
+                            kfin = k;
+                            pen[0] = pen_u;
+                            pen[1] = pen_g;
+                        }
+                    }
+                    SV_EV(3);
+                    if (ahead) __builtin_amdgcn_s_setprio(0);
+                }
+                __syncthreads();
+                // ---- phase 2 (k_lnlike's): the walker's units dealt to the waves
+                SV_EV(4);
+                if (!overlap && kfin.status == ROW_OK) {
+                    const WalkerK k = kfin;
+                    for (int u = wave; u < nun; u += nwave) {
+                        const int4 us = (u == wave) ? us_first : a.unit_tab[u];
+                        store_unit(us, classic_unit(us, k));
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
             SV_EV(5);
             // ---- phase 3 (k_lnlike's): band sums in fixed order, lnL -> the pinned result slots
             if (wave == 0) {
@@ -293,19 +427,34 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     if (st == ROW_BELOW_LOWLIM) r = -__builtin_inf();
                     else if (st != ROW_OK) r = __builtin_nan("");
                     else {
-                        r = fma(-0.5, acc, pen[0]);                    // :828
-                        if (a.has_gprior) r += pen[1];                 // :830-831
+                        double pen_u = pen[0], pen_g = pen[1];
+                        if (overlap && (((a.has_uplim | a.has_gprior) >> 5) & 1u)) {
+                            // the peak wavelength's wall and prior, behind the five parameters' as in mbb_walker_consts.inc
+                            const double peak = kfin.peak;
+                            if (((a.has_uplim >> 5) & 1u) && peak > a.uplim[5]) {  // likelihood.py:710-715
+                                double lw = 0.02 * a.uplim[5], d = peak - a.uplim[5];
+                                pen_u -= 0.5 * d * d / (lw * lw);
+                            }
+                            if ((a.has_gprior >> 5) & 1u) {                        // :748-750
+                                double d = peak - a.gmean[5];
+                                pen_g = fma(-0.5 * a.givar[5] * d, d, pen_g);
+                            }
+                        }
+                        r = fma(-0.5, acc, pen_u);                     // :828
+                        if (a.has_gprior) r += pen_g;                  // :830-831
                     }
                     // lnl and status as ONE 16-byte store into the row's result record (pinned host memory): every
                     // store is a PCIe write of its own and they leave one after the other -- two per row cost 125 rows
-                    // ~2 us more than one.  The host takes a row when its status word has turned.
+                    // ~2 us more than one.  The host takes a row when its status word has turned.  A record has a cache
+                    // line of its own (kSrvStride): four to a line, each write was a read-modify-write of a line the host
+                    // was polling -- 125 rows 9.2 -> 8.3 us (tools/ab_m1.py); the whole line in one 64-byte write: 8.5.
                     // (system scope -- straight through to the host -- spelled out: there is no 16-byte atomic store to
                     // ask the compiler for, and a non-temporal one may stay in L2 until the kernel ends)
                     typedef int v4i __attribute__((ext_vector_type(4)));
                     const long long rb = __double_as_longlong(r), sb = (long long)(a.debug ? (st | (kfin.pad << 8)) : st);
                     v4i rec;
                     rec.x = (int)rb; rec.y = (int)(rb >> 32); rec.z = (int)sb; rec.w = (int)(sb >> 32);
-                    double *dst = a.lnl + 2 * (size_t)w;
+                    double *dst = a.lnl + kSrvStride * (size_t)w;
                     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(rec) : "memory");
                     SV_EV(6);
                 }
@@ -329,7 +478,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 __builtin_amdgcn_s_sleep(8);
             }
             s_req[turn & 1] = v;
-#ifdef MBB_STAMPS
+#if defined(MBB_STAMPS) && !defined(MBB_STAMPS_MIN)
             if (a.stamps) a.stamps[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memrealtime();     // (the word was seen)
 #endif
         }

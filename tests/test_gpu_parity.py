@@ -51,7 +51,9 @@ def boundary_eval(like, pars, path):
     say that every batch was answered by the resident kernel -- a silent fall-back to a launch cannot pass."""
     pars = np.ascontiguousarray(pars, dtype=np.float64)
     if path == "launched":
-        return like(pars)
+        # (k_lnlike: the general path's kernel -- model_flux, row status, batches beyond a row per CU)
+        lnl, st = like._sync_device().lnlike_batch(np.atleast_2d(pars))
+        return float(lnl[0]) if pars.ndim == 1 else lnl
     ctx = like._sync_device()
     saved_after = 3
     ctx.set_option("serve", 2); ctx.set_option("serve_after", 1)
@@ -196,7 +198,7 @@ def test_lnlike_cfg1_delta(mbb, g_lnl, name, opthin, noalpha, path):
     np.testing.assert_array_equal(like.uplims, g_lnl[k + "/uplim"])
     pars = g_lnl[k + "/pars"]
     got = boundary_eval(like, pars, path)
-    lnl_close(got, g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (served)")
+    lnl_close(got, g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (%s)" % path)
     fin = np.isfinite(g_lnl[k + "/lnl"])
     mf = like.model_flux(pars[fin])
     rel_below("band flux", mf, g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
@@ -215,7 +217,7 @@ def test_lnlike_cfg2_passbands(mbb, g_lnl, name, opthin, noalpha, path):
     like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
     rec_allclose(like.uplims, g_lnl[k + "/uplim"], rtol=1e-15, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
-    lnl_close(boundary_eval(like, pars, path), g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (served)")
+    lnl_close(boundary_eval(like, pars, path), g_lnl[k + "/lnl"], kind="lnL" if path == "launched" else "lnL (%s)" % path)
     fin = np.isfinite(g_lnl[k + "/lnl"])
     rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
@@ -230,7 +232,7 @@ def test_lnlike_cfg4_covariance(mbb, g_lnl, name, opthin, noalpha, path):
     rec_allclose(like.data_wave, g_lnl[k + "/eff_wave"], rtol=1e-14, kind="host bookkeeping")
     pars = g_lnl[k + "/pars"]
     lnl_close(boundary_eval(like, pars, path), g_lnl[k + "/lnl"],
-              kind="lnL (covariance)" if path == "launched" else "lnL (covariance, served)")
+              kind="lnL (covariance)" if path == "launched" else "lnL (covariance, %s)" % path)
     fin = np.isfinite(g_lnl[k + "/lnl"])
     rel_below("band flux", like.model_flux(pars[fin]), g_lnl[k + "/model_flux"][fin], FLUX_RTOL)
 
@@ -251,7 +253,7 @@ def test_lnlike_priors_and_peak(mbb, g_lnl, path):
     like.set_uplim("fnorm", 41.0)
     like.set_lowlim("beta", 1.5)
     pars = g_lnl["cfg2/priors/pars"]
-    kind = "lnL" if path == "launched" else "lnL (served)"
+    kind = "lnL" if path == "launched" else "lnL (%s)" % path
     lnl_close(boundary_eval(like, pars, path), g_lnl["cfg2/priors/lnl"], kind=kind)
     like.set_gaussian_prior("lambda_peak", 260.0, 15.0)
     like.set_uplim("lambda_peak", 265.0)
@@ -1633,9 +1635,9 @@ def test_random_configurations_vs_oracle(mbb, oracle, seed, path):
     like.context.set_option("block_threads", int(rng.choice([0, 64, 256, 640, 1024])))
     got = boundary_eval(like, pars, path)
     like.context.set_option("walkers_per_group", 0); like.context.set_option("block_threads", 0)
-    lnl_close(got, ref, kind=("lnL (covariance%s)" % (", served" if path == "served" else "")) if cov is not None else
-              ("lnL" if path == "launched" else "lnL (served)"))
-    # (and the two ways agree bit for bit: the other one now, default geometry)
+    lnl_close(got, ref, kind=("lnL (covariance%s)" % ("" if path == "launched" else ", " + path)) if cov is not None else
+              ("lnL" if path == "launched" else "lnL (%s)" % path))
+    # (and the ways agree bit for bit: another one now, default geometry)
     assert np.array_equal(got, boundary_eval(like, pars, "served" if path == "launched" else "launched"), equal_nan=True)
 
 

@@ -33,4 +33,10 @@ for n in [int(a) for a in sys.argv[1:]] or [125, 1]:
         if n == 1:
             raw = st.reshape(-1).astype(np.int64)
             print("   constructor, core cycles (one row): sed_prologue %d, the rest (record, penalties) %d" % (raw[9] - raw[8], raw[10] - raw[9]))
+        if ovl:
+            # per wave, workgroup 0: ahead pass start / end, barrier passed, unit summed -- ns after the workgroup's 'request seen'
+            wv = st.reshape(-1)[4096:4096 + 64].reshape(16, 4).astype(np.float64) * 10.0 - ev[0, 0]
+            print("   per wave of workgroup 0 (ns after 'request seen'):  ahead begins / ends | behind the barrier / unit stored")
+            for w_ in range(1, 16):
+                print("      wave %2d  %6.0f %6.0f | %6.0f %6.0f" % (w_, wv[w_, 0], wv[w_, 1], wv[w_, 2], wv[w_, 3]))
         print("   spread of 'request seen' over the workgroups: %.0f ns; of 'result stored': %.0f ns" % (ev[:, 0].max() - ev[:, 0].min(), ev[:, 6].max() - ev[:, 6].min()))
