@@ -256,6 +256,9 @@ struct mbb_ctx {
     WalkerK *d_sed_wk = nullptr;
     // options
     long opt_wpb = 0, opt_threads = 0, opt_seg_chunks = 4, opt_debug = 0;
+    long opt_prepass = -1, last_prepass = 0;   // big batches: the constructors by k_walker_pre, a lane per walker (launch_lnlike)
+    double *d_pre = nullptr;                   // ... its records
+    size_t pre_cap = 0;                        // (doubles)
     long opt_zero_copy = 1;   // host path: kernel reads/writes pinned host memory (26 vs 34 us per call)
     long opt_stage = -1;      // -1 auto, 0 never, 1 whenever the tables fit in LDS
     long opt_roof_wgs = 0, opt_roof_threads = 0;   // measurement: geometry of mbb_roof_probe
@@ -479,6 +482,7 @@ extern "C" void mbb_ctx_destroy(mbb_ctx *c)
     free_dev(c->w_pars);
     free_dev(c->w_door); free_host(c->h_gone); free_host(c->h_srv);
     free_dev(c->d_gather); free_host(c->h_gather);
+    free_dev(c->d_pre);
     free_dev(c->d_sed_pars); free_dev(c->d_sed_out); free_dev(c->d_sed_status);
     free_dev(c->d_sed_wk);
     for (int i = 0; i < 2; ++i)
@@ -864,6 +868,29 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     if (smem > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
     c->last_wpb = wpb; c->last_threads = threads; c->last_grid = grid;
     a.nsrc = c->nsrc;
+    // Big batches of given rows: gate, constructor and penalties by a pass of their own with a LANE per walker (k_walker_pre)
+    // -- where a launch is bound by the number of instructions it issues, a row of 16 lanes per walker spends a quarter of
+    // them on the constructors (cfg5's 250 000 rows: 1.31 -> 1.0x ms).  Option "prepass": -1 auto (from 64 walkers per CU),
+    // 0 never, 1 always.
+    c->last_prepass = 0;
+    if (!sl && (c->opt_prepass > 0 || (c->opt_prepass < 0 && (long)n >= 64L * c->cu_count))) {
+        const size_t need = (size_t)n * kPreWords;
+        if (need > c->pre_cap) {
+            size_t cap = c->pre_cap ? c->pre_cap : 16384 * (size_t)kPreWords;
+            while (cap < need) cap *= 2;
+            HIPCHK(hipStreamSynchronize(c->stream));
+            free_dev(c->d_pre); c->d_pre = nullptr; c->pre_cap = 0;
+            HIPCHK(hipMalloc((void **)&c->d_pre, cap * sizeof(double)));
+            c->pre_cap = cap;
+        }
+        a.spec = c->d_pre;
+        a.xargs = nullptr;
+        static void (*const ptable[4])(const LikeArgs) = {k_walker_pre<false, false>, k_walker_pre<false, true>,
+                                                          k_walker_pre<true, false>, k_walker_pre<true, true>};
+        hipLaunchKernelGGL(ptable[(c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)], dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+        HIPCHK(hipGetLastError());
+        c->last_prepass = 1;
+    }
     a.rows_per_src = 0;
     a.nw_src = 0;
     if (c->nsrc > 1) {
@@ -2259,6 +2286,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
     else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
     else if (!strcmp(name, "serve_lease_us")) c->opt_serve_lease_us = value < 0 ? 0 : value;
+    else if (!strcmp(name, "prepass")) c->opt_prepass = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
     else if (!strcmp(name, "xchg_spin_max")) c->x.spin_max = value;
     else if (!strcmp(name, "lookahead_sampler")) c->opt_lookahead = value;
@@ -2288,6 +2316,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "serving")) *value = c->serving ? 1 : 0;
     else if (!strcmp(name, "serve_requests")) *value = c->srv_requests;
     else if (!strcmp(name, "serve_fallbacks")) *value = c->srv_fallbacks;
+    else if (!strcmp(name, "last_prepass")) *value = c->last_prepass;
     else if (!strcmp(name, "serve_enabled")) *value = c->opt_serve;
     else if (!strcmp(name, "device_peers")) *value = mbbh::registry_peers(c->reg_key, true);
     else if (!strcmp(name, "serve_peer_yields")) *value = c->srv_peer_yields;

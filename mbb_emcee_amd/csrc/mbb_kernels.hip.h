@@ -122,6 +122,12 @@ struct LikeArgs {
 };
 // k_serve's result records (pinned host memory): {lnl, status} every kSrvStride doubles -- a cache line each
 // (profiles/r05/served_boundary.txt; -DMBB_SRV_STRIDE=2: packed, four to a line, for the A/B)
+#ifndef MBB_WC_ROW
+#define MBB_WC_ROW true          // mbb_walker_consts.inc: the constructor on a row of 16 lanes (k_walker_pre: on one)
+#endif
+// k_walker_pre's records: {WalkerK: 13 words, pen_u, pen_g, -}
+constexpr int kPreWords = 16;
+static_assert(sizeof(mbbd::WalkerK) == 13 * sizeof(double), "a walker's record is 13 words");
 #ifndef MBB_SRV_STRIDE
 #define MBB_SRV_STRIDE 8
 #endif
@@ -858,6 +864,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
         k.status = ROW_SKIP;
         k.pad = 0;
         double pen_u = 0.0, pen_g = 0.0;
+        bool pre_done = false;
         if (w < a.n) {
             double p[5], lT, lL = 0.0;
             if (SAMPLER) {
@@ -913,6 +920,15 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                     prop[j * 8 + 6] = srow5;
                     prop[j * 8 + 7] = lo[3];                  // ln u
                 }
+            } else if (a.spec) {
+                // big batches: gate, constructor and penalties were worked out by k_walker_pre, a LANE per walker (below), and
+                // are fetched: lane l of the row takes word l of the walker's record {WalkerK: 13 words, pen_u, pen_g, -}
+                const double v = a.spec[(size_t)w * kPreWords + (tid & 15)];
+                const int l = tid & 15;
+                double *wkd = reinterpret_cast<double *>(wk + j);
+                if (l < 13) wkd[l] = v;
+                else if (l < 15) pen[2 * j + (l - 13)] = v;
+                pre_done = true;
             } else {
 #pragma unroll
                 for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
@@ -927,10 +943,12 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                     lT = lo[0]; lL = lo[1];
                 }
             }
+            if (!pre_done) {
 #include "mbb_walker_consts.inc"
+            }
         }
         STAMPD(10, pen_u + pen_g);
-        if (lead) {
+        if (lead && !pre_done) {
             if (k.status == ROW_OK) wk[j] = k;
             else { wk[j].status = k.status; wk[j].pad = k.pad; }
             pen[2 * j] = pen_u;
@@ -1435,6 +1453,39 @@ __global__ void __launch_bounds__(1024) k_roof(const LikeArgs a, const WalkerK *
         clk[0] = __builtin_amdgcn_s_memtime() - c0;
         clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
+}
+
+// Gate, SED constructor and parameter-only penalties of n rows, a LANE per row (k_lnlike does them on a row of 16 lanes per
+// walker: right for an emcee half-step, where a constructor is latency, but ~600 wave instructions per walker -- a quarter
+// of everything a 250 000-row launch executes, profiles/r04/pmc_valu_cfg5_v5.json -- where only their number counts; a
+// lane per walker makes it ~40).  The same text, the same values (MBB_WC_ROW false: every exp where the row form deals
+// them to its lanes): records {WalkerK, pen_u, pen_g} in a.spec, kPreWords words each, which k_lnlike's phase 1 fetches.
+template <bool OPTHIN, bool NOALPHA>
+__global__ void __launch_bounds__(256) k_walker_pre(const LikeArgs a)
+{
+    [[maybe_unused]] const int tid = threadIdx.x;           // (the diagnostic build's stamps inside the text)
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.n) return;
+    double p[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
+    const double lT = m_log(p[0]), lL = OPTHIN ? 0.0 : m_log(p[2]);      // vlog<true> of k_lnlike's phase 1: the same m_log
+    WalkerK k;
+    k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+    k.status = ROW_SKIP;
+    k.pad = 0;
+    double pen_u = 0.0, pen_g = 0.0;
+#undef MBB_WC_ROW
+#define MBB_WC_ROW false
+#include "mbb_walker_consts.inc"
+#undef MBB_WC_ROW
+#define MBB_WC_ROW true
+    double *rec = a.spec + (size_t)w * kPreWords;
+    const double *kd = reinterpret_cast<const double *>(&k);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) rec[i] = kd[i];
+    rec[13] = pen_u;
+    rec[14] = pen_g;
 }
 
 // modified_blackbody.__init__ + max_wave for n rows, one lane per row.

@@ -362,6 +362,55 @@ def test_geometry_invariance(mbb, g_lnl, wpb, threads):
     assert np.array_equal(ref, got, equal_nan=True)
 
 
+@pytest.mark.parametrize("name,opthin,noalpha", VARIANTS)
+def test_prepass_lane_per_walker_equals_rows_of_lanes(mbb, g_lnl, name, opthin, noalpha):
+    """Big batches work out gate, SED constructor and penalties in a pass of their own with a LANE per walker
+    (k_walker_pre: mbb_walker_consts.inc with every exp evaluated where the row form deals them to its 16 lanes) and
+    k_lnlike fetches the records.  The same values bit for bit as with a row of lanes per walker: lnL, row status (rows
+    below a limit, NaN rows, rows the reference raises for), model fluxes; with priors and the peak wavelength's terms
+    (a second root); every model variant; batch sizes around the workgroup sizes.  And it is what a 250 000-row launch
+    takes by itself (`prepass` -1: from 64 rows per CU)."""
+    k = "cfg2/" + name
+    like = mbb.likelihood(noalpha=noalpha, opthin=opthin, response=True)
+    like.set_phot([str(b) for b in g_lnl["cfg2/bands"]], g_lnl[k + "/flux"], g_lnl[k + "/unc"])
+    like.set_gaussian_prior("T", 11.0, 2.0)
+    like.set_gaussian_prior("lambda_peak", 260.0, 15.0)
+    like.set_uplim("lambda_peak", 265.0)
+    like.set_uplim("fnorm", 41.0)
+    ctx = like._sync_device()
+    base = g_lnl[k + "/pars"]
+    pars = np.tile(base, (14, 1))[:4099].copy()
+    pars[7, 0] = np.nan; pars[11, 2] = np.inf
+    like.set_lowlim("alpha", -5.0); like.set_lowlim("beta", -5.0)     # (so that rows the reference raises for get past the gate)
+    pars[13, 3] = -1.0; pars[17, 1] = -0.5
+    ctx = like._sync_device()
+    for n in (1, 63, 257, 4099):
+        ctx.set_option("prepass", 0)
+        lnl0, st0, fl0 = ctx.lnlike_batch(pars[:n], want_flux=True)
+        assert ctx.info("last_prepass") == 0
+        ctx.set_option("prepass", 1)
+        lnl1, st1, fl1 = ctx.lnlike_batch(pars[:n], want_flux=True)
+        assert ctx.info("last_prepass") == 1
+        assert np.array_equal(st0, st1), n
+        assert np.array_equal(lnl0, lnl1, equal_nan=True) and np.array_equal(fl0, fl1, equal_nan=True), n
+    assert set(np.unique(st1)) >= {0, 1, 7} and (noalpha or 2 in st1) and 3 in st1
+    # other geometries fetch the same records
+    for wpb, thr in ((3, 256), (16, 512), (64, 1024)):
+        ctx.set_option("walkers_per_group", wpb); ctx.set_option("block_threads", thr)
+        assert np.array_equal(ctx.lnlike_batch(pars)[0], lnl1, equal_nan=True)
+    ctx.set_option("walkers_per_group", 0); ctx.set_option("block_threads", 0)
+    # by itself: only for big batches
+    ctx.set_option("prepass", -1)
+    ctx.lnlike_batch(pars)
+    assert ctx.info("last_prepass") == 0
+    big = np.tile(base, (64 * ctx.info("cu_count") // base.shape[0] + 1, 1))
+    lb = ctx.lnlike_batch(big)[0]
+    assert ctx.info("last_prepass") == 1
+    ctx.set_option("prepass", 0)
+    assert np.array_equal(ctx.lnlike_batch(big)[0], lb, equal_nan=True)
+    ctx.set_option("prepass", -1)
+
+
 def test_empty_and_bad_shapes(mbb, g_lnl):
     like, k = _like_cfg1(mbb, g_lnl, "thick_walpha", False, False)
     assert like(np.empty((0, 5))).shape == (0,)

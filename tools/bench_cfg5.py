@@ -30,6 +30,8 @@ def main():
     d_pars = ctx.alloc(flat.nbytes); d_pars.upload(flat)
     d_lnl = ctx.alloc(n * 8); d_st = ctx.alloc(n * 4)
     nq = ctx.info("nq")
+    if "--prepass" in sys.argv:
+        ctx.set_option("prepass", int(sys.argv[sys.argv.index("--prepass") + 1]))
     best = None
     sweep = [(0, 0)] if "--quick" in sys.argv else [(0, 0), (16, 256), (8, 512), (16, 512), (24, 512), (32, 512), (24, 384), (32, 1024), (48, 768), (48, 1024), (64, 1024)]
     if "--stage" in sys.argv:
