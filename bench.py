@@ -66,7 +66,7 @@ if os.environ.get("MBB_BENCH_WALKERS_PER_GPU"):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # vendor fp64 vector peak
 N_SIMD = 1024                  # 256 CUs x 4
-ONE_LAUNCH_FORMS = (7, 8, 9)   # sampler forms whose launches cover many half-steps: counters are taken per half-step
+ONE_LAUNCH_FORMS = (7, 9)   # sampler forms whose launches cover many half-steps: counters are taken per half-step
 # N > 1: what the supervisor allows the whole run, what a rank allows any one step that may wedge (communicator
 # set-up, a rehearsal, a timed run), and the age of the run beyond which nothing optional is started any more
 SUPERVISOR_DEADLINE_S, GUARD_S, OPTIONAL_UNTIL_S = 480.0, 45.0, 240.0
@@ -183,8 +183,8 @@ def kernel_key(form, opthin=False, noalpha=False, staged=True, pairs=None):
     if form == 7:
         key = "k_flowm<%s, %s, %s," % (b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
         return key + (" %d>" % pairs if pairs else "")
-    if form in (8, 9):          # the resident forms: k_flowr (nothing ahead), k_flowa (constructor a half-step ahead)
-        return "%s<%s, %s, %s>" % ("k_flowr" if form == 8 else "k_flowa", b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
+    if form == 9:               # the resident form: k_flowa (a workgroup owns walkers, the constructor a half-step ahead)
+        return "k_flowa<%s, %s, %s>" % (b[bool(opthin)], b[bool(noalpha)], b[bool(staged)])
     return "k_lnlike<%s, %s, %d, %s>" % (b[bool(opthin)], b[bool(noalpha)], form, b[bool(staged)])
 
 
@@ -422,7 +422,7 @@ def config_roofline(name, plain_us, half_step_us, form, half, ctx):
     roof = valu_roofline(plain, src, plain_us * 1e-6,
                          "k_lnlike<plain> n=%d (%d workgroups x %d threads)" % (half, ctx.info("last_grid"), ctx.info("last_threads"))) \
         if plain else {"bound": "fp64-valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None}
-    smp = next((v for k, v in d["kernels"].items() if any(n in k for n in ("k_flowm<", "k_flowa<", "k_flowr<")) and "counters_per_half_step" in v), None)
+    smp = next((v for k, v in d["kernels"].items() if any(n in k for n in ("k_flowm<", "k_flowa<")) and "counters_per_half_step" in v), None)
     if smp and form in ONE_LAUNCH_FORMS:
         sm = dict(smp)
         sm["counters_per_launch"] = smp["counters_per_half_step"]
@@ -1257,10 +1257,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
                 out["config"]["sampler_form"] = ("one launch per 4096 steps, the quadrature of both candidates ahead of the partner's "
                                                  "decision (k_flowm, form 7): the timed region is %d launch(es) of %d half-steps"
                                                  % (nlaunch, 2 * args.steps))
-            elif form in (8, 9):
-                kern_label = ("%s<thick,alpha,staged>: %d workgroups, each owning %d walker(s) of each half%s"
-                              % ("k_flowr" if form == 8 else "k_flowa", ctx.info("last_grid"), ctx.info("last_wpb"),
-                                 "; the constructor a half-step ahead for both outcomes of the partner's pending move" if form == 9 else ""))
+            elif form == 9:
+                kern_label = ("k_flowa<thick,alpha,staged>: %d workgroups, each owning %d walker(s) of each half; the constructor a "
+                              "half-step ahead for both outcomes of the partner's pending move" % (ctx.info("last_grid"), ctx.info("last_wpb")))
                 out["config"]["sampler_form"] = ("one launch per 4096 steps, resident (form %d): the timed region is %d launch(es) of %d "
                                                  "half-steps" % (form, nlaunch, 2 * args.steps))
             else:
@@ -1274,7 +1273,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
             out["config"]["sampler_form"] = "one launch per half-step (k_lnlike SMODE %d)" % form
             out["kernel_avg_us"] = k_us
         out["half_step_us"] = k_us
-        short_kern = ({7: "k_flowm", 8: "k_flowr", 9: "k_flowa"}.get(form, "k_lnlike") + "<thick,alpha,%sform %d> %d workgroups x %d threads"
+        short_kern = ({7: "k_flowm", 9: "k_flowa"}.get(form, "k_lnlike") + "<thick,alpha,%sform %d> %d workgroups x %d threads"
                       % ("staged," if run["staged"] else "", form, ctx.info("last_grid"), ctx.info("last_threads")))
         out["config"]["sampler_form_short"] = ("form %d: %s" % (form, "one launch per <=4096 steps" if form in (6,) + ONE_LAUNCH_FORMS
                                                                   else "one launch per half-step"))
@@ -1525,12 +1524,11 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     assert np.array_equal(like(last), got, equal_nan=True)
 
     # ---- the same chain in the sampler's other forms: a train of launches, one per half-step (what round 1 and the
-    # first half of round 2 timed), and the resident forms larger ensembles take (form 9: the constructor a half-step
-    # ahead; form 8: nothing ahead), here with one walker of each half per workgroup
+    # first half of round 2 timed), and the resident form larger ensembles take (form 9: the constructor a half-step
+    # ahead), here with one walker of each half per workgroup
     forms = {}
     for name, opts in (("one_launch_per_half_step", {"lookahead_sampler": 0}),
-                       ("resident_constructor_ahead_form9", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
-                       ("resident_nothing_ahead_form8", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0})):
+                       ("resident_constructor_ahead_form9", {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2})):
         for o, v in opts.items():
             ctx.set_option(o, v)
         s2 = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
@@ -1543,7 +1541,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
                        "kernel_form": ctx.info("last_kernel_form")}
         del s2
     ctx.set_option("lookahead_sampler", 1); ctx.set_option("flow_sampler", 1); ctx.set_option("merged_flow_sampler", 1)
-    ctx.set_option("resident_sampler", 1); ctx.set_option("resident_ahead", 1)
+    ctx.set_option("resident_sampler", 1)
     forms["note"] = "the other forms of the device sampler, same chain bit for bit (stream time, HIP events)"
     out["other_sampler_forms"] = forms
 
@@ -1570,7 +1568,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
         big["walkers_%d" % nwb] = row
     ctx.set_option("lookahead_sampler", 1)
     big["note"] = ("one ensemble of that many walkers on this GPU, 300 steps by HIP events; kernel_form 9 = resident with the "
-                   "constructor a half-step ahead (k_flowa), 8 = resident, nothing ahead (k_flowr), 1 = one launch per half-step; "
+                   "constructor a half-step ahead (k_flowa), 1 = one launch per half-step; "
                    "roofline_frac = algorithmic flops of a half-step (90 x NQ x walkers / 2) over its time, against the fp64 "
                    "vector peak")
     out["large_ensembles"] = big

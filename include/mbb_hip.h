@@ -254,9 +254,9 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * resident forms below too),
  * "resident_sampler" (default 1: ensembles beyond that run as ONE launch per 4096 steps as well, a workgroup owning
  * W = ceil(half / CUs) walkers of each half, up to 8; 0: off, the plain train; 2: every eligible ensemble takes it),
- * "resident_ahead" (default 1: up to six walkers per CU and half that run constructs every walker's proposal a half-step
- * ahead, for both outcomes of its partner's pending move, beside the quadrature of the half-step before -- "form 9",
- * k_flowa; beyond, and with 0, nothing runs ahead -- "form 8", k_flowr; 2: always ahead),
+ * that run -- "form 9", k_flowa -- constructs every walker's proposal a half-step ahead, for both outcomes of its partner's
+ * pending move, beside the quadrature of the half-step before ("resident_ahead", round 4's choice between it and a form
+ * with nothing ahead, is accepted and ignored: that form is gone),
  * "resident_walkers" (walkers per workgroup and half of the resident forms; 0 = the host's choice),
  * "lookahead_rows" / "lookahead_waves" (the sharded one-launch run: 0 = the host's choice of candidates per wave and
  * waves per workgroup among those that work ahead), "sharded_flow_sampler" (default 1: a sharded run with the

@@ -32,7 +32,6 @@ DEPS = [SRC, SRC_HOST, SRC_FLOW, SRC_REG, os.path.join(HERE, "csrc", "mbb_host_t
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),
         os.path.join(HERE, "csrc", "mbb_kernels.hip.h"),
         os.path.join(HERE, "csrc", "mbb_flowm.hip.h"),
-        os.path.join(HERE, "csrc", "mbb_flowr.hip.h"),
         os.path.join(HERE, "csrc", "mbb_flowa.hip.h"),
         os.path.join(HERE, "csrc", "mbb_serve.hip.h"),
         os.path.join(os.path.dirname(HERE), "include", "mbb_hip.h")]

@@ -1,4 +1,4 @@
-// mbb_flow.hip -- the one-launch sampler runs (k_flowm, k_flowr, k_flowa; k_lnlike SMODE 6, sharded) in a translation unit
+// mbb_flow.hip -- the one-launch sampler runs (k_flowm, k_flowa; k_lnlike SMODE 6, sharded) in a translation unit
 // of its own, because it wants other code generation than the rest of the library: the kernel
 // is a loop over half-steps around two long dependent chains, and with the default pipeline the
 // compiler hoists every loop-invariant value out of that loop, runs out of registers and
@@ -26,16 +26,6 @@ MBB_FLOWM_INST(false, true)
 MBB_FLOWM_INST(true, false)
 MBB_FLOWM_INST(true, true)
 #undef MBB_FLOWM_INST
-
-#include "mbb_flowr.hip.h"
-#define MBB_FLOWR_INST(OT, NA)                                     \
-    template __global__ void k_flowr<OT, NA, false>(const LikeArgs); \
-    template __global__ void k_flowr<OT, NA, true>(const LikeArgs);
-MBB_FLOWR_INST(false, false)
-MBB_FLOWR_INST(false, true)
-MBB_FLOWR_INST(true, false)
-MBB_FLOWR_INST(true, true)
-#undef MBB_FLOWR_INST
 
 #include "mbb_flowa.hip.h"
 #define MBB_FLOWA_INST(OT, NA)                                     \

@@ -1,7 +1,7 @@
 // mbb_flowa.hip.h -- k_flowa, sampler form 9: the resident run for ensembles of any size up to 8 walkers per CU and
 // half, with the SED constructor running one half-step ahead (single GPU, single ensemble).  Included by mbb_flow.hip.
 //
-// k_flowr (form 8) made the launch train resident: workgroup g owns walkers [g W, g W + W) of both halves and does a
+// Round 4's k_flowr (form 8, removed in round 5) made the launch train resident: workgroup g owns walkers [g W, g W + W) of both halves and does a
 // half-step as k_lnlike's launch does it -- constructor, then quadrature, then accept test, one after the other: 6.3 us
 // per half-step with one walker per workgroup, 11.5 with four, of which the constructor is 3.6 whatever W is (the
 // walkers' rows of 16 lanes run it in lock-step).  Here the constructor of half-step j + 1 runs WHILE half-step j is in

@@ -50,17 +50,6 @@ MBB_FLOWM_EXT(false, true)
 MBB_FLOWM_EXT(true, false)
 MBB_FLOWM_EXT(true, true)
 #undef MBB_FLOWM_EXT
-// ... and k_flowr, sampler form 8: the launch train made resident (mbb_flowr.hip.h)
-template <bool OPTHIN, bool NOALPHA, bool STAGE>
-__global__ void k_flowr(const LikeArgs a);
-#define MBB_FLOWR_EXT(OT, NA)                                               \
-    extern template __global__ void k_flowr<OT, NA, false>(const LikeArgs); \
-    extern template __global__ void k_flowr<OT, NA, true>(const LikeArgs);
-MBB_FLOWR_EXT(false, false)
-MBB_FLOWR_EXT(false, true)
-MBB_FLOWR_EXT(true, false)
-MBB_FLOWR_EXT(true, true)
-#undef MBB_FLOWR_EXT
 // ... and k_flowa, form 9: the same resident run with the constructor a half-step ahead (mbb_flowa.hip.h)
 template <bool OPTHIN, bool NOALPHA, bool STAGE>
 __global__ void k_flowa(const LikeArgs a);
@@ -95,12 +84,7 @@ static size_t serve_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)         
 {
     return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
 }
-constexpr int kFrMaxWHost = 8;
-static size_t flowr_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t W)        // = flowr_lds() of mbb_flowr.hip.h
-{
-    return 2 * W * (sizeof(WalkerK) + 8 * npart + 8 * 8 + 8 * 2) + 8 * W * nb + 8 * 2 * W * 8 + 16 * nb +
-           (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
-}
+constexpr int kFrMaxWHost = 8;                  // walkers of each half a workgroup of the resident form may own (mbb_flowa.hip.h)
 constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)   // = flowm_lds() of mbb_flowm.hip.h
 {
@@ -242,7 +226,7 @@ struct mbb_ctx {
     unsigned long long buf_gen = 1;   // mbb_boundary_generation: bumped whenever the blocks below are freed and made anew
     double *call_in = nullptr;   // mbb_boundary_buffers: where the caller writes its rows (w_pars or h_pars)
     size_t call_cap = 0;         // ... and the capacity that answer was given for
-    hipFunction_t mod_fn[80] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 16 k_flowr / k_flowa)
+    hipFunction_t mod_fn[80] = {};   // launch_api 1: the kernels' module handles, by variant (32 k_lnlike, 8 k_flowm, 8 + 8 k_flowa (slots 40..55), 16 k_serve)
     hipEvent_t *launch_ev = nullptr; // != nullptr: two events to record right before and right behind the next launch
     long opt_launch_api = 1;     // 1 hipModuleLaunchKernel with a packed argument buffer (-0.2 us per call, profiles/r04/boundary_breakdown.txt); 0 hipLaunchKernel
     double *d_gather = nullptr, *h_gather = nullptr;   // sharded boundary: every rank's lnprob, device / pinned landing place
@@ -285,9 +269,8 @@ struct mbb_ctx {
     long opt_flow = 1;        // 1: ... as ONE launch per run, the half-steps handing over row by row (SMODE 5)
     long opt_flowm = 1;       // 1: ... with the quadrature of both candidates running ahead too (k_flowm, form 7)
     long opt_flowr = 1;       // 1: ensembles beyond one pair of walkers per CU run as ONE resident launch too, several walkers per
-                              // workgroup, nothing computed ahead (k_flowr, form 8); 0: off; 2: every eligible ensemble takes it
-    long opt_flowr_ahead = 1;     // that form with the SED constructor running a half-step ahead, for both outcomes of each
-                                  // partner's pending move (k_flowa, form 9); 0: nothing ahead (k_flowr, form 8)
+                              // workgroup, the SED constructor a half-step ahead for both outcomes of each partner's pending move
+                              // (k_flowa, form 9); 0: off; 2: every eligible ensemble takes it
     long opt_flowr_walkers = 0;   // walkers per workgroup and half of that form (0: the host's choice, ceil(half / CUs))
                               // (ensembles of 258-512 walkers on 256 CUs); 1, 2 force it (testing)
     long opt_la_waves = 0;
@@ -797,7 +780,7 @@ struct SamplerLaunch {
     double *spec;                 // != nullptr: the one-launch run's device state
     bool xflow = false;           // one-launch run of a sharded ensemble (SMODE 6): spec is the FlowX
     bool merged = false;          // k_flowm (form 7): one workgroup per (pair of walkers, candidate)
-    bool resident = false;        // k_flowr (form 8): the launch train made resident, several walkers per workgroup
+    bool resident = false;        // k_flowa (form 9): a workgroup owns several walkers of each half, every workgroup resident
     int res_w = 1;                // ... walkers per workgroup and half
     bool res_ahead = false;       // ... with the constructor a half-step ahead (k_flowa, form 9)
     unsigned long long serial = 0;   // ... the number of its launch (in its check words and decision words)
@@ -913,7 +896,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
     void (*kern)(const LikeArgs);
     int vi_of_kernel = 0;
     if (sl && sl->resident) {
-        // sampler form 8: ceil(n / W) workgroups of 16 waves, every one resident, W walkers of each half apiece
+        // sampler form 9: ceil(n / W) workgroups of 16 waves, every one resident, W walkers of each half apiece
         a.pos6 = sl->pos6; a.chain6 = sl->chain6; a.nacc = sl->nacc; a.errflag = sl->errflag;
         a.s_begin = sl->s_begin; a.c_begin = sl->c_begin; a.c_count = sl->c_count; a.nw = sl->nw;
         a.m_count = sl->m_count;
@@ -926,8 +909,7 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         a.n_ahead = 0;
         const int Wr = sl->res_w, wgs = (n + Wr - 1) / Wr, thr = 1024;
         a.wpb = Wr;
-        const bool ahead = sl->res_ahead;
-        auto lds_of = [&](bool cov) { return ahead ? flowa_lds_bytes(c->nb, c->npart, cov, Wr) : flowr_lds_bytes(c->nb, c->npart, cov, Wr); };
+        auto lds_of = [&](bool cov) { return flowa_lds_bytes(c->nb, c->npart, cov, Wr); };
         a.cov_in_lds = (c->has_cov && lds_of(true) <= std::min<size_t>(64 * 1024, dyn_limit)) ? 1 : 0;
         const size_t sm = lds_of(a.cov_in_lds != 0);
         const bool stg = c->opt_stage != 0 && sm + table_bytes + 16 <= dyn_limit;
@@ -935,15 +917,13 @@ static int launch_lnlike(mbb_ctx *c, const double *d_pars, int n, double *d_lnl,
         if (sm_total > dyn_limit) return fail(MBB_ERR_ARG, "band tables too large for the LDS plan");
         if (wgs > c->cu_count || Wr > kFrMaxWHost)
             return fail(MBB_ERR_ARG, "the one-launch sampler run needs every workgroup resident: too many for this GPU");
-        static void (*const rtable[16])(const LikeArgs) = {
-            k_flowr<false, false, false>, k_flowr<false, false, true>, k_flowr<false, true, false>, k_flowr<false, true, true>,
-            k_flowr<true, false, false>, k_flowr<true, false, true>, k_flowr<true, true, false>, k_flowr<true, true, true>,
+        static void (*const rtable[8])(const LikeArgs) = {
             k_flowa<false, false, false>, k_flowa<false, false, true>, k_flowa<false, true, false>, k_flowa<false, true, true>,
             k_flowa<true, false, false>, k_flowa<true, false, true>, k_flowa<true, true, false>, k_flowa<true, true, true>};
-        const int ri = (ahead ? 8 : 0) + ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
+        const int ri = ((c->opthin ? 2 : 0) | (c->noalpha ? 1 : 0)) * 2 + (stg ? 1 : 0);
         kern = rtable[ri];
         c->last_wpb = Wr; c->last_threads = thr; c->last_grid = wgs; c->last_smem = (long)sm_total;
-        c->last_stage = stg ? 1 : 0; c->last_smode = ahead ? 9 : 8; c->last_ahead = 0;
+        c->last_stage = stg ? 1 : 0; c->last_smode = 9; c->last_ahead = 0;
         if (static_lds(c) + sm_total > 60 * 1024) {
             size_t &g = c->lds_granted[72 + ri];
             if (sm_total > g) {
@@ -1692,8 +1672,8 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
     //           -- 8.4-8.9 from 258 to 512 walkers (round 3's forms there, removed this round: form 5 9.6-10.2 up to 340,
     //           form 7 with two pairs per workgroup 11.5 up to 512), 10.7-11.3 up to 1000, 15.6 at 1500, 18.6 at 2000
     //           (train: 18.9 / 19.1 / 22.4 / 26.0);
-    //   form 8 (k_flowr): the same ownership, nothing ahead -- from seven walkers per CU and half on, where the constructor
-    //           waves of form 9 cost the quadrature more than running ahead gains: 32.1 at 3584, 35.5 at 4096 (train 37.9).
+    //           (round 4's form 8, k_flowr -- the same ownership, nothing ahead -- existed for 3073-4096 walkers only and was
+    //           6 % ahead there, 35.5 against 37.6 us per step at 4096: removed in round 5, form 9 takes those too).
     bool one_launch = c->opt_lookahead && c->opt_flow && p.shards == 1 && !p.collective && s->nsrc == 1 &&
                       nsteps >= (int)std::max<long>(1, c->opt_flow_min_steps);
     const bool merged = one_launch && c->opt_flowm && c->opt_flowr != 2 && 2 * (int)nl <= c->cu_count && wpb_1 == 1;
@@ -1701,9 +1681,7 @@ static int sampler_enqueue(mbb_ctx *c, mbb_sampler_state *s, int nsteps, double 
                                          : ((int)nl + c->cu_count - 1) / c->cu_count;
     const bool res_fits = res_w >= 1 && res_w <= kFrMaxWHost && ((int)nl + res_w - 1) / res_w <= c->cu_count;
     const bool resident = one_launch && !merged && c->opt_flowr != 0 && res_fits;
-    // (the constructor ahead up to six walkers per CU and half -- 2560 / 3000 walkers: 23.8 / 26.8 us per step against form 8's
-    // 27.3 / 29.6; at seven 32.4 against 32.1 --; option "resident_ahead": 0 never, 2 always)
-    const bool res_ahead = c->opt_flowr_ahead == 2 || (c->opt_flowr_ahead == 1 && res_w <= 6);
+    const bool res_ahead = true;
     one_launch = merged || resident;
     if (one_launch && c->flow_rest > 0) { --c->flow_rest; one_launch = false; }   // resting after give-ups in a row
     if (one_launch) {
@@ -2294,7 +2272,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "merged_flow_sampler")) c->opt_flowm = value;
     else if (!strcmp(name, "resident_sampler")) c->opt_flowr = value;
     else if (!strcmp(name, "resident_walkers")) c->opt_flowr_walkers = value;
-    else if (!strcmp(name, "resident_ahead")) c->opt_flowr_ahead = value;
+    else if (!strcmp(name, "resident_ahead")) { /* (round 4's choice between forms 8 and 9: form 8 is gone, accepted and ignored) */ }
     else if (!strcmp(name, "flow_spin_log2")) c->opt_flow_spin_log2 = value;
     else if (!strcmp(name, "flow_min_steps")) c->opt_flow_min_steps = value;
     else if (!strcmp(name, "sharded_flow_sampler")) c->opt_xflow = value;

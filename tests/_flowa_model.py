@@ -1,5 +1,5 @@
-"""A host-side model of the hand-over protocol of the resident sampler forms (k_flowr, form 8, and k_flowa,
-form 9: mbb_flowr.hip.h, mbb_flowa.hip.h), used by tests/test_host_cpu.py.  Like _flowm_model.py for form 7 it
+"""A host-side model of the hand-over protocol of the resident sampler forms (k_flowa, form 9: mbb_flowa.hip.h;
+round 4's form 8 used the same protocol), used by tests/test_host_cpu.py.  Like _flowm_model.py for form 7 it
 restates WHO waits for WHAT and who reads and writes which slot, with the kernel's own index arithmetic
 (mbb_flow_index.h through the C hooks), and runs the actors in random or adversarial order with every store to
 memory landing at a random later time.  Every slot remembers the move whose data it holds -- what the check words

@@ -1809,23 +1809,18 @@ def _sampler_forms(ctx):
     return [("plain", {"lookahead_sampler": 0, "flow_sampler": 0}),
             ("one launch, quadrature ahead (form 7)", {"lookahead_sampler": 1, "flow_sampler": 1, "merged_flow_sampler": 1,
                                                        "resident_sampler": 1}),
-            ("one launch, the train made resident (form 8), one walker of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0}),
-            ("one launch, the train made resident (form 8), three walkers of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 0, "resident_walkers": 3}),
             ("one launch, resident, constructor a half-step ahead (form 9), one walker of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1}),
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2}),
             ("one launch, resident, constructor a half-step ahead (form 9), three walkers of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 1, "resident_walkers": 3}),
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_walkers": 3}),
             ("one launch, resident, constructor a half-step ahead (form 9), seven walkers of each half per workgroup",
-             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_ahead": 2, "resident_walkers": 7})]
+             {"lookahead_sampler": 1, "flow_sampler": 1, "resident_sampler": 2, "resident_walkers": 7})]
 
 
 def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
     """The one-launch forms of the device sampler -- form 7 (k_flowm: one workgroup per pair of walkers and candidate,
-    quadrature and constructor ahead of the decisions they depend on), form 8 (k_flowr: the launch train made resident,
-    several walkers of each half per workgroup) and form 9 (k_flowa: the same with the constructor a half-step ahead for
-    both outcomes of each partner's pending move) -- make the same draws and do the same arithmetic per proposal as the
+    quadrature and constructor ahead of the decisions they depend on) and form 9 (k_flowa: a workgroup owns several
+    walkers of each half, the constructor a half-step ahead for both outcomes of each partner's pending move) -- make the same draws and do the same arithmetic per proposal as the
     plain train of one launch per half-step, so chain, lnprob, final state and acceptance counts must be bitwise its:
     every model variant, stored and unstored runs in sequence."""
     bands = [str(b) for b in g_lnl["cfg2/bands"]]
@@ -1850,21 +1845,21 @@ def test_lookahead_sampler_forms_equal_the_plain_launch_train(mbb, g_lnl):
         assert res[0][6].shape == (250, 47, 5) and 0.1 < res[0][8].mean() / 102 < 0.9
 
 
-@pytest.mark.parametrize("ahead", [1, 0])
 @pytest.mark.parametrize("nw,W", [(514, 0), (1000, 0), (2000, 0), (2000, 8), (4096, 0), (300, 5), (36, 8), (26, 7), (300, 2)])
-def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, g_lnl, nw, W, ahead):
-    """Sampler form 8 (k_flowr): ensembles beyond one pair of walkers per CU -- cfg3's 2000 walkers on one GPU
+def test_resident_sampler_form_for_large_ensembles_equals_the_launch_train(mbb, g_lnl, nw, W):
+    """Sampler form 9 (k_flowa): ensembles beyond one pair of walkers per CU -- cfg3's 2000 walkers on one GPU
     among them -- run as ONE launch per run with several walkers of each half per workgroup, the rows handed over
-    through check words instead of a launch boundary.  Nothing is computed ahead or twice: the chain, the final
+    through check words instead of a launch boundary, the constructor a half-step ahead.  The chain, the final
     state and the counts are bitwise the launch train's, whatever the number of walkers per workgroup (the
-    host's choice, a forced one, a last workgroup that owns fewer)."""
+    host's choice, a forced one, a last workgroup that owns fewer; up to the eight of 4096 walkers: round 4's form 8,
+    which took 3073-4096, is gone)."""
+    ahead = 1
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
     out = []
     for resident in (0, 1):
         ctx.set_option("lookahead_sampler", resident); ctx.set_option("resident_sampler", 2 if W else 1); ctx.set_option("resident_walkers", W)
-        ctx.set_option("resident_ahead", 2 if ahead else 0)      # (2: ahead whatever the number of walkers per workgroup)
         s = mbb.DeviceEnsembleSampler(nw, 5, like, seed=nw + 1)
         a = s.run_mcmc(p0, 9)
         if resident:
@@ -2066,11 +2061,11 @@ def test_stored_chain_comes_back_in_emcees_layout_small_and_large(mbb, g_lnl):
 def test_advance_timed_is_advance_async_with_a_clock(mbb, g_lnl):
     """mbb_sampler_advance_timed (bench.py's timed region on one GPU) enqueues exactly what advance_async does --
     the same chain afterwards, whatever form the run takes (form 7; form 9 with one, two, four and six walkers of each half
-    per workgroup; form 8 beyond; the launch train for an ensemble too large for any) -- and returns a wall time that
+    per workgroup, and seven; the launch train for an ensemble too large for any) -- and returns a wall time that
     covers the stream time."""
     like = _cfg2_like(mbb, g_lnl)
     ctx = like.context
-    for nw, form in ((60, 7), (300, 9), (600, 9), (2000, 9), (2600, 9), (3600, 8), (4200, 1)):
+    for nw, form in ((60, 7), (300, 9), (600, 9), (2000, 9), (2600, 9), (3600, 9), (4200, 1)):
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(nw).normal(size=(nw, 5)))
         a = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
         b = mbb.DeviceEnsembleSampler(nw, 5, like, seed=8)
@@ -2092,8 +2087,8 @@ def test_one_launch_sampler_falls_back_when_it_cannot_be_resident(mbb, g_lnl):
     ctx = like.context
     cus = ctx.info("cu_count")
     for nw, opts, form in ((cus, {}, 7), (cus + 2, {}, 9), (cus + 2, {"resident_sampler": 0}, 1), (12 * cus, {}, 9),
-                           (12 * cus + 2, {}, 8), (16 * cus, {}, 8), (16 * cus + 2, {}, 1), (cus, {"merged_flow_sampler": 0}, 9),
-                           (60, {"resident_sampler": 2, "resident_walkers": 9}, 8)):
+                           (12 * cus + 2, {}, 9), (16 * cus, {}, 9), (16 * cus + 2, {}, 1), (cus, {"merged_flow_sampler": 0}, 9),
+                           (60, {"resident_sampler": 2, "resident_walkers": 9}, 9)):
         for o in ("merged_flow_sampler", "resident_sampler"):
             ctx.set_option(o, 1)
         ctx.set_option("resident_walkers", 0)
@@ -2119,10 +2114,9 @@ def test_one_launch_sampler_run_that_times_out_is_redone_as_a_launch_train(mbb, 
     of launches -- the caller gets the chain it would have got, with a warning.  A give-up is a
     property of the moment: the next run takes the one-launch form again; only three give-ups in a
     row rest it, for sixteen runs."""
-    for merged, ahead, form in ((1, 1, 7), (0, 1, 9), (0, 0, 8)):
+    for merged, form in ((1, 7), (0, 9)):
         like = _cfg2_like(mbb, g_lnl)
         ctx = like.context
-        ctx.set_option("resident_ahead", ahead)
         p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * np.random.RandomState(8).normal(size=(100, 5)))
         ctx.set_option("lookahead_sampler", 0)
         s0 = mbb.DeviceEnsembleSampler(100, 5, like, seed=4)

@@ -30,7 +30,7 @@ def main(fetch_dir, write_dir, out, half_steps="0"):
                                  "traffic_bytes_per_launch": 1024.0 * (f[k]["median_KB"] + (w[k]["median_KB"] if k in w else 0.0))}
             # half_steps: a number, or "<log of the FETCH pass>,<log of the WRITE pass>" (the passes are separate runs)
             hs = [_hs(x) for x in (str(half_steps).split(",") * 2)[:2]]
-            if any(n in k for n in ("k_flowm", "k_flowa", "k_flowr")) and min(hs) > 0:
+            if any(n in k for n in ("k_flowm", "k_flowa")) and min(hs) > 0:
                 # the one-launch sampler kernel: its launches cover different numbers of half-steps
                 res["kernels"][k]["half_steps_in_all_launches"] = {"fetch_pass": hs[0], "write_pass": hs[1]}
                 res["kernels"][k]["traffic_bytes_per_half_step"] = \

@@ -18,7 +18,7 @@ def main(run_dir, bench_json, out):
     line = json.load(open(bench_json))
     steps, warm = line["steps"], line["warmup"]
     trace = glob.glob(run_dir + "/*/*_kernel_trace.csv")[0]
-    rows = [r for r in csv.DictReader(open(trace)) if any(n in r["Kernel_Name"] for n in ("k_flowm<", "k_flowa<", "k_flowr<"))]
+    rows = [r for r in csv.DictReader(open(trace)) if any(n in r["Kernel_Name"] for n in ("k_flowm<", "k_flowa<"))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # bench.py says which sampler runs it made (rehearsal, the scratch ensemble that preconditions the GPU, warm-up, the
     # timed region, eight more of it); runs of fewer than two steps are launch trains, not launches of this kernel

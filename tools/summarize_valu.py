@@ -19,7 +19,7 @@ def main(run_dir, out, command="", note="", half_steps="0"):
     path = glob.glob(run_dir + "/*/*_counter_collection.csv")[0]
     per = {}
     for r in csv.DictReader(open(path)):
-        if not any(n in r["Kernel_Name"] for n in ("k_lnlike<", "k_flowm<", "k_flowa<", "k_flowr<")):
+        if not any(n in r["Kernel_Name"] for n in ("k_lnlike<", "k_flowm<", "k_flowa<")):
             continue
         grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
         per.setdefault(r["Kernel_Name"], {}).setdefault(grid, {}).setdefault(r["Counter_Name"], []).append(
@@ -32,7 +32,7 @@ def main(run_dir, out, command="", note="", half_steps="0"):
         fma, add, mul = (c.get("SQ_INSTS_VALU_" + x, 0.0) for x in ("FMA_F64", "ADD_F64", "MUL_F64"))
         f64 = fma + add + mul + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
         extra = {}
-        if any(n in k for n in ("k_flowm<", "k_flowa<", "k_flowr<")) and _hs(half_steps) > 0:
+        if any(n in k for n in ("k_flowm<", "k_flowa<")) and _hs(half_steps) > 0:
             tot = {cn: float(np.sum(v)) for cn, v in grids[g].items()}
             extra = {"half_steps_in_all_launches": _hs(half_steps), "counters_all_launches": tot,
                      "counters_per_half_step": {cn: v / _hs(half_steps) for cn, v in tot.items()}}
