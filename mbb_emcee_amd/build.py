@@ -27,6 +27,7 @@ DEPS = [SRC, SRC_HOST, SRC_FLOW, SRC_REG, os.path.join(HERE, "csrc", "mbb_host_t
         os.path.join(HERE, "csrc", "mbb_registry.h"),
         os.path.join(HERE, "csrc", "mbb_exp2_tab.inc"),
         os.path.join(HERE, "csrc", "mbb_walker_consts.inc"),
+        os.path.join(HERE, "csrc", "mbb_walker_penalties.inc"),
         os.path.join(HERE, "csrc", "mbb_flow_index.h"),
         os.path.join(HERE, "csrc", "mbb_device.hip.h"),
         os.path.join(HERE, "csrc", "mbb_math.hip.h"),

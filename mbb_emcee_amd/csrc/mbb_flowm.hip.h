@@ -66,6 +66,8 @@ __device__ __forceinline__ long long flow_spin_limit(int spec_cfg)
 constexpr int kFmReady = 0;    // [kFmNB] half-step + 1 of the record last handed to Q through buffer b
 constexpr int kFmQDone = 4;    // [kFmNB] Q waves that have finished a unit pass over buffer b, running total
 constexpr int kFmEDone = 8;    // [kFmNB] half-step + 1 of the last record of buffer b E is through with
+constexpr int kFmPen = 16;     // [kFmNB] half-step + 1 of the record of buffer b whose two penalties are there (they follow the
+                               // record: the quadrature does not wait for them, the accept test does)
 constexpr int kFmStaged = 12;  //        Q and E waves that have copied their share of the tables to LDS
 constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: proposal 0..4, (dim-1) ln z,
                                // ln u, the two penalties, the walker's row as it is (9..13)
@@ -74,7 +76,7 @@ constexpr int kFmProp = 16;    // doubles per hand-over record besides WalkerK: 
 __host__ __device__ constexpr size_t flowm_lds(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)
 {
     return np * kFmNB * sizeof(WalkerK) + 8 * (np * kFmNB * npart + 2 * nb + np * kFmNB * kFmProp + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (kFmNC * 64) + 64 * np + 32;
+           8 * (nb + 2) + 8 * (kFmNC * 64) + 128 * np + 32;
 }
 
 // The lane number as the compiler cannot see through it: what a C wave derives from it (which item a lane
@@ -117,7 +119,7 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     int2 *s_band = reinterpret_cast<int2 *>(s_invcov + (a.cov_in_lds ? (size_t)nb * nb : 0)); \
     double *cscr = reinterpret_cast<double *>(s_band + nb + 1); \
     int *ctl0 = reinterpret_cast<int *>(cscr + kFmNC * 64); \
-    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl0 + 16 * NP) - smem_raw) + 15) & ~(size_t)15; \
+    const size_t tab_off = ((size_t)(reinterpret_cast<unsigned char *>(ctl0 + 32 * NP) - smem_raw) + 15) & ~(size_t)15; \
     double *s_nu = reinterpret_cast<double *>(smem_raw + tab_off); \
     double *s_lnnu = s_nu + (STAGE ? a.nchunk * 64 : 0); \
     double *s_wt = s_lnnu + (STAGE ? a.nchunk * 64 : 0); \
@@ -137,7 +139,7 @@ __device__ __forceinline__ bool fm_get(const double *pair, unsigned long long ta
     WalkerK *const wk = wk0 + (vp) * kFmNB; \
     double *const partial = partial0 + (size_t)(vp) * kFmNB * npart; \
     double *const prop = prop0 + (vp) * kFmNB * kFmProp; \
-    int *const ctl = ctl0 + 16 * (vp); \
+    int *const ctl = ctl0 + 32 * (vp); \
     (void)wk; (void)partial; (void)prop; (void)ctl
 // ... and the waits.  Hand-over words in LDS: a wave's LDS operations execute in the order it issued
 // them, so data then word (writer) and word then data (reader) need no wait in between, only the
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     {
         MBB_ROLE_ARGS();
         MBB_FM_COMMON();
-        if (tid < 16 * NP) ctl0[tid] = 0;
+        if (tid < 32 * NP) ctl0[tid] = 0;
         if (cand == 0 && tid < 12 * NP && wbase + tid / 12 < a.n) {
             const int t12 = tid % 12;
             const int r = (t12 < 6 ? 0 : a.c_count) + wbase + tid / 12, e = t12 < 6 ? t12 : t12 - 6;
@@ -397,6 +399,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             double cbb = 0.0, pen_u = 0.0, pen_g = 0.0, lnz4 = 0.0, lnu = 0.0, acc = 0.0;
             double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
             auto sums = [&]() {
+                lds_wait(ctl + kFmPen + b, it + 1);                    // (C posts the penalties behind the record)
                 st = wkb->status;
                 cbb = wkb->cbb; pen_u = pr[7]; pen_g = pr[8];
 #pragma unroll
@@ -700,7 +703,9 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             const unsigned long long need2 = (unsigned long long)flow_seq(hj, m_s);
             unsigned long long v2 = 0;
 #define MBB_WC_AFTER_PROLOGUE if (watch2) v2 = __hip_atomic_load(w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define MBB_WC_PENALTIES_LATER
 #include "mbb_walker_consts.inc"
+#undef MBB_WC_PENALTIES_LATER
 #undef MBB_WC_AFTER_PROLOGUE
 #ifdef MBB_STAMPS
             {
@@ -728,9 +733,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 for (int i = 0; i < 5; ++i) { pr[i] = p[i]; pr[9 + i] = snv[i]; }
                 pr[5] = 4.0 * lo[2];                              // (dim - 1) ln z, dim = 5
                 pr[6] = lo[3];                                    // ln u
-                pr[7] = pen_u;
-                pr[8] = pen_g;
-                lds_post(ctl + kFmReady + bj, j + 1);
+                lds_post(ctl + kFmReady + bj, j + 1);             // (the quadrature may start; the penalties follow)
 #ifdef MBB_STAMPS
                 if (a.stamps && j >= niter - 64)
                     a.stamps[(1u << 20) + 8192 + (((size_t)blockIdx.x * 64 + (j & 63)) * 16 + 3)] = __builtin_amdgcn_s_memrealtime();
@@ -741,6 +744,14 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                 const unsigned long long tag = serial32 | (unsigned long long)(j + 1);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) fm_put(rec + 2 * i, p[i], tag);
+            }
+            // the five parameters' walls and priors, behind the hand-over: their first reader is the accept test
+#include "mbb_walker_penalties.inc"
+            if (vrow == vsel && l16 == 0) {
+                double *pr = prop + bj * kFmProp;
+                pr[7] = pen_u;
+                pr[8] = pen_g;
+                lds_post(ctl + kFmPen + bj, j + 1);
             }
             FM_T(5);
         }

@@ -89,7 +89,7 @@ constexpr int kFmPropHost = 16;
 static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t np = 1)   // = flowm_lds() of mbb_flowm.hip.h
 {
     return np * 4 * sizeof(WalkerK) + 8 * (np * 4 * npart + 2 * nb + np * 4 * kFmPropHost + 2 * nb + (cov_in_lds ? nb * nb : 0)) +
-           8 * (nb + 2) + 8 * (3 * 64) + 64 * np + 32;
+           8 * (nb + 2) + 8 * (3 * 64) + 128 * np + 32;
 }
 #include "mbb_host_tables.h"
 #include "mbb_registry.h"

@@ -2024,7 +2024,7 @@ def test_random_sampler_configurations_all_forms_equal(mbb, seed):
             assert np.array_equal(x, y, equal_nan=True), (seed, form[0], names, nw, opts)
     # (the forced forms ran as asked; the default one-launch entry: form 7 while every pair and candidate has a CU
     # of its own, the resident form with the constructor ahead beyond)
-    assert forms[0] == 1 and forms[2:] == [8, 8, 9, 9, 9], forms
+    assert forms[0] == 1 and forms[2:] == [9, 9, 9], forms
     assert forms[1] == (7 if nw <= 256 else 9), (nw, forms)
 
 

@@ -10,11 +10,16 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 export TMPDIR=/tmp
+export MBB_BENCH_FULL_LINE=1     # (the summarizers read legs that the driver's short line leaves to the side file)
 cd $R
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 SHORT="--steps 300 --warmup 50 --no-extras"
 # (how many half-steps the sampler kernel covers in such a run: bench.py says on its line, the summaries read the logs)
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
+cp $R/gpurun_out/bench_full.json $O/bench_full.json
+# the driver's own command, as the driver sees it: the short line on stdout, everything else in the side file
+( unset MBB_BENCH_FULL_LINE; timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_command.json 2> $O/bench_driver_command.err ) || exit 1
+cp $R/gpurun_out/bench_full.json $O/bench_driver_command_full.json
 echo "bench done"
 # kernel trace + stats of the timed region alone (default K and W): the dominant kernel's three launches
 # (rehearsal, warm-up, timed), tools/summarize_stats.py holds the timed one against the line's HIP events

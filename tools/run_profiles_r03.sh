@@ -10,6 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 export TMPDIR=/tmp
+export MBB_BENCH_FULL_LINE=1     # (the summarizers read legs that the driver's short line leaves to the side file)
 cd $R
 VALU="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"
 HS=$((2 * (50 + 300)))
