@@ -1417,6 +1417,55 @@ def test_served_boundary_with_several_likelihoods_alive(mbb, g_lnl):
     del s, a, b
 
 
+def test_two_threads_two_likelihoods_one_device(mbb, g_lnl):
+    """contexts of one process that share a device used from different THREADS at once -- ctypes
+    and the _mbbfast extension release the GIL around the native call.  A likelihood that comes to the device tells a
+    sibling's resident server to leave; that touches the sibling's serve state from the visitor's thread, which is guarded
+    by a per-context mutex since round 5.  Two threads, a likelihood each, a loop of boundary calls each, at the same time
+    (so that servers start, are sent away and start again all the time), plus a third thread that uses other entry
+    points of one of the contexts' SIBLING: every result right, no deadlock, the feature not struck out."""
+    import threading, time
+    a, b = _cfg2_like(mbb, g_lnl), _cfg2_like(mbb, g_lnl)
+    b.set_uplim("T", 12.0)
+    p = np.ascontiguousarray(np.tile(g_lnl["cfg2/thick_walpha/pars"], (2, 1))[:125])
+    for like in (a, b):
+        like._sync_device().set_option("serve", 0)
+    wa, wb = a(p).copy(), b(p).copy()
+    for like in (a, b):
+        like._sync_device().set_option("serve", 2)              # (2: this test session's other processes do not matter)
+    bad, done = [], []
+
+    def loop(like, want, ncalls, pause):
+        try:
+            for i in range(ncalls):
+                if not np.array_equal(like(p), want, equal_nan=True):
+                    bad.append(i)
+                if pause:
+                    time.sleep(pause)
+            done.append(ncalls)
+        except Exception as e:                                    # noqa
+            bad.append(repr(e))
+    # (the second thread pauses between its calls: the first gets runs of calls long enough to be served, and every call
+    # of the second finds a server of the first's to send away -- from its own thread, while the first is inside a call)
+    ths = [threading.Thread(target=loop, args=(a, wa, 6000, 0.0)), threading.Thread(target=loop, args=(b, wb, 150, 0.0004))]
+    t0 = time.time()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths), "a thread is stuck"
+    assert bad == [] and len(done) == 2, bad[:5]
+    assert time.time() - t0 < 60
+    ca, cb = a._sync_device(), b._sync_device()
+    assert ca.info("serve_enabled") == 2 and cb.info("serve_enabled") == 2
+    # (how often each was served says how the two got along; nothing is asserted about it)
+    print("served requests: %d / %d, fall-backs %d / %d" % (ca.info("serve_requests"), cb.info("serve_requests"),
+                                                             ca.info("serve_fallbacks"), cb.info("serve_fallbacks")))
+    assert ca.info("serve_requests") > 100                      # (the first thread WAS served in between: servers came and went)
+    for like in (a, b):
+        like._sync_device().set_option("serve", 1)
+
+
 def _run_pool_workers(mbb, g_lnl, world, ncalls, env_extra=None):
     """Start `world` processes that each unpickle the same likelihood and make `ncalls` boundary calls of 125 rows at
     the same time on this one GPU (tests/_pool_worker.py); returns their reports."""
