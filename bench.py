@@ -10,33 +10,35 @@ Workload (BASELINE.json configs[1] / configs[2], SURVEY.md 8d "cfg2/cfg3"):
 One *step* is one MCMC step of the whole ensemble (metric M2): the
 device-resident stretch-move sampler advances 250 N walkers, two DEPENDENT half-steps
 per step (emcee's, mbb_fit.py:80-81 / :533), each evaluating the fused likelihood of
-its half.  On one GPU a run is ONE launch per 4096 steps (k_lnlike SMODE 5): 125
-workgroups move the walkers, 125 more prepare the next half-step's proposals (draw, SED
-constructor, penalties) for both outcomes of each partner's pending move, and a row's
-half-step starts when the rows it depends on are done -- the same chain, bit for bit, as
-one launch per half-step (tests/test_gpu_parity.py).  With N > 1 ranks the ensemble is
-sharded (125 moving walkers per GPU per half-step); the same one-launch run goes across the
-ranks (SMODE 6: decisions, rows and progress words stored into every rank's copy as they are
-made) or, if that does not come up, one launch per half-step with the moved state rows
-exchanged after every launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane stores the row
-into every rank's copy through hipIpc mappings), or by an in-place ncclAllGather over
-RCCL (--exchange rccl; also the automatic fall-back).  Positions live in HBM for the whole run: there is no host round
-trip inside the timed region.  `value` = walker-likelihood evaluations per second of
-that real chain = 250 N K / t.
+its half.  On one GPU a run is ONE launch per 4096 steps (k_flowm, form 7): a workgroup
+per (pair of walkers, candidate), the quadrature of both proposals a walker can end up
+making and the SED constructor for every outcome still open running ahead of the
+decisions they depend on -- the same chain, bit for bit, as one launch per half-step
+(tests/test_gpu_parity.py).  With N > 1 ranks the ensemble is sharded (125 moving
+walkers per GPU per half-step); the one-launch run goes across the ranks (SMODE 6:
+decisions, rows and progress words stored into every rank's copy as they are made) or,
+if that does not come up, one launch per half-step with the moved state rows exchanged
+after every launch -- by the one-hop peer-write exchange (mbb_xchg_*: the accepting lane
+stores the row into every rank's copy through hipIpc mappings), or by an in-place
+ncclAllGather over RCCL (--exchange rccl; also the automatic fall-back).  Positions live
+in HBM for the whole run: there is no host round trip inside the timed region.  `value`
+= walker-likelihood evaluations per second of that real chain = 250 N K / t.
 
-Also on the line (rank 0, N = 1, outside the timed region):
-  boundary      SURVEY.md 8d metric M1: synchronous likelihood.__call__ on host arrays
+Also measured (rank 0, N = 1, outside the timed region; in the side file, the starred ones on the line too):
+  boundary *    SURVEY.md 8d metric M1: synchronous likelihood.__call__ on host arrays
                 (PCIe inclusive), median of >= 200 calls, for 125 and 250 rows
   pipelined     independent launches on pre-computed proposals enqueued back to back
                 (an upper bound: no dependence between launches)
-  roofline      the binding roof of the dominant kernel: fp64 vector arithmetic
+  roofline *    the binding roof of the dominant kernel: fp64 vector arithmetic
                 (flop and VALU counts from the committed rocprofv3 PMC pass of this very
                 launch), the empirical sample-arithmetic roof measured in this run, and
                 the HBM figures north_star asks for
   cfg5          1000 sources x 250 walkers in one launch (BASELINE.json configs[4])
-  cpu_baseline  the CPU oracle timed on this box's cores
+  cpu_baseline * the CPU oracle timed on this box's cores
 
-Prints ONE JSON line on rank 0.  torch is used only as launcher plumbing
+Prints ONE short JSON line on rank 0 (< 4 KB: the contract's keys, roofline, roofline_hbm,
+boundary_M1, cpu_baseline, cfg5's three numbers) and writes everything measured -- the
+legs listed here in full -- to gpurun_out/bench_full.json.  torch is used only as launcher plumbing
 (torch.distributed gloo rendezvous + barrier); all device work goes through the C-ABI
 of libmbb_hip.so.  A collective that cannot be set up or does not return is a failure:
 the line says so and the exit status is non-zero.
