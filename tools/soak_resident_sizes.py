@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The resident sampler forms (9: k_flowa, 8: k_flowr) at many ensemble sizes against the plain launch train, long runs:
+"""The resident sampler form (9: k_flowa) at many ensemble sizes against the plain launch train, long runs:
 final state, acceptance counts and the run's error flag, bit for bit; whether any run had to fall back.
     python tools/soak_resident_sizes.py [steps] [sizes ...]"""
 import os, sys, time
