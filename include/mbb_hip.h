@@ -226,7 +226,8 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * table in POSIX shared memory keyed by the device's PCI address: csrc/mbb_registry.h; mbb_get_info "device_peers",
  * "serve_peer_yields", "serve_lease_yields"); and for processes that table cannot show, a server is sent away after "serve_lease_us" (50000;
  * 0: never) in one go -- the rows of that call go by a launch, the next server starts after the next few calls in a row.
- * 0: a launch per call; 2: a server even while other processes are registered on the device (tests).  "prepass" (-1 auto: from
+ * 0: a launch per call; 2: a server even while other processes are registered on the device (tests).  "serve_prefetch" (32; 0 to
+ * 256): once a request's first record has turned the host asks for that many record lines ahead of its scan.  "prepass" (-1 auto: from
  * 64 rows per CU; 0 never; 1 always): a likelihood launch of given rows is preceded by k_walker_pre, which works out gate, SED
  * constructor and penalties with a LANE per row (k_lnlike: a row of 16 lanes per walker -- right where a constructor is
  * latency, a quarter of all instructions where a launch is bound by their number); same values bit for bit

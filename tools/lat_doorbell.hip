@@ -47,6 +47,34 @@ __global__ void k_echo_s(const volatile uint64_t *door, uint64_t *rec, long limi
     }
 }
 
+// thread 0 keeps FOUR polls of the doorbell in flight (a poll of fine-grained device memory takes ~1 us to come back: with one in
+// flight a new request number is seen a whole latency and half a period after it lands, with four a latency and an eighth)
+__global__ void k_echo_k4(const uint64_t *door, uint64_t *rec, long limit, int answering, int sleepy) {
+    if (threadIdx.x != 0) return;
+    uint64_t seen = 0, r0, r1, r2, r3;
+    long idle = 0;
+#define LD(r) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(r) : "v"(door) : "memory"); if (sleepy) __builtin_amdgcn_s_sleep(4);
+#define WT(r) asm volatile("s_waitcnt vmcnt(3)" : "+v"(r) : : "memory");
+    LD(r0) LD(r1) LD(r2) LD(r3)
+    bool go = true;
+    while (go) {
+        uint64_t d;
+#define STEP(r)                                                                                                              \
+        WT(r) d = r;                                                                                                        \
+        if (go && d == ~0ull) go = false;                                                                                   \
+        if (go && d != seen) {                                                                                              \
+            seen = d; idle = 0;                                                                                             \
+            if ((int)blockIdx.x < answering) __hip_atomic_store(rec + blockIdx.x * 8, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+        } else if (++idle > limit) go = false;                                                                              \
+        LD(r)
+        STEP(r0) STEP(r1) STEP(r2) STEP(r3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+#undef LD
+#undef WT
+#undef STEP
+}
+
 // every workgroup polls ITS OWN 64-byte request line (lanes 0..3, 16 bytes each: one read of the line; the request number is the
 // line's last word, the row would be the words before it) and answers with one 16-byte record in its own line
 template <int SLEEP>
@@ -194,6 +222,11 @@ int main() {
                     {"125 answer; scan 8 us late, prefetch 32 ahead", 125, 8, 125, 8},
                     {"125 answer, a line each, prefetch 16 ahead", 125, 8, 125, 8},
                     {"125 answer, a line each, prefetch 32 ahead", 125, 8, 125, 8},
+                    {"1 workgroup, four polls in flight", 1, 8, 1, 204},
+                    {"1 workgroup, four polls in flight, s_sleep 4", 1, 8, 1, 205},
+                    {"125 answer, four polls in flight", 125, 8, 125, 204},
+                    {"125 answer, four polls in flight, s_sleep 4", 125, 8, 125, 205},
+                    {"256 poll, 125 answer, four in flight, sl 4", 256, 8, 125, 205},
                     {"256 poll, 125 answer, a line each", 256, 8, 125, 8},
                     {"256 answer, a line each", 256, 8, 256, 8}};
     for (const V &v : vs) {
@@ -207,7 +240,8 @@ int main() {
         //  host looks at the last record alone)
         const bool late = std::string(v.what).find("late") != std::string::npos;
         const int ahead = std::string(v.what).find("prefetch 16") != std::string::npos ? 16 : std::string(v.what).find("prefetch 32") != std::string::npos ? 32 : 0;
-        if (v.sleep == 101) hipLaunchKernelGGL(k_echo_s<1>, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, answering);
+        if (v.sleep == 204 || v.sleep == 205) hipLaunchKernelGGL(k_echo_k4, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, answering, v.sleep - 204);
+        else if (v.sleep == 101) hipLaunchKernelGGL(k_echo_s<1>, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, answering);
         else if (v.sleep == 102) hipLaunchKernelGGL(k_echo_s<2>, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, answering);
         else if (v.sleep == 103) hipLaunchKernelGGL(k_echo_s<3>, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, answering);
         else if (v.sleep == 0) hipLaunchKernelGGL(k_echo_v<0>, dim3(v.wgs), dim3(64), 0, st, d_door, hd_rec, 4000000L, v.stride, answering);
