@@ -8,7 +8,8 @@ from bench import make_likelihood, walkers
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
+    args = [a for i, a in enumerate(argv) if not a.startswith("--") and not (i and argv[i - 1] in ("--rows", "--rounds"))]
     opt, vals = args[0], [int(v) for v in args[1:]]
     rows = [125, 250, 1]
     rounds = 6

@@ -109,6 +109,39 @@ __global__ void k_echo_own(const uint64_t *req, uint64_t *rec, long limit, int a
     }
 }
 
+// ONE workgroup polls its request line in pinned host memory with FOUR reads in flight (lanes 0..7, 8 bytes each: one read of the
+// line; the request number is the line's last word)
+__global__ void k_echo_own4(const uint64_t *req, uint64_t *rec, long limit, int gap) {
+    if (threadIdx.x >= 8) return;
+    const uint64_t *mine = req + blockIdx.x * 8 + threadIdx.x;
+    uint64_t seen = 0, r0, r1, r2, r3;
+    long idle = 0;
+#define LD(r) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(r) : "v"(mine) : "memory"); if (gap) __builtin_amdgcn_s_sleep(1);
+#define WT(r) asm volatile("s_waitcnt vmcnt(3)" : "+v"(r) : : "memory");
+    LD(r0) LD(r1) LD(r2) LD(r3)
+    bool go = true;
+    while (go) {
+        uint64_t d;
+#define STEP(r)                                                                                                              \
+        WT(r)                                                                                                               \
+        d = ((uint64_t)(unsigned)__builtin_amdgcn_readlane((int)(r >> 32), 7) << 32) | (unsigned)__builtin_amdgcn_readlane((int)r, 7); \
+        if (go && d == ~0ull) go = false;                                                                                   \
+        if (go && d != seen) {                                                                                              \
+            seen = d; idle = 0;                                                                                             \
+            const bool bad = threadIdx.x < 5 && r != d + threadIdx.x;                                                       \
+            const bool torn = __builtin_amdgcn_ballot_w64(bad) != 0;                                                        \
+            if (threadIdx.x == 0) { __hip_atomic_store(rec + blockIdx.x * 8 + 1, torn ? 0 : d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  \
+                                    __hip_atomic_store(rec + blockIdx.x * 8, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } \
+        } else if (++idle > limit) go = false;                                                                              \
+        LD(r)
+        STEP(r0) STEP(r1) STEP(r2) STEP(r3)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : : "memory");
+#undef LD
+#undef WT
+#undef STEP
+}
+
 template <int SLEEP>
 __global__ void k_echo_v(const volatile uint64_t *door, volatile uint64_t *rec, long limit, int stride, int answering) {
     if (threadIdx.x != 0) return;
@@ -285,12 +318,14 @@ int main() {
     uint64_t *h_req = nullptr, *hd_req = nullptr;
     CHK(hipHostMalloc((void **)&h_req, maxwg * 64, hipHostMallocMapped | hipHostMallocCoherent));
     CHK(hipHostGetDevicePointer((void **)&hd_req, h_req, 0));
-    for (int sleep : {0, 8}) for (int wgs : {1, 16, 125, 256}) {
+    for (int sleep : {0, 8, 100, 101}) for (int wgs : {1, 16, 125, 256}) {
+        if (sleep >= 100 && wgs != 1) continue;
         for (int i = 0; i < maxwg * 8; ++i) { h_rec[i] = 0; h_req[i] = 0; }
         _mm_sfence();
         CHK(hipStreamSynchronize(st));
         const int answering = wgs > 125 ? 125 : wgs;
-        if (sleep) hipLaunchKernelGGL(k_echo_own<8>, dim3(wgs), dim3(64), 0, st, hd_req, hd_rec, 2000000L, answering);
+        if (sleep >= 100) hipLaunchKernelGGL(k_echo_own4, dim3(wgs), dim3(64), 0, st, hd_req, hd_rec, 8000000L, sleep - 100);
+        else if (sleep) hipLaunchKernelGGL(k_echo_own<8>, dim3(wgs), dim3(64), 0, st, hd_req, hd_rec, 2000000L, answering);
         else hipLaunchKernelGGL(k_echo_own<0>, dim3(wgs), dim3(64), 0, st, hd_req, hd_rec, 2000000L, answering);
         std::vector<double> t;
         bool lost = false;
