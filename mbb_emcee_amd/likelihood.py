@@ -100,43 +100,45 @@ class likelihood(object):
         self._response_integrate = True
         self._dirty = True
 
+    def _passbands_for(self, names):
+        """The wheel's responses in the order of the photometry; a name the wheel does not hold is made on the spot when
+        its second field spells one of the special passbands (box, gauss, dsb, alma, delta: likelihood.py:182-203)."""
+        if not isinstance(names[0], str):
+            raise ValueError("Expecting response string name")
+        wheel, found = self._responsewheel, []
+        for name in map(str, names):
+            if name not in wheel:
+                kind = name.split('_')[1].lower() if '_' in name else None
+                if kind not in special_types:
+                    raise ValueError("Unknown filter response {:s}".format(name))
+                wheel.add_special(name)
+            found.append(wheel[name])
+        return found
+
     def set_phot(self, firstarg, flux, flux_unc):
         """Set photometry: passband names (response mode) or wavelengths [um],
-        flux densities and uncertainties [mJy] (likelihood.py:158-232)."""
-        if self._response_integrate:
-            if not isinstance(firstarg[0], str):
-                raise ValueError("Expecting response string name")
-            self._responses = []
-            for name in firstarg:
-                name = str(name)
-                if name not in self._responsewheel:
-                    spl = name.split('_')
-                    if len(spl) > 1 and spl[1].lower() in special_types:
-                        self._responsewheel.add_special(name)          # :187-193
-                    else:
-                        raise ValueError("Unknown filter response {:s}".format(name))
-                self._responses.append(self._responsewheel[name])
-            self._response_names = [r.name for r in self._responses]
-            self._wave = np.array([r.effective_wavelength for r in self._responses])
-        else:
-            self._wave = np.asarray(firstarg, dtype=np.float64)
-
-        self._ndata = len(self._wave)
-        if self._ndata == 0:
+        flux densities and uncertainties [mJy] (likelihood.py:158-232).  A covariance matrix set before is dropped
+        (:231); nothing of the object changes when an argument is refused."""
+        bands = self._passbands_for(firstarg) if self._response_integrate else None
+        wave = (np.array([r.effective_wavelength for r in bands]) if bands is not None
+                else np.asarray(firstarg, dtype=np.float64))
+        npts = len(wave)
+        if npts == 0:
             raise ValueError("No elements in wavelength vector")
-        self._flux = np.asarray(flux, dtype=np.float64)
-        self._flux_unc = np.asarray(flux_unc, dtype=np.float64)
-        if self._ndata != len(self._flux):
-            raise ValueError("wave not same length as flux")
-        if self._ndata != len(self._flux_unc):
-            raise ValueError("wave not same length as flux_unc")
+        values = {}
+        for what, given in (("flux", flux), ("flux_unc", flux_unc)):
+            values[what] = np.asarray(given, dtype=np.float64)
+            if len(values[what]) != npts:
+                raise ValueError("wave not same length as " + what)
+        if bands is not None:
+            self._responses, self._response_names = bands, [r.name for r in bands]
+        self._wave, self._ndata = wave, npts
+        self._flux, self._flux_unc = values["flux"], values["flux_unc"]
         self._ivar = 1.0 / self._flux_unc ** 2
-        if not self._has_uplim[2]:                                     # :227-229
-            self._has_uplim[2] = True
-            self._uplim[2] = 3.0 * self._wave.max()
-        self._data_read = True
-        self._has_covmatrix = False
-        self._nsources = 1
+        # lambda0 three times beyond the longest wavelength says nothing the data can test (:224-229)
+        if not self._has_uplim[2]:
+            self._has_uplim[2], self._uplim[2] = True, 3.0 * wave.max()
+        self._data_read, self._has_covmatrix, self._nsources = True, False, 1
         self._dirty = True
 
     def set_phot_multi(self, firstarg, flux, flux_unc):
@@ -182,21 +184,20 @@ class likelihood(object):
         return self._flux_unc
 
     def set_cov(self, covmatrix):
-        """Set the flux covariance matrix [mJy^2] (likelihood.py:330-357)."""
+        """Set the flux covariance matrix [mJy^2] (likelihood.py:330-357): square, one row per photometry point."""
         if not self._data_read:
             raise Exception("Can't set covariance matrix without photometry")
-        covmatrix = np.asarray(covmatrix, dtype=np.float64)
-        if covmatrix.ndim != 2:
+        cov = np.asarray(covmatrix, dtype=np.float64)
+        if cov.ndim != 2:
             raise ValueError("Covariance matrix is not 2 dimensional")
-        if covmatrix.shape[0] != covmatrix.shape[1]:
-            raise ValueError("Covariance matrix from is not square: %d by %d" % covmatrix.shape)
-        if covmatrix.shape[0] != self._ndata:
+        nrow, ncol = cov.shape
+        if nrow != ncol:
+            raise ValueError("Covariance matrix from is not square: %d by %d" % (nrow, ncol))
+        if nrow != self._ndata:
             raise ValueError("Covariance matrix doesn't have same number of datapoints as "
-                             "photometry; {0:d} vs. {1:d}".format(covmatrix.shape[0], self._ndata))
-        self._covmatrix = covmatrix
-        self._invcovmatrix = np.linalg.inv(self._covmatrix)
-        self._has_covmatrix = True
-        self._dirty = True
+                             "photometry; {0:d} vs. {1:d}".format(nrow, self._ndata))
+        self._covmatrix, self._invcovmatrix = cov, np.linalg.inv(cov)
+        self._has_covmatrix = self._dirty = True
 
     def read_cov(self, filename, extn=0):
         """Covariance matrix from a FITS file (likelihood.py:359-376); needs astropy."""
