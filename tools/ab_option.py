@@ -22,6 +22,9 @@ def main():
     for rnd in range(rounds):
         for v in vals:
             ctx.set_option(opt, v)
+            if opt in ("seg_chunks", "pack_tails"):       # (options of the band layout: the tables are made anew)
+                like._dirty = True
+                like._sync_device()
             for n in rows:
                 p = np.ascontiguousarray(walkers(1)[:n])
                 arg = p if n > 1 else p[0].copy()
