@@ -17,12 +17,14 @@
 namespace mbbh {
 namespace {
 
-constexpr uint32_t kMagic = 0x4d424231u;      // "MBB1"
+constexpr uint32_t kMagic = 0x4d424232u;      // "MBB2"
 constexpr int kSlots = 256, kKeys = 16;
 
 struct Slot {
     std::atomic<int32_t> pid;                 // 0: free
     std::atomic<uint32_t> key[kKeys];         // 0: none
+    std::atomic<uint64_t> born;               // the process's start time (clock ticks since boot, /proc/<pid>/stat field 22;
+                                              // 0: unknown): a pid handed out again to somebody else is not mistaken for the owner
 };
 struct Table {
     std::atomic<uint32_t> magic;
@@ -44,18 +46,45 @@ struct Local {
     char name[64] = {};
 } g;
 
-bool alive(int32_t pid)
+// /proc/<pid>/stat field 22 (0: not to be had -- no /proc, another pid namespace)
+uint64_t born_of(int32_t pid)
 {
-    return pid > 0 && (kill(pid, 0) == 0 || errno != ESRCH);
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%d/stat", (int)pid);
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return 0;
+    const ssize_t n = read(fd, buf, sizeof buf - 1);
+    close(fd);
+    if (n <= 0) return 0;
+    buf[n] = 0;
+    const char *q = strrchr(buf, ')');          // (the command may hold spaces and brackets: fields are counted behind it)
+    if (!q) return 0;
+    int field = 2;
+    for (++q; *q; ++q)
+        if (*q == ' ' && ++field == 22) return strtoull(q + 1, nullptr, 10);
+    return 0;
 }
 
-void at_exit()
+// Is the process that wrote the slot still there?  (Its pid answers, and -- where both are known -- was born when it said.)
+bool alive(int32_t pid, uint64_t born)
 {
-    // (no lock: the process is going; a slot left behind would be reclaimed by its dead pid anyway)
+    if (pid <= 0 || (kill(pid, 0) != 0 && errno == ESRCH)) return false;
+    if (born == 0) return true;
+    const uint64_t now = born_of(pid);
+    return now == 0 || now == born;
+}
+
+// When the library goes (the process ends, or dlclose): the slot is given back.  A destructor of the library's own, not
+// atexit(): a handler registered there would outlive an unloaded library.  (No lock: whoever still calls in is gone too; a
+// slot left behind by a process that was killed is reclaimed by whoever counts next.)
+__attribute__((destructor)) void registry_unload()
+{
     if (g.tab && g.my >= 0 && g.pid == (int32_t)getpid()) {
         for (int i = 0; i < kKeys; ++i) g.tab->slot[g.my].key[i].store(0, std::memory_order_relaxed);
+        g.tab->slot[g.my].born.store(0, std::memory_order_relaxed);
         g.tab->slot[g.my].pid.store(0, std::memory_order_release);
         g.tab->gen.fetch_add(1, std::memory_order_release);
+        g.my = -1;
     }
 }
 
@@ -72,7 +101,7 @@ bool attach()
         g.tried = true;
         const char *forced = getenv("MBB_REGISTRY_NAME");       // (tests: a table of their own)
         if (forced && forced[0] == '/') snprintf(g.name, sizeof g.name, "%s", forced);
-        else snprintf(g.name, sizeof g.name, "/mbb_hip_registry_%u", (unsigned)getuid());
+        else snprintf(g.name, sizeof g.name, "/mbb_hip_registry2_%u", (unsigned)getuid());
         int fd = shm_open(g.name, O_RDWR | O_CREAT, 0600);
         if (fd < 0) return false;
         if (ftruncate(fd, (off_t)sizeof(Table)) != 0) { close(fd); return false; }
@@ -83,17 +112,24 @@ bool attach()
         uint32_t none = 0;
         g.tab->magic.compare_exchange_strong(none, kMagic);
         if (g.tab->magic.load() != kMagic) { munmap(p, sizeof(Table)); g.tab = nullptr; return false; }
-        atexit(at_exit);
     }
     if (g.my >= 0 && g.tab->slot[g.my].pid.load(std::memory_order_acquire) == me) return true;
     g.my = -1;
     for (int pass = 0; pass < 2 && g.my < 0; ++pass)
         for (int i = 0; i < kSlots && g.my < 0; ++i) {
-            int32_t cur = g.tab->slot[i].pid.load(std::memory_order_acquire);
-            // first pass: free slots; second: slots of processes that are gone
-            if (pass == 0 ? cur != 0 : alive(cur)) continue;
-            if (g.tab->slot[i].pid.compare_exchange_strong(cur, me, std::memory_order_acq_rel)) {
-                for (int k = 0; k < kKeys; ++k) g.tab->slot[i].key[k].store(0, std::memory_order_relaxed);
+            Slot &sl = g.tab->slot[i];
+            int32_t cur = sl.pid.load(std::memory_order_acquire);
+            // first pass: free slots; second: also slots of processes that are gone -- freed first (the birth time with
+            // them), so that a slot never shows a live pid beside somebody else's birth time
+            if (cur != 0) {
+                if (pass == 0 || alive(cur, sl.born.load(std::memory_order_acquire))) continue;
+                if (!sl.pid.compare_exchange_strong(cur, 0, std::memory_order_acq_rel)) continue;
+                sl.born.store(0, std::memory_order_release);
+            }
+            int32_t none = 0;
+            if (sl.pid.compare_exchange_strong(none, me, std::memory_order_acq_rel)) {
+                for (int k = 0; k < kKeys; ++k) sl.key[k].store(0, std::memory_order_relaxed);
+                sl.born.store(born_of(me), std::memory_order_release);
                 g.my = i;
             }
         }
@@ -164,9 +200,12 @@ int registry_peers(uint32_t key, bool recount)
     for (int s = 0; s < kSlots; ++s) {
         int32_t pid = g.tab->slot[s].pid.load(std::memory_order_acquire);
         if (pid == 0 || pid == me) continue;
-        if (!alive(pid)) {
+        if (!alive(pid, g.tab->slot[s].born.load(std::memory_order_acquire))) {
             // gone without a word: its slot is free again
-            if (g.tab->slot[s].pid.compare_exchange_strong(pid, 0, std::memory_order_acq_rel)) reclaimed = true;
+            if (g.tab->slot[s].pid.compare_exchange_strong(pid, 0, std::memory_order_acq_rel)) {
+                g.tab->slot[s].born.store(0, std::memory_order_release);     // (at worst a new owner's: then it counts by its pid alone)
+                reclaimed = true;
+            }
             continue;
         }
         for (int k = 0; k < kKeys; ++k) {

@@ -8,10 +8,11 @@
 // (profiles/r05/pool_two_processes_before.txt).  So a process starts a server only while it is the ONLY user of this
 // library on the device, and a server that finds a second one registered leaves at its next request.
 //
-// How: a small table in POSIX shared memory (/dev/shm/mbb_hip_registry_<uid>), one slot per process: its pid and
+// How: a small table in POSIX shared memory (/dev/shm/mbb_hip_registry2_<uid>), one slot per process: its pid and
 // the keys (PCI domain:bus:device -- not the HIP ordinal, which HIP_VISIBLE_DEVICES renumbers) of the devices it
 // holds contexts on; a generation word, bumped at every change, makes the per-call check one load of shared memory.
-// A slot whose process is gone (kill(pid, 0) == ESRCH) is reclaimed by whoever counts next; a count that says
+// A slot whose process is gone (kill(pid, 0) == ESRCH, or the pid belongs to a process born at another time than the slot
+// says: /proc/<pid>/stat) is reclaimed by whoever counts next; a count that says
 // "somebody else" is made again every so often, so a peer that died without a word is not believed for long.
 // Processes that do not share /dev/shm (other containers) or do not use this library are not seen: for those the
 // server's lease (option "serve_lease_us") bounds how long it holds the GPU in one go.

@@ -984,6 +984,31 @@ def test_device_registry_sees_other_processes_and_forgets_dead_ones(tmp_path):
             for pr, ask in kids:
                 pr.kill(); pr.wait()
             assert lib.mbbh_registry_peers(K, 1) == 0 and lib.mbbh_registry_leave(K) == 0
+        # a pid handed out again: a slot written by a process that is gone, whose pid now belongs to somebody else (here:
+        # to a live child of this test, with a birth time that is not the one the slot holds) is not a peer and is free again
+        import mmap, struct
+        d, ask_d = child()
+        assert ask_d("join %d" % K2) == 1 and lib.mbbh_registry_join(K) == 1
+        with open("/dev/shm" + name, "r+b") as f:
+            mm = mmap.mmap(f.fileno(), 0)
+            slot_bytes, header = 80, 16                     # {pid i32, key u32[16], pad, born u64}; {magic u32, pad, gen u64}
+            assert (len(mm) - header) // slot_bytes == 256
+            free = next(i for i in range(256) if struct.unpack_from("<i", mm, header + i * slot_bytes)[0] == 0)
+            off = header + free * slot_bytes
+            struct.pack_into("<i", mm, off, d.pid)
+            struct.pack_into("<I", mm, off + 4, K)
+            struct.pack_into("<Q", mm, off + 72, 12345)     # (nobody alive was born then)
+            assert lib.mbbh_registry_peers(K, 1) == 0
+            assert struct.unpack_from("<i", mm, off)[0] == 0
+            # ... the same slot with the birth time unknown: the pid alone answers
+            struct.pack_into("<Q", mm, off + 72, 0)
+            struct.pack_into("<I", mm, off + 4, K)
+            struct.pack_into("<i", mm, off, d.pid)
+            assert lib.mbbh_registry_peers(K, 1) == 1
+            struct.pack_into("<i", mm, off, 0); struct.pack_into("<I", mm, off + 4, 0)
+            mm.close()
+        d.kill(); d.wait()
+        assert lib.mbbh_registry_leave(K) == 0
     finally:
         del os.environ["MBB_REGISTRY_NAME"]
         try:
