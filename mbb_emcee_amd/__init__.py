@@ -6,12 +6,13 @@ Same API surface as the reference for this path: ``modified_blackbody``,
 kernels behind a C-ABI (include/mbb_hip.h); there is no CPU fallback.
 """
 from .response import response, response_set, special_types
-from .modified_blackbody import modified_blackbody
+from .modified_blackbody import modified_blackbody, alpha_merge_eqn
+from .utility import isiterable
 from .likelihood import likelihood
 from .ensemble import EnsembleSampler
 from .device_sampler import DeviceEnsembleSampler
 from .mbb_fit import mbb_fitter
 
 __version__ = "0.1.0"
-__all__ = ["response", "response_set", "modified_blackbody", "likelihood",
+__all__ = ["response", "response_set", "modified_blackbody", "alpha_merge_eqn", "isiterable", "likelihood",
            "EnsembleSampler", "DeviceEnsembleSampler", "mbb_fitter"]

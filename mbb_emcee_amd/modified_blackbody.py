@@ -6,11 +6,14 @@ properties, same call conventions.  All arithmetic (the constructor's
 normalisation / merge-point solve, f_nu on a grid, the SED peak) runs in HIP
 kernels through the C-ABI; there is no CPU implementation here.
 """
+import math
+
 import numpy as np
 
 from . import _native
+from .utility import isiterable as _is_iterable
 
-__all__ = ["modified_blackbody"]
+__all__ = ["modified_blackbody", "alpha_merge_eqn"]
 
 # modified_blackbody.py:15-18
 c = 299792458e6  # um / s
@@ -19,14 +22,21 @@ k = 1.3806505e-23  # J / K
 um_to_GHz = 299792458e-3
 
 
-def _is_iterable(obj):
-    if isinstance(obj, np.ndarray):
-        return obj.ndim > 0
+def alpha_merge_eqn(x, alpha, beta, x0, opthin=False):
+    """The function whose root x = h nu / k T is where the blue-side power law nu^-alpha takes over from the modified
+    blackbody (reference modified_blackbody.py:122-151):
+
+        x - (1 - e^-x) (3 + alpha + beta b),   b = y / (e^y - 1),   y = (x / x0)^beta   (b = 0 where y overflows).
+
+    `opthin` is accepted and, as in the reference, plays no part here (the optically thin merge point has its own
+    fixed-point form, :262).  The constructor on the device finds the root itself (csrc/mbb_device.hip.h
+    `thick_merge_root`, parity: tests/golden/sed.npz xmerge to 1e-10); this host form is for callers that import the name."""
     try:
-        iter(obj)
-        return True
-    except TypeError:
-        return False
+        y = math.pow(x / x0, beta)
+        b = y / math.expm1(y) if y > 0.0 else 1.0
+    except OverflowError:
+        b = 0.0
+    return x - (3.0 + alpha + beta * b) * -math.expm1(-x)
 
 
 class modified_blackbody(object):

@@ -1015,3 +1015,32 @@ def test_device_registry_sees_other_processes_and_forgets_dead_ones(tmp_path):
             os.unlink("/dev/shm" + name)
         except OSError:
             pass
+
+
+def test_package_level_helpers_of_the_reference():
+    """The reference exports `alpha_merge_eqn` (modified_blackbody.py:122-151) and `isiterable` (utility.py) beside its
+    classes; a caller that imports the names finds them here.  The merge equation on the host is zero at the merge
+    points the reference itself found (tests/golden/sed.npz, made by the imported reference), follows the reference's
+    formula term by term elsewhere, and takes the overflow of (x / x0)^beta as the reference does (b -> 0)."""
+    import math
+    import mbb_emcee_amd as mbb
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sed.npz"))
+    pars, scal = g["pars"], g["thick_walpha/scalars"]
+    for p, s in zip(pars, scal):
+        xmerge, x0 = s[1], s[3]
+        assert abs(mbb.alpha_merge_eqn(xmerge, p[3], p[1], x0)) < 1e-9 * max(1.0, xmerge)
+        assert mbb.alpha_merge_eqn(0.5 * xmerge, p[3], p[1], x0) < 0 < mbb.alpha_merge_eqn(2.0 * xmerge, p[3], p[1], x0)
+    rng = np.random.RandomState(4)
+    for _ in range(2000):
+        x, a, b, x0 = 10 ** rng.uniform(-2, 2), rng.uniform(0.1, 6), rng.uniform(0, 4), 10 ** rng.uniform(-2, 2)
+        y = (x / x0) ** b
+        try:
+            bterm = y / math.expm1(y)
+        except OverflowError:                     # (the reference: bterm = 0, :144-150)
+            bterm = 0.0
+        want = x - (1.0 - math.exp(-x)) * (3.0 + a + b * bterm)
+        assert abs(mbb.alpha_merge_eqn(x, a, b, x0) - want) <= 2e-15 * max(1.0, abs(want))     # (1 - e^-x by expm1 here: a few ulp)
+    assert mbb.alpha_merge_eqn(50.0, 3.0, 400.0, 0.01) == 50.0 - (1.0 - math.exp(-50.0)) * 6.0      # (x / x0)^beta overflows
+    assert mbb.alpha_merge_eqn(2.0, 3.0, 1.5, 1.0, opthin=True) == mbb.alpha_merge_eqn(2.0, 3.0, 1.5, 1.0)
+    assert [mbb.isiterable(o) for o in (np.array(3.0), [1], 3, np.zeros(3), "ab", (x for x in ()), None)] == \
+        [False, True, False, True, True, True, False]
