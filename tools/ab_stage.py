@@ -4,8 +4,15 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mbb_emcee_amd as mbb
 from tools.bench_cfg5 import setup
-from tools.probe_kernel import timeit
 from bench import make_likelihood, walkers
+
+def timeit(ctx, d_pars, n, d_lnl, d_st, reps=300):
+    """us per launch of the fused kernel, HIP events around `reps` back-to-back launches"""
+    ctx.lnlike_repeat_device(d_pars, n, d_lnl, d_st, 20); ctx.sync()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0); ctx.lnlike_repeat_device(d_pars, n, d_lnl, d_st, reps); ctx.record(e1); ctx.sync()
+    return ctx.elapsed_ms(e0, e1) * 1e3 / reps
+
 
 def run(ctx, d_pars, n, d_lnl, d_st, cfgs, reps, rounds=7):
     res = {c: [] for c in cfgs}
