@@ -1324,6 +1324,12 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
             assert np.array_equal(got, want[:n], equal_nan=True), (variant, cov, n)
         assert ctx.info("serving") == 1 and ctx.info("serve_requests") >= 6 and ctx.info("serve_fallbacks") == 0
         assert like(allp[3]) == w1 and type(like(allp[3])) is float and ctx.info("serving") == 1
+        # how far ahead of its scan the host asks for the record lines (option serve_prefetch) is the host's business alone
+        for ahead in (0, 1, 7, 256, 32):
+            ctx.set_option("serve_prefetch", ahead)
+            for n in (125, 125, 125, 125, cus, 33, 1):
+                assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), (variant, cov, ahead, n)
+            assert ctx.info("serve_fallbacks") == 0
         # more rows than CUs: by a launch (the server leaves), then served again after a few calls in a row
         big = like(allp[:cus + 8])
         assert ctx.info("serving") == 0 and np.array_equal(big[:cus], want, equal_nan=True)
