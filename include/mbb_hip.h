@@ -220,13 +220,17 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * answered 256 requests: likelihoods used in turns do not spend their time starting and stopping kernels), tells it to
  * leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
- * switch the feature off.  One such kernel per device across PROCESSES too: nothing of another process fits beside a resident
- * server (emcee's pool, mbb_fit.py:80-81 with threads > 1), so a server is started only while no other process of this
- * library holds a context on the device, and a resident one leaves with the first call that finds one registered (a
- * table in POSIX shared memory keyed by the device's PCI address: csrc/mbb_registry.h; mbb_get_info "device_peers",
- * "serve_peer_yields", "serve_lease_yields"); and for processes that table cannot show, a server is sent away after "serve_lease_us" (50000;
- * 0: never) in one go -- the rows of that call go by a launch, the next server starts after the next few calls in a row.
- * 0: a launch per call; 2: a server even while other processes are registered on the device (tests).  "serve_prefetch" (32; 0 to
+ * switch the feature off.  A server holds a CU per workgroup, and nothing of another PROCESS fits on those (emcee's pool,
+ * mbb_fit.py:80-81 with threads > 1): so it is as wide as the calls have rows (in eights; "serve_grid" > 0: that many
+ * workgroups; mbb_get_info "serve_grid": the resident one's) and no wider than this process's share of the device -- the CUs
+ * divided by the processes of this library that are making boundary calls on it right now (a table in POSIX shared memory
+ * keyed by the device's PCI address, each process noting its calls: csrc/mbb_registry.h; mbb_get_info "device_peers").  Two
+ * workers of 125 rows have their servers side by side; a call of more rows than the share goes by a launch
+ * ("serve_peer_yields"); a server too wide for the share or too narrow for the call leaves and the next starts with the same
+ * call ("serve_resizes").  For processes that table cannot show, a server is sent away after "serve_lease_us" (50000;
+ * 0: never) in one go -- the rows of that call go by a launch, the next server starts after the next few calls in a row
+ * ("serve_lease_yields").
+ * "serve" 0: a launch per call; 2: the whole device is this process's share whoever else is there (tests).  "serve_prefetch" (32; 0 to
  * 256): once a request's first record has turned the host asks for that many record lines ahead of its scan.  "prepass" (-1 auto: from
  * 64 rows per CU; 0 never; 1 always): a likelihood launch of given rows is preceded by k_walker_pre, which works out gate, SED
  * constructor and penalties with a LANE per row (k_lnlike: a row of 16 lanes per walker -- right where a constructor is

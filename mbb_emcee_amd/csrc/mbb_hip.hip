@@ -216,12 +216,15 @@ struct mbb_ctx {
     long opt_serve_after = 3;                 // boundary calls in a row before a server is started
     long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (~1 us per poll)
     long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
+    int opt_serve_grid = 0;                   // workgroups of a resident server (0: as many as the calls have rows, in eights)
+    int srv_grid = 0;                         // ... of the one that is resident
+    int srv_want = 0;                         // the most rows a call of this context has had (in eights): a server is started that wide
+    long srv_resizes = 0;                     // servers that left because they were the wrong width
     int opt_serve_prefetch = 32;              // record lines asked for ahead of the host's scan once the first record has turned (0: none)
     long opt_serve_lease_us = 50000;          // a server is sent away after this long in one go (0: never): processes this library
                                               // cannot see (other containers, other programs) get the CUs at least that often
     long srv_t0_ns = 0;                       // when the present server was started
     uint32_t reg_key = 0;                     // the device's name in the cross-process registry (mbb_registry.h): PCI domain:bus:device
-    unsigned reg_tick = 0;
     long srv_lease_yields = 0;                // servers sent away because their lease was up
     long srv_peer_yields = 0;                 // servers not started, or sent away, because another process is on the device
     unsigned long long buf_gen = 1;   // mbb_boundary_generation: bumped whenever the blocks below are freed and made anew
@@ -1195,8 +1198,19 @@ static int serve_stop(mbb_ctx *c)
 
 // Start a server with the request in the launch itself.  The argument block is launch_lnlike's, filled in here for
 // the fields k_serve reads.
-static int serve_start(mbb_ctx *c, int n, unsigned long long word)
+// How many workgroups a server of this context is started with: a row each for the widest call so far, in eights -- not
+// one per CU: what it does not hold is there for the launches and the servers of other processes (two pool workers of 125
+// rows each have their servers side by side, 8.7 us per call in both: profiles/r05/pool_two_processes_sized.txt) --, and never
+// more than this process's share of the device.
+static int serve_grid(const mbb_ctx *c, int n, int share)
 {
+    int g = c->opt_serve_grid > 0 ? c->opt_serve_grid : std::max(c->srv_want, (n + 7) & ~7);
+    return std::min(std::min(g, share), c->cu_count);
+}
+
+static int serve_start(mbb_ctx *c, int n, unsigned long long word, int grid)
+{
+    if (n > grid) return 1;
     if (!c->w_door) {
         if (hipExtMallocWithFlags((void **)&c->w_door, 64, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
@@ -1263,10 +1277,11 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
     __atomic_store_n(c->w_door, word, __ATOMIC_RELAXED);
     __builtin_ia32_sfence();
     {
-        int rc = launch_packed(c, kern, 56 + si, c->cu_count, threads, sm_total, a);
+        int rc = launch_packed(c, kern, 56 + si, grid, threads, sm_total, a);
         if (rc) return rc;
     }
-    c->last_wpb = 1; c->last_threads = threads; c->last_grid = c->cu_count; c->last_smem = (long)sm_total;
+    c->srv_grid = grid;
+    c->last_wpb = 1; c->last_threads = threads; c->last_grid = grid; c->last_smem = (long)sm_total;
     c->last_stage = stg ? 1 : 0; c->last_smode = 10;
     c->serving = true;
     c->srv_run = 0;
@@ -1280,7 +1295,7 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word)
 
 // One request: MBB_OK when the results are in the pinned slots, 1 when the rows have to go by a launch after all,
 // negative on error.  The parameter rows are in c->w_pars already.
-static int serve_request(mbb_ctx *c, int n)
+static int serve_request(mbb_ctx *c, int n, int grid)
 {
     const int kPfAhead = c->opt_serve_prefetch;
     auto now_ns = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1000000000L + ts.tv_nsec; };
@@ -1298,7 +1313,7 @@ static int serve_request(mbb_ctx *c, int n)
     const long t_b = now_ns();
     long budget_ns = c->opt_serve_budget_us * 1000L;
     if (!c->serving) {
-        int rc = serve_start(c, n, word);
+        int rc = serve_start(c, n, word, grid);
         if (rc) return rc;
         budget_ns += 200000L;                      // (a launch, and the tables into LDS on every CU)
     } else {
@@ -1365,19 +1380,33 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // host path is the default one.  One server per device and process: whichever context comes to the device tells a
     // sibling's to leave first (use(), and the line below).
     bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
-    // ... and one server per device across PROCESSES: a resident server leaves no room for anything of another process
-    // (emcee's pool, mbb_fit.py:80-81 threads > 1: profiles/r05/pool_two_processes_before.txt -- one worker's call waited 42 ms
-    // for the other's whole loop).  While another process of this library is registered on the device no server is
-    // started and a resident one leaves with this call ("serve" 2: regardless -- tests).  An answer that says "somebody
-    // else" is made anew every 256 calls: a peer that died without a word is not believed for long.
-    if (can_serve && c->opt_serve != 2) {
-        const bool had_peers = c->reg_tick & 0x80000000u;
-        const int peers = mbbh::registry_peers(c->reg_key, had_peers && ((c->reg_tick & 255u) == 255u));
-        c->reg_tick = ((c->reg_tick + 1) & 0x7fffffffu) | (peers > 0 ? 0x80000000u : 0u);
-        if (peers > 0) {
+    // ... and across PROCESSES (emcee's pool, mbb_fit.py:80-81 threads > 1: the likelihood pickled into workers that share the
+    // GPU): a server holds a CU per workgroup, and nothing of another process fits on those -- with round 4's server on every
+    // CU one worker's call waited 42 ms for the other's whole loop (profiles/r05/pool_two_processes_before.txt).  So a server is
+    // as wide as the calls have rows, and no wider than this process's share of the device: the CUs divided by the processes
+    // of this library that are making boundary calls on it right now (csrc/mbb_registry.h: each says so at every call; one
+    // that holds a context but does not call -- a pool's parent -- is not in the way).  A call of more rows than the share goes
+    // by a launch; a server that is too wide for the share, or too narrow for the call, leaves and the next starts with this
+    // call.  ("serve" 2: the whole device is this process's share -- tests.)
+    int share = c->cu_count, grid = 0;
+    const long need_hot = c->srv_need > 0 ? c->srv_need : c->opt_serve_after;
+    if (can_serve) {
+        if (c->opt_serve != 2) {
+            timespec tb; clock_gettime(CLOCK_MONOTONIC_COARSE, &tb);
+            const uint64_t now_ms = (uint64_t)tb.tv_sec * 1000u + (uint64_t)(tb.tv_nsec / 1000000);
+            const int busy = mbbh::registry_busy(c->reg_key, now_ms, 250);
+            share = c->cu_count / (busy + 1);
+        }
+        c->srv_want = std::max(c->srv_want, std::min((n + 7) & ~7, c->cu_count));
+        grid = serve_grid(c, n, share);
+        if (n > grid) {
             // (counted once per run of calls that would have been served)
-            if (c->serving || ++c->srv_hot == (c->srv_need > 0 ? c->srv_need : c->opt_serve_after)) ++c->srv_peer_yields;
+            if (c->serving || ++c->srv_hot == need_hot) ++c->srv_peer_yields;
             can_serve = false;
+        } else if (c->serving && (c->srv_grid > share || n > c->srv_grid)) {
+            if ((rc = serve_stop(c))) return rc;
+            c->srv_hot = need_hot;
+            ++c->srv_resizes;
         }
     }
     // ... and not for ever in one go: processes the registry cannot see get the CUs when the lease is up (the rows of this
@@ -1394,8 +1423,8 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // context's run of calls)
     if (!c->serving && (rc = yield_server(c))) return rc;
     bool done = false;
-    if (can_serve && (c->serving || ++c->srv_hot >= (c->srv_need > 0 ? c->srv_need : c->opt_serve_after))) {
-        rc = serve_request(c, n);
+    if (can_serve && (c->serving || ++c->srv_hot >= need_hot)) {
+        rc = serve_request(c, n, grid);
         if (rc < 0) return rc;
         done = rc == MBB_OK;
     } else if (c->serving && (rc = serve_stop(c))) {
@@ -2272,6 +2301,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
     else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
     else if (!strcmp(name, "serve_lease_us")) c->opt_serve_lease_us = value < 0 ? 0 : value;
+    else if (!strcmp(name, "serve_grid")) c->opt_serve_grid = value < 0 ? 0 : (int)std::min<long>(value, 1 << 20);
     else if (!strcmp(name, "serve_prefetch")) c->opt_serve_prefetch = value < 0 ? 0 : (value > 256 ? 256 : (int)value);
     else if (!strcmp(name, "prepass")) c->opt_prepass = value;
     else if (!strcmp(name, "virtual_ranks")) c->opt_vranks = value;
@@ -2307,6 +2337,8 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "serve_enabled")) *value = c->opt_serve;
     else if (!strcmp(name, "device_peers")) *value = mbbh::registry_peers(c->reg_key, true);
     else if (!strcmp(name, "serve_peer_yields")) *value = c->srv_peer_yields;
+    else if (!strcmp(name, "serve_resizes")) *value = c->srv_resizes;
+    else if (!strcmp(name, "serve_grid")) *value = c->serving ? c->srv_grid : 0;
     else if (!strcmp(name, "serve_lease_yields")) *value = c->srv_lease_yields;
     else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;
     else if (!strcmp(name, "last_wait_ns")) *value = c->t_wait_ns;

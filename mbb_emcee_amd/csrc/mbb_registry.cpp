@@ -17,12 +17,13 @@
 namespace mbbh {
 namespace {
 
-constexpr uint32_t kMagic = 0x4d424232u;      // "MBB2"
+constexpr uint32_t kMagic = 0x4d424233u;      // "MBB3"
 constexpr int kSlots = 256, kKeys = 16;
 
 struct Slot {
     std::atomic<int32_t> pid;                 // 0: free
     std::atomic<uint32_t> key[kKeys];         // 0: none
+    std::atomic<uint64_t> beat[kKeys];        // when the process last made a boundary call on that device (CLOCK_MONOTONIC, ms; 0: never)
     std::atomic<uint64_t> born;               // the process's start time (clock ticks since boot, /proc/<pid>/stat field 22;
                                               // 0: unknown): a pid handed out again to somebody else is not mistaken for the owner
 };
@@ -43,6 +44,9 @@ struct Local {
     int joins[kKeys] = {};
     uint64_t gen_seen = ~0ull;                // generation the cached counts are of
     int peers[kKeys] = {};
+    uint64_t scan_ms[kKeys] = {};             // when the busy peers of a key were last counted, and of which generation
+    uint64_t scan_gen[kKeys] = {};
+    int busy[kKeys] = {};
     char name[64] = {};
 } g;
 
@@ -80,7 +84,7 @@ bool alive(int32_t pid, uint64_t born)
 __attribute__((destructor)) void registry_unload()
 {
     if (g.tab && g.my >= 0 && g.pid == (int32_t)getpid()) {
-        for (int i = 0; i < kKeys; ++i) g.tab->slot[g.my].key[i].store(0, std::memory_order_relaxed);
+        for (int i = 0; i < kKeys; ++i) { g.tab->slot[g.my].key[i].store(0, std::memory_order_relaxed); g.tab->slot[g.my].beat[i].store(0, std::memory_order_relaxed); }
         g.tab->slot[g.my].born.store(0, std::memory_order_relaxed);
         g.tab->slot[g.my].pid.store(0, std::memory_order_release);
         g.tab->gen.fetch_add(1, std::memory_order_release);
@@ -95,13 +99,14 @@ bool attach()
     if (g.pid != me) {                        // first use, or a child of fork(): nothing of the parent's is ours
         g.pid = me; g.my = -1; g.gen_seen = ~0ull;
         memset(g.keys, 0, sizeof g.keys); memset(g.joins, 0, sizeof g.joins); memset(g.peers, 0, sizeof g.peers);
+        memset(g.scan_ms, 0, sizeof g.scan_ms); memset(g.scan_gen, 0xff, sizeof g.scan_gen); memset(g.busy, 0, sizeof g.busy);
     }
     if (!g.tab) {
         if (g.tried) return false;
         g.tried = true;
         const char *forced = getenv("MBB_REGISTRY_NAME");       // (tests: a table of their own)
         if (forced && forced[0] == '/') snprintf(g.name, sizeof g.name, "%s", forced);
-        else snprintf(g.name, sizeof g.name, "/mbb_hip_registry2_%u", (unsigned)getuid());
+        else snprintf(g.name, sizeof g.name, "/mbb_hip_registry3_%u", (unsigned)getuid());
         int fd = shm_open(g.name, O_RDWR | O_CREAT, 0600);
         if (fd < 0) return false;
         if (ftruncate(fd, (off_t)sizeof(Table)) != 0) { close(fd); return false; }
@@ -128,7 +133,7 @@ bool attach()
             }
             int32_t none = 0;
             if (sl.pid.compare_exchange_strong(none, me, std::memory_order_acq_rel)) {
-                for (int k = 0; k < kKeys; ++k) sl.key[k].store(0, std::memory_order_relaxed);
+                for (int k = 0; k < kKeys; ++k) { sl.key[k].store(0, std::memory_order_relaxed); sl.beat[k].store(0, std::memory_order_relaxed); }
                 sl.born.store(born_of(me), std::memory_order_release);
                 g.my = i;
             }
@@ -163,6 +168,7 @@ int registry_join(uint32_t key)
     const int i = key_index(key, true);
     if (i < 0) return 0;                      // (more than kKeys devices: the rest go unseen)
     if (++g.joins[i] == 1) {
+        g.tab->slot[g.my].beat[i].store(0, std::memory_order_relaxed);
         g.tab->slot[g.my].key[i].store(key, std::memory_order_release);
         g.tab->gen.fetch_add(1, std::memory_order_acq_rel);
     }
@@ -220,10 +226,38 @@ int registry_peers(uint32_t key, bool recount)
     return g.peers[i];
 }
 
+int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms)
+{
+    if (key == 0) return 0;
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!attach()) return 0;
+    const int i = key_index(key, false);
+    if (i < 0) return 0;
+    g.tab->slot[g.my].beat[i].store(now_ms ? now_ms : 1, std::memory_order_relaxed);       // this process's own call
+    const uint64_t gen = g.tab->gen.load(std::memory_order_acquire);
+    if (now_ms == g.scan_ms[i] && gen == g.scan_gen[i]) return g.busy[i];                   // (counted this millisecond)
+    // Memory reads only: a process that is gone stops calling, and that is all that is asked here (its slot is reclaimed
+    // by registry_peers' recount or by the next process that needs one)
+    const int32_t me = (int32_t)getpid();
+    int n = 0;
+    for (int s = 0; s < kSlots; ++s) {
+        const int32_t pid = g.tab->slot[s].pid.load(std::memory_order_acquire);
+        if (pid == 0 || pid == me) continue;
+        for (int k = 0; k < kKeys; ++k) {
+            if (g.tab->slot[s].key[k].load(std::memory_order_acquire) != key) continue;
+            const uint64_t b = g.tab->slot[s].beat[k].load(std::memory_order_relaxed);
+            if (b != 0 && b + window_ms >= now_ms) ++n;
+        }
+    }
+    g.scan_ms[i] = now_ms; g.scan_gen[i] = gen; g.busy[i] = n;
+    return n;
+}
+
 }  // namespace mbbh
 
 // ---- C hooks for the CPU tests (tests/test_host_cpu.py) ----------------------------------------------------------
 extern "C" int mbbh_registry_join(uint32_t key) { return mbbh::registry_join(key); }
 extern "C" int mbbh_registry_leave(uint32_t key) { return mbbh::registry_leave(key); }
 extern "C" int mbbh_registry_peers(uint32_t key, int recount) { return mbbh::registry_peers(key, recount != 0); }
+extern "C" int mbbh_registry_busy(uint32_t key, unsigned long long now_ms, unsigned long long window_ms) { return mbbh::registry_busy(key, now_ms, window_ms); }
 extern "C" const char *mbbh_registry_name(void) { return mbbh::registry_name(); }

@@ -6,7 +6,8 @@
 // once per half-step, mbb_fit.py:80-81) costs beside its kernel is the launch: ~2.5 us in the runtime's launch call,
 // ~3 us from the doorbell to the first wave, the tables into LDS again -- 14 us per 125-row call of which the kernel
 // is under 7 (profiles/r04/boundary_breakdown.txt).  A sampler's calls come one after another with nothing but host
-// work in between, so after a few of them in a row the host starts THIS kernel instead: one workgroup per CU, tables
+// work in between, so after a few of them in a row the host starts THIS kernel instead: a workgroup per row of the widest call (each on a CU
+// of its own; mbb_hip.hip serve_grid), tables
 // staged once, and then per request
 //   host:   rows -> the parameter block in device memory (through the BAR), sfence, the request word -> the doorbell
 //           (same allocation, same path: PCIe keeps posted writes in order), watches the result slots in pinned memory

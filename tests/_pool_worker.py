@@ -55,6 +55,8 @@ def main():
            "serve_requests": ctx.info("serve_requests"), "serve_fallbacks": ctx.info("serve_fallbacks"),
            "serve_enabled_at_end": ctx.info("serve_enabled"), "serving_at_end": ctx.info("serving"),
            "serve_peer_yields": ctx.info("serve_peer_yields") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
+           "serve_grid_at_end": ctx.info("serve_grid") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
+           "serve_resizes": ctx.info("serve_resizes") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "peers_at_start": peers_at_start}
     json.dump(out, open(os.path.join(d, "out.%d.json" % rank), "w"))
     print("POOL_OK %d" % rank if ok and bad == 0 else "POOL_BAD %d" % rank, flush=True)

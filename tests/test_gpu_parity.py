@@ -1504,16 +1504,52 @@ def _run_pool_workers(mbb, g_lnl, world, ncalls, env_extra=None):
     return [json.load(open(os.path.join(d, "out.%d.json" % r))) for r in range(world)]
 
 
+def test_a_server_is_as_wide_as_the_calls_have_rows(mbb, g_lnl):
+    """A resident server (k_serve) holds a CU per workgroup; it has a workgroup per row of the widest call so far, in eights,
+    not one per CU -- what it does not hold is there for other processes (test_served_boundary_in_two_processes_on_one_gpu).
+    A call of more rows than it has workgroups makes it leave and the next one, wide enough, starts with the same call;
+    option "serve_grid" fixes the width; results bit for bit the launches' throughout."""
+    like = _cfg2_like(mbb, g_lnl)
+    ctx = like._sync_device()
+    cus = ctx.info("cu_count")
+    allp = np.tile(g_lnl["cfg2/thick_walpha/pars"], (3, 1))[:cus]
+    ctx.set_option("serve", 0)
+    want = like(allp).copy()
+    ctx.set_option("serve", 2); ctx.set_option("serve_after", 1); ctx.set_option("serve_budget_us", 100000)
+    ctx.set_option("serve_lease_us", 0)
+    assert ctx.info("serve_grid") == 0                                       # (nobody resident)
+    for _ in range(3):
+        assert like(allp[3]) == want[3]
+    assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 8         # a row at a time: eight workgroups
+    r0 = ctx.info("serve_resizes")
+    for n, grid in ((5, 8), (8, 8), (9, 16), (3, 16), (125, 128), (64, 128), (129, 136), (cus, cus), (1, cus)):
+        for _ in range(3):
+            assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), n
+        assert ctx.info("serving") == 1 and ctx.info("serve_grid") == min(grid, cus), (n, grid, ctx.info("serve_grid"))
+    assert ctx.info("serve_resizes") - r0 == 4 and ctx.info("serve_fallbacks") == 0
+    # a width asked for: calls of more rows go by a launch, the server stays away until the calls fit again
+    ctx.set_option("serve_grid", 32)
+    for n in (20, 32, 20):
+        for _ in range(3):
+            assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), n
+    assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 32
+    assert np.array_equal(like(allp[:33]), want[:33], equal_nan=True) and ctx.info("serving") == 0
+    for _ in range(3):
+        assert np.array_equal(like(allp[:30]), want[:30], equal_nan=True)
+    assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 32 and ctx.info("serve_fallbacks") == 0
+
+
 def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
     """emcee's pool (reference mbb_fit.py:80-81 with threads > 1: the likelihood pickled into worker processes): two
     processes, each with its own copy of the same likelihood, each in a loop of boundary calls -- on ONE GPU.  A
-    resident server (k_serve) holds every CU with most of its LDS, so while one process is being served nothing of
-    another process's fits beside it: neither its own server nor its plain launches.  The library therefore starts a
-    server only while its process is the only one of this library's users on the device (a registry in shared memory:
-    mbb_hip.hip `DeviceRegistry`), and a server that finds a second process registered leaves at its next request.
-    Here: every result of both processes bit for bit right, both loops done in a bounded time, neither process waiting
-    long for the other (no call beyond 20 ms), and -- both being there for the whole loop -- no request answered by a
-    resident kernel."""
+    resident server (k_serve) holds a CU per workgroup with most of its LDS: nothing of another process fits on those.
+    Round 4's server sat on every CU and one worker's call waited 42 ms for the other's whole loop.  Now a server is as wide
+    as the calls have rows and no wider than the process's share of the device (the CUs divided by the processes that are
+    making boundary calls on it: a registry in shared memory, csrc/mbb_registry.cpp), so two workers of 125 rows each have
+    their servers side by side; three cannot (a share of 85 CUs), and every call of theirs is a launch.
+    Here: every result of every process bit for bit right, the loops done in a bounded time, nobody waiting long for another
+    (no call beyond 20 ms), two workers served (the process of this test session holds contexts on the device as well, but
+    makes no calls meanwhile: it is not in the way), three not."""
     import json
     from conftest import ROOT
     ncalls = 3000
@@ -1526,13 +1562,21 @@ def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
     overlap = min(r["t_end"] for r in rep) - max(r["t_start"] for r in rep)
     for r in rep:
         assert r["first_ok"] and r["bad_calls"] == 0 and r["calls"] == ncalls, r
-        assert r["wall_s"] < 5.0 and r["max_us"] < 20000.0, r          # nobody starved: 3000 calls take ~0.05-0.1 s
+        assert r["wall_s"] < 5.0 and r["max_us"] < 20000.0, r          # nobody starved: 3000 calls take ~0.03-0.1 s
         assert r["serve_enabled_at_end"] == 1, r                       # the feature did not strike out either
+        assert r["peers_at_start"] >= 1, r                             # (each sees the other, and this session's process)
     assert overlap > 0.0, rep                                          # (the two loops did run at the same time)
-    # while both were there nobody held the GPU: at most the few requests served before the other process registered
-    # (each worker sees the other, and this test session's own process, which holds contexts on the device too)
-    assert all(r["peers_at_start"] >= 1 for r in rep), rep
-    assert sum(r["serve_requests"] for r in rep) <= 0.05 * 2 * ncalls, rep
+    # side by side: all but the first few calls of each were answered by its own resident kernel, 128 workgroups wide
+    assert all(r["serve_requests"] >= 0.9 * ncalls and r["serve_fallbacks"] <= 3 for r in rep), rep
+    assert all(r.get("serve_grid_at_end", 128) == 128 for r in rep), rep
+    # three workers of 125 rows: 375 CUs are not there -- a share of 85 each, every call a launch, nobody starved
+    rep3 = _run_pool_workers(mbb, g_lnl, 3, 1500, {"MBB_POOL_HAS_PEERS_INFO": "1"})
+    for r in rep3:
+        assert r["first_ok"] and r["bad_calls"] == 0 and r["calls"] == 1500 and r["max_us"] < 20000.0, r
+    # (a worker that begins before it has seen the others call is served for its first milliseconds; once each has counted
+    # the two others -- at most a millisecond later -- its share is 85 CUs, its server leaves and its calls are launches)
+    assert all(r["serving_at_end"] == 0 and r["serve_peer_yields"] >= 1 for r in rep3), rep3
+    assert sum(r["serve_requests"] for r in rep3) <= 0.5 * 3 * 1500, rep3
 
 
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):

@@ -911,11 +911,15 @@ import ctypes, os, sys
 lib = ctypes.CDLL(sys.argv[1])
 lib.mbbh_registry_join.argtypes = [ctypes.c_uint32]; lib.mbbh_registry_leave.argtypes = [ctypes.c_uint32]
 lib.mbbh_registry_peers.argtypes = [ctypes.c_uint32, ctypes.c_int]
+lib.mbbh_registry_busy.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
 for line in sys.stdin:
     cmd, _, arg = line.strip().partition(" ")
     if cmd == "join": print(lib.mbbh_registry_join(int(arg)), flush=True)
     elif cmd == "leave": print(lib.mbbh_registry_leave(int(arg)), flush=True)
     elif cmd == "peers": print(lib.mbbh_registry_peers(int(arg), 0), flush=True)
+    elif cmd == "busy":
+        key, now = arg.split()
+        print(lib.mbbh_registry_busy(int(key), int(now), 250), flush=True)
     elif cmd == "fork":
         # a child of fork() starts afresh: it is a process of its own in the table
         pid = os.fork()
@@ -984,6 +988,23 @@ def test_device_registry_sees_other_processes_and_forgets_dead_ones(tmp_path):
             for pr, ask in kids:
                 pr.kill(); pr.wait()
             assert lib.mbbh_registry_peers(K, 1) == 0 and lib.mbbh_registry_leave(K) == 0
+        # who is BUSY on the device (what a server's width goes by): processes that made a boundary call within the last
+        # 250 ms of the clock they all read -- a process that holds a context and does not call (a pool's parent) is not
+        lib.mbbh_registry_busy.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64]
+        e, ask_e = child()
+        f, ask_f = child()
+        assert ask_e("join %d" % K) == 1 and ask_f("join %d" % K) == 1 and lib.mbbh_registry_join(K) == 1
+        assert lib.mbbh_registry_busy(K, 1000, 250) == 0                                   # registered, none has called
+        assert ask_e("busy %d 1001" % K) == 1                                              # (this process, a millisecond ago)
+        assert lib.mbbh_registry_busy(K, 1002, 250) == 1 and ask_f("busy %d 1003" % K) == 2
+        assert lib.mbbh_registry_busy(K, 1100, 250) == 2
+        assert lib.mbbh_registry_busy(K, 1260, 250) == 0                                   # their calls are 250 ms old
+        assert ask_e("busy %d 1270" % K) == 1 and lib.mbbh_registry_busy(K, 1271, 250) == 1
+        assert lib.mbbh_registry_busy(K2, 1272, 250) == 0                                  # (not a device of this process)
+        e.kill(); e.wait()
+        assert lib.mbbh_registry_busy(K, 1600, 250) == 0                                   # gone: it stopped calling
+        f.stdin.write("quit\n"); f.stdin.flush(); f.wait(timeout=30)
+        assert lib.mbbh_registry_leave(K) == 0
         # a pid handed out again: a slot written by a process that is gone, whose pid now belongs to somebody else (here:
         # to a live child of this test, with a birth time that is not the one the slot holds) is not a peer and is free again
         import mmap, struct
@@ -991,17 +1012,17 @@ def test_device_registry_sees_other_processes_and_forgets_dead_ones(tmp_path):
         assert ask_d("join %d" % K2) == 1 and lib.mbbh_registry_join(K) == 1
         with open("/dev/shm" + name, "r+b") as f:
             mm = mmap.mmap(f.fileno(), 0)
-            slot_bytes, header = 80, 16                     # {pid i32, key u32[16], pad, born u64}; {magic u32, pad, gen u64}
+            slot_bytes, header, born_at = 208, 16, 200      # {pid i32, key u32[16], pad, beat u64[16], born u64}; {magic u32, pad, gen u64}
             assert (len(mm) - header) // slot_bytes == 256
             free = next(i for i in range(256) if struct.unpack_from("<i", mm, header + i * slot_bytes)[0] == 0)
             off = header + free * slot_bytes
             struct.pack_into("<i", mm, off, d.pid)
             struct.pack_into("<I", mm, off + 4, K)
-            struct.pack_into("<Q", mm, off + 72, 12345)     # (nobody alive was born then)
+            struct.pack_into("<Q", mm, off + born_at, 12345)     # (nobody alive was born then)
             assert lib.mbbh_registry_peers(K, 1) == 0
             assert struct.unpack_from("<i", mm, off)[0] == 0
             # ... the same slot with the birth time unknown: the pid alone answers
-            struct.pack_into("<Q", mm, off + 72, 0)
+            struct.pack_into("<Q", mm, off + born_at, 0)
             struct.pack_into("<I", mm, off + 4, K)
             struct.pack_into("<i", mm, off, d.pid)
             assert lib.mbbh_registry_peers(K, 1) == 1
