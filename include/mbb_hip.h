@@ -223,9 +223,10 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * switch the feature off.  A server holds a CU per workgroup, and nothing of another PROCESS fits on those (emcee's pool,
  * mbb_fit.py:80-81 with threads > 1): so it is as wide as the calls have rows (in eights; "serve_grid" > 0: that many
  * workgroups; mbb_get_info "serve_grid": the resident one's) and no wider than this process's share of the device -- the CUs
- * divided by the processes of this library that are making boundary calls on it right now (a table in POSIX shared memory
- * keyed by the device's PCI address, each process noting its calls: csrc/mbb_registry.h; mbb_get_info "device_peers").  Two
- * workers of 125 rows have their servers side by side; a call of more rows than the share goes by a launch
+ * divided (in whole rows of the 8 XCDs) by the processes of this library that are making boundary calls on it right now (a table in POSIX shared memory
+ * keyed by the device's PCI address, each process noting its calls: csrc/mbb_registry.h; mbb_get_info "device_peers": registered, "device_busy": calling).  Two
+ * workers of 125 rows have their servers side by side; a server narrower than a call has rows takes two rows a workgroup
+ * (three workers: 80 CUs each); a call of more than twice the share's rows goes by a launch
  * ("serve_peer_yields"); a server too wide for the share or too narrow for the call leaves and the next starts with the same
  * call ("serve_resizes").  For processes that table cannot show, a server is sent away after "serve_lease_us" (50000;
  * 0: never) in one go -- the rows of that call go by a launch, the next server starts after the next few calls in a row

@@ -80,6 +80,8 @@ MBB_SERVE_EXT(true, false)
 MBB_SERVE_EXT(true, true)
 #undef MBB_SERVE_EXT
 constexpr unsigned long long kServeQuitHost = 0xffffull;
+constexpr int kXcds = 8;                      // MI355X: 8 XCDs of 32 CUs
+constexpr int kServePasses = 2;               // rows a workgroup of a resident server takes of one request, at most
 static size_t serve_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)                  // = serve_lds() of mbb_serve.hip.h
 {
     return sizeof(WalkerK) + 8 * npart + 8 * nb + 16 + 16 * nb + (cov_in_lds ? 8 * nb * nb : 0) + 8 * (nb + 2) + 64;
@@ -220,6 +222,7 @@ struct mbb_ctx {
     int srv_grid = 0;                         // ... of the one that is resident
     int srv_want = 0;                         // the most rows a call of this context has had (in eights): a server is started that wide
     long srv_resizes = 0;                     // servers that left because they were the wrong width
+    int srv_busy = 0;                         // busy processes beside this one, as the latest boundary call counted them
     int opt_serve_prefetch = 32;              // record lines asked for ahead of the host's scan once the first record has turned (0: none)
     long opt_serve_lease_us = 50000;          // a server is sent away after this long in one go (0: never): processes this library
                                               // cannot see (other containers, other programs) get the CUs at least that often
@@ -1210,7 +1213,7 @@ static int serve_grid(const mbb_ctx *c, int n, int share)
 
 static int serve_start(mbb_ctx *c, int n, unsigned long long word, int grid)
 {
-    if (n > grid) return 1;
+    if (grid <= 0 || n > kServePasses * grid) return 1;
     if (!c->w_door) {
         if (hipExtMallocWithFlags((void **)&c->w_door, 64, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
@@ -1392,18 +1395,25 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     const long need_hot = c->srv_need > 0 ? c->srv_need : c->opt_serve_after;
     if (can_serve) {
         if (c->opt_serve != 2) {
-            timespec tb; clock_gettime(CLOCK_MONOTONIC_COARSE, &tb);
+            timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb);
             const uint64_t now_ms = (uint64_t)tb.tv_sec * 1000u + (uint64_t)(tb.tv_nsec / 1000000);
-            const int busy = mbbh::registry_busy(c->reg_key, now_ms, 250);
-            share = c->cu_count / (busy + 1);
+            // (before a server is there every call looks: a pool's workers begin together, and three servers of 128 do not fit)
+            const int busy = mbbh::registry_busy(c->reg_key, now_ms, 250, !c->serving);
+            // (the dispatcher deals a kernel's workgroups to the device's 8 XCDs in turn, and there they stay: what has to fit
+            // is every process's ceil(workgroups / 8) into an XCD's CUs -- three servers of 85 are 33 on the first XCDs of 32,
+            // one workgroup never starts and every request of its server times out)
+            share = kXcds * ((c->cu_count / kXcds) / (busy + 1));
+            c->srv_busy = busy;
         }
         c->srv_want = std::max(c->srv_want, std::min((n + 7) & ~7, c->cu_count));
         grid = serve_grid(c, n, share);
-        if (n > grid) {
+        // (a server narrower than the call has rows takes them in turns, kServePasses rows a workgroup at most: beyond that a
+        // launch is the faster way)
+        if (grid <= 0 || n > kServePasses * grid) {
             // (counted once per run of calls that would have been served)
             if (c->serving || ++c->srv_hot == need_hot) ++c->srv_peer_yields;
             can_serve = false;
-        } else if (c->serving && (c->srv_grid > share || n > c->srv_grid)) {
+        } else if (c->serving && (c->srv_grid > share || (n > c->srv_grid && grid > c->srv_grid))) {
             if ((rc = serve_stop(c))) return rc;
             c->srv_hot = need_hot;
             ++c->srv_resizes;
@@ -2338,6 +2348,7 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "device_peers")) *value = mbbh::registry_peers(c->reg_key, true);
     else if (!strcmp(name, "serve_peer_yields")) *value = c->srv_peer_yields;
     else if (!strcmp(name, "serve_resizes")) *value = c->srv_resizes;
+    else if (!strcmp(name, "device_busy")) *value = c->srv_busy;
     else if (!strcmp(name, "serve_grid")) *value = c->serving ? c->srv_grid : 0;
     else if (!strcmp(name, "serve_lease_yields")) *value = c->srv_lease_yields;
     else if (!strcmp(name, "last_launch_ns")) *value = c->t_launch_ns;

@@ -226,7 +226,7 @@ int registry_peers(uint32_t key, bool recount)
     return g.peers[i];
 }
 
-int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms)
+int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms, bool recount)
 {
     if (key == 0) return 0;
     std::lock_guard<std::mutex> lk(g.mu);
@@ -235,7 +235,7 @@ int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms)
     if (i < 0) return 0;
     g.tab->slot[g.my].beat[i].store(now_ms ? now_ms : 1, std::memory_order_relaxed);       // this process's own call
     const uint64_t gen = g.tab->gen.load(std::memory_order_acquire);
-    if (now_ms == g.scan_ms[i] && gen == g.scan_gen[i]) return g.busy[i];                   // (counted this millisecond)
+    if (!recount && now_ms == g.scan_ms[i] && gen == g.scan_gen[i]) return g.busy[i];       // (counted this millisecond)
     // Memory reads only: a process that is gone stops calling, and that is all that is asked here (its slot is reclaimed
     // by registry_peers' recount or by the next process that needs one)
     const int32_t me = (int32_t)getpid();
@@ -259,5 +259,6 @@ int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms)
 extern "C" int mbbh_registry_join(uint32_t key) { return mbbh::registry_join(key); }
 extern "C" int mbbh_registry_leave(uint32_t key) { return mbbh::registry_leave(key); }
 extern "C" int mbbh_registry_peers(uint32_t key, int recount) { return mbbh::registry_peers(key, recount != 0); }
-extern "C" int mbbh_registry_busy(uint32_t key, unsigned long long now_ms, unsigned long long window_ms) { return mbbh::registry_busy(key, now_ms, window_ms); }
+extern "C" int mbbh_registry_busy(uint32_t key, unsigned long long now_ms, unsigned long long window_ms) { return mbbh::registry_busy(key, now_ms, window_ms, false); }
+extern "C" int mbbh_registry_busy_now(uint32_t key, unsigned long long now_ms, unsigned long long window_ms) { return mbbh::registry_busy(key, now_ms, window_ms, true); }
 extern "C" const char *mbbh_registry_name(void) { return mbbh::registry_name(); }

@@ -31,8 +31,9 @@ int registry_leave(uint32_t key);
 int registry_peers(uint32_t key, bool recount);
 // Other processes registered on `key` that made a boundary call on it within the last `window_ms` (they say so here, with
 // `now_ms` of one clock all processes read: CLOCK_MONOTONIC in ms); also notes this process's own call.  Counted at most once
-// per millisecond, from memory alone.  A process that holds a context but is not calling (a pool's parent) is not in the way.
-int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms);
+// per millisecond unless `recount` (a process about to start a server looks every time: workers of a pool begin together),
+// from memory alone.  A process that holds a context but is not calling (a pool's parent) is not in the way.
+int registry_busy(uint32_t key, uint64_t now_ms, uint64_t window_ms, bool recount);
 // (tests) the name of the shared-memory object this process uses
 const char *registry_name();
 

@@ -136,8 +136,9 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
     const long long idle = a.persist > 0 ? (long long)a.persist : 1000;
     for (int turn = 0;; ++turn) {
         const int n = (int)(cur & 0xffffull);
-        const int w = (int)blockIdx.x;
-        if (w < n) {
+        // (a server narrower than the request has rows -- its process's share of the device, mbb_hip.hip -- takes its rows in
+        // turns: workgroup b rows b, b + workgroups, ...)
+        for (int w = (int)blockIdx.x; w < n; w += (int)gridDim.x) {
             // ---- phase 1 (k_lnlike's, SMODE 0): gate, constructor, parameter-only penalties on one row of 16 lanes --
             // in two parts when the quadrature may start on the first
             SV_EV(0);
@@ -460,6 +461,9 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     SV_EV(6);
                 }
             }
+            // (another row of this request: the first wave is through with this row's sums and penalties before any wave writes
+            // the next row's)
+            if (w + (int)gridDim.x < n) __syncthreads();
         }
         // ---- the next request: thread 0 watches the doorbell, the workgroup follows it
         if (tid == 0) {

@@ -57,6 +57,7 @@ def main():
            "serve_peer_yields": ctx.info("serve_peer_yields") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "serve_grid_at_end": ctx.info("serve_grid") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "serve_resizes": ctx.info("serve_resizes") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
+           "busy_at_end": ctx.info("device_busy") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "peers_at_start": peers_at_start}
     json.dump(out, open(os.path.join(d, "out.%d.json" % rank), "w"))
     print("POOL_OK %d" % rank if ok and bad == 0 else "POOL_BAD %d" % rank, flush=True)

@@ -1527,15 +1527,17 @@ def test_a_server_is_as_wide_as_the_calls_have_rows(mbb, g_lnl):
             assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), n
         assert ctx.info("serving") == 1 and ctx.info("serve_grid") == min(grid, cus), (n, grid, ctx.info("serve_grid"))
     assert ctx.info("serve_resizes") - r0 == 4 and ctx.info("serve_fallbacks") == 0
-    # a width asked for: calls of more rows go by a launch, the server stays away until the calls fit again
+    # a width asked for (what the share of a device does to a pool's worker): a server narrower than a call has rows takes two
+    # rows a workgroup; calls of more rows than that go by a launch and the server stays away until the calls fit again
     ctx.set_option("serve_grid", 32)
-    for n in (20, 32, 20):
+    for n in (20, 32, 33, 64, 47, 20):
         for _ in range(3):
             assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), n
-    assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 32
-    assert np.array_equal(like(allp[:33]), want[:33], equal_nan=True) and ctx.info("serving") == 0
+        assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 32, n
+    assert np.array_equal(like(allp[:65]), want[:65], equal_nan=True) and ctx.info("serving") == 0
+    assert np.array_equal(like(allp[:cus]), want, equal_nan=True) and ctx.info("serving") == 0
     for _ in range(3):
-        assert np.array_equal(like(allp[:30]), want[:30], equal_nan=True)
+        assert np.array_equal(like(allp[:61]), want[:61], equal_nan=True)
     assert ctx.info("serving") == 1 and ctx.info("serve_grid") == 32 and ctx.info("serve_fallbacks") == 0
 
 
@@ -1546,10 +1548,10 @@ def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
     Round 4's server sat on every CU and one worker's call waited 42 ms for the other's whole loop.  Now a server is as wide
     as the calls have rows and no wider than the process's share of the device (the CUs divided by the processes that are
     making boundary calls on it: a registry in shared memory, csrc/mbb_registry.cpp), so two workers of 125 rows each have
-    their servers side by side; three cannot (a share of 85 CUs), and every call of theirs is a launch.
+    their servers side by side; three have a share of 80 CUs each and their servers' workgroups take two rows of a request.
     Here: every result of every process bit for bit right, the loops done in a bounded time, nobody waiting long for another
-    (no call beyond 20 ms), two workers served (the process of this test session holds contexts on the device as well, but
-    makes no calls meanwhile: it is not in the way), three not."""
+    (no call beyond 20 ms), everybody served (the process of this test session holds contexts on the device as well, but
+    makes no calls meanwhile: it is not in the way)."""
     import json
     from conftest import ROOT
     ncalls = 3000
@@ -1569,14 +1571,13 @@ def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
     # side by side: all but the first few calls of each were answered by its own resident kernel, 128 workgroups wide
     assert all(r["serve_requests"] >= 0.9 * ncalls and r["serve_fallbacks"] <= 3 for r in rep), rep
     assert all(r.get("serve_grid_at_end", 128) == 128 for r in rep), rep
-    # three workers of 125 rows: 375 CUs are not there -- a share of 85 each, every call a launch, nobody starved
+    # three workers of 125 rows: 375 CUs are not there -- a share of 80 each (10 on each of the 8 XCDs: the dispatcher deals a
+    # kernel's workgroups to the XCDs in turn, three times 11 do not fit into an XCD's 32 CUs), two rows a workgroup
     rep3 = _run_pool_workers(mbb, g_lnl, 3, 1500, {"MBB_POOL_HAS_PEERS_INFO": "1"})
     for r in rep3:
         assert r["first_ok"] and r["bad_calls"] == 0 and r["calls"] == 1500 and r["max_us"] < 20000.0, r
-    # (a worker that begins before it has seen the others call is served for its first milliseconds; once each has counted
-    # the two others -- at most a millisecond later -- its share is 85 CUs, its server leaves and its calls are launches)
-    assert all(r["serving_at_end"] == 0 and r["serve_peer_yields"] >= 1 for r in rep3), rep3
-    assert sum(r["serve_requests"] for r in rep3) <= 0.5 * 3 * 1500, rep3
+        assert r["serving_at_end"] == 1 and r["serve_grid_at_end"] == 80 and r["serve_fallbacks"] <= 3, r
+        assert r["serve_requests"] >= 0.9 * 1500, r
 
 
 def test_emcee_call_conventions_on_the_gpu_path(mbb, g_lnl, monkeypatch):
