@@ -1393,9 +1393,10 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // call.  ("serve" 2: the whole device is this process's share -- tests.)
     int share = c->cu_count, grid = 0;
     const long need_hot = c->srv_need > 0 ? c->srv_need : c->opt_serve_after;
+    timespec tb = {0, 0};
     if (can_serve) {
+        clock_gettime(CLOCK_MONOTONIC, &tb);                   // (one look at the clock: who is busy, and the lease)
         if (c->opt_serve != 2) {
-            timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb);
             const uint64_t now_ms = (uint64_t)tb.tv_sec * 1000u + (uint64_t)(tb.tv_nsec / 1000000);
             // (before a server is there every call looks: a pool's workers begin together, and three servers of 128 do not fit)
             const int busy = mbbh::registry_busy(c->reg_key, now_ms, 250, !c->serving);
@@ -1422,8 +1423,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // ... and not for ever in one go: processes the registry cannot see get the CUs when the lease is up (the rows of this
     // call go by a launch, a new server starts after the next few calls in a row)
     if (can_serve && c->serving && c->opt_serve_lease_us > 0) {
-        timespec tl; clock_gettime(CLOCK_MONOTONIC, &tl);
-        if (tl.tv_sec * 1000000000L + tl.tv_nsec - c->srv_t0_ns > c->opt_serve_lease_us * 1000L) {
+        if (tb.tv_sec * 1000000000L + tb.tv_nsec - c->srv_t0_ns > c->opt_serve_lease_us * 1000L) {
             can_serve = false;
             c->srv_hot = 0;
             ++c->srv_lease_yields;
