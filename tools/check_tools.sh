@@ -38,6 +38,7 @@ run python3 tools/ab_two_libs.py tools/libmbb_hip_cur.so mbb_emcee_amd/libmbb_hi
 run python3 tools/ab_m1.py tools/libmbb_hip_cur.so mbb_emcee_amd/libmbb_hip.so 1
 run python3 tools/ab_sampler_step.py tools/libmbb_hip_cur.so mbb_emcee_amd/libmbb_hip.so 1
 run python3 tools/ab_option.py serve_prefetch 0 32 --rounds 1
+run python3 tools/probe_other_streams.py
 run python3 tools/soak_flowm_sizes.py 200
 run python3 tools/soak_resident_sizes.py 100 300
 run python3 tools/soak_random_configs.py 1 2

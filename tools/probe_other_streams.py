@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """What a resident server (k_serve) means for OTHER streams of its process: the time a small torch kernel takes from its launch to
 its completion (torch's own streams) while a sampler-like loop of boundary calls is being served, against the same with
-nothing resident; by the priority the library's stream was made with (MBB_STREAM_PRIORITY = default / high / low).
-    python tools/probe_other_streams.py"""
+nothing resident.  (Measured once with the library's stream made at high and at low priority as well: the same, and M1 the
+same: profiles/r05/served_boundary.txt 16.)      python tools/probe_other_streams.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,9 +33,7 @@ def torch_latency(like, nrep=300):
 
 print("a torch kernel on one of six torch streams, launch -> done (us: median, p99, max)")
 print("  nothing of the library resident:          %.1f  %.1f  %.1f" % torch_latency(None))
-for name in ("default", "high", "low"):
-    if name == "default": os.environ.pop("MBB_STREAM_PRIORITY", None)
-    else: os.environ["MBB_STREAM_PRIORITY"] = name
+for name in ("default",):
     like = make_likelihood(0)[0]
     ctx = like._sync_device()
     for serve in (0, 1):
