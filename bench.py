@@ -440,6 +440,69 @@ def config_roofline(name, plain_us, half_step_us, form, half, ctx):
     return roof
 
 
+_POOL_WORKER = r"""
+import json, os, pickle, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+d, rank, world, ncalls, serve = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+import mbb_emcee_amd  # noqa
+like = pickle.load(open(os.path.join(d, "like.pkl"), "rb"))
+pars = np.load(os.path.join(d, "pars.npy"))
+ctx = like._sync_device()
+ctx.set_option("serve", 0)
+first = like(pars)
+ctx.set_option("serve", serve)
+open(os.path.join(d, "ready.%d.%d" % (serve, rank)), "w").close()
+t0 = time.time()
+while not all(os.path.exists(os.path.join(d, "ready.%d.%d" % (serve, r))) for r in range(world)):
+    if time.time() - t0 > 60:
+        raise SystemExit("the other worker never came")
+    time.sleep(0.0005)
+ts = np.empty(ncalls)
+ok = True
+for i in range(ncalls):
+    a = time.perf_counter(); r = like(pars); ts[i] = time.perf_counter() - a
+    if i % 97 == 0:
+        ok = ok and bool(np.array_equal(r, first, equal_nan=True))
+json.dump({"p50_us": float(np.median(ts) * 1e6), "p99_us": float(np.percentile(ts, 99) * 1e6), "max_us": float(ts.max() * 1e6),
+           "served": int(ctx.info("serve_requests")), "fell_back": int(ctx.info("serve_fallbacks")), "ok": ok,
+           "server_workgroups": int(ctx.info("serve_grid"))}, open(os.path.join(d, "out.%d.%d.json" % (serve, rank)), "w"))
+"""
+
+
+def pool_leg(like, pos, world=2, ncalls=1500):
+    """emcee's pool (reference mbb_fit.py:80-81 with threads > 1): the likelihood pickled into `world` worker PROCESSES, each in
+    a loop of boundary calls of NW/2 rows at the same time on the one GPU; as the library does it (every worker's own
+    resident kernel, as wide as its calls have rows, side by side) and with a launch per call."""
+    import pickle, subprocess, tempfile, shutil
+    d = tempfile.mkdtemp(prefix="mbb_pool_")
+    try:
+        pickle.dump(like, open(os.path.join(d, "like.pkl"), "wb"))
+        np.save(os.path.join(d, "pars.npy"), np.ascontiguousarray(pos[:NW_PER_GPU // 2]))
+        out = {"workers": world, "rows": NW_PER_GPU // 2, "calls": ncalls}
+        for name, serve in (("served", 1), ("launch_per_call", 0)):
+            procs = [subprocess.Popen([sys.executable, "-c", _POOL_WORKER, ROOT, d, str(r), str(world), str(ncalls), str(serve)],
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(world)]
+            errs = []
+            for pr in procs:
+                try:
+                    e = pr.communicate(timeout=90)[1]
+                    if pr.returncode:
+                        errs.append(e.decode(errors="replace")[-300:])
+                except subprocess.TimeoutExpired:
+                    pr.kill(); errs.append("timeout")
+            if errs:
+                out[name] = {"error": errs[0]}
+                continue
+            reps = [json.load(open(os.path.join(d, "out.%d.%d.json" % (serve, r)))) for r in range(world)]
+            out[name] = {"p50_us": [r["p50_us"] for r in reps], "p99_us": [r["p99_us"] for r in reps],
+                         "served_requests": [r["served"] for r in reps], "fell_back": [r["fell_back"] for r in reps],
+                         "server_workgroups": [r["server_workgroups"] for r in reps], "results_right": all(r["ok"] for r in reps)}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def postprocess_leg(like, pos, cpu=True):
     """SURVEY.md 8f rank 4 measured: the chain post-processing of mbb_results (results.py:570-581 peak wavelength,
     :627-674 L_IR, :746-801 dust mass, :895-944 predicted fluxes) over a stored 250 x 250 chain of the bench
@@ -590,7 +653,7 @@ def short_line(full):
         out["roofline_hbm"] = _pick(h, ("achieved", "peak", "unit", "frac", "traffic_ratio"))
     b = full.get("boundary_M1")
     if isinstance(b, dict):
-        out["boundary_M1"] = _pick(b, ("rows", "p50_us", "p90_us", "evals_per_s", "launch_per_call_p50_us"))
+        out["boundary_M1"] = _pick(b, ("rows", "p50_us", "p90_us", "evals_per_s", "launch_per_call_p50_us", "two_processes_p50_us"))
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         o = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_value"))
@@ -1655,6 +1718,14 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     if not args.no_fit:
         out["user_runs"] = user_runs(like, pos)
         out["postprocess"] = postprocess_leg(like, pos, cpu=not args.no_cpu)
+        try:
+            ctx.set_option("serve", 1)            # (this process steps aside: nothing of it resident, it makes no calls meanwhile)
+            out["pool_two_processes"] = pool_leg(like, pos)
+            pw = out["pool_two_processes"].get("served", {})
+            if "p50_us" in pw and isinstance(out.get("boundary_M1"), dict):
+                out["boundary_M1"]["two_processes_p50_us"] = float(max(pw["p50_us"]))
+        except Exception as e:      # noqa -- a side leg
+            out["pool_two_processes"] = {"error": repr(e)}
 
     # ---- the other single-GPU configurations of BASELINE.json (configs[0], configs[3]): M1, M2, the
     # plain launch, its fp64 roofline from the committed PMC pass of that launch, the CPU oracle on
