@@ -216,7 +216,7 @@ struct mbb_ctx {
     long srv_requests = 0, srv_fallbacks = 0;
     long opt_serve = 1;                       // 0: every boundary call is a launch; 2: a server even beside other contexts (tests)
     long opt_serve_after = 3;                 // boundary calls in a row before a server is started
-    long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (~1 us per poll)
+    long opt_serve_idle_us = 1000;            // the server leaves after this long without a request (by the clock all CUs share)
     long opt_serve_budget_us = 400;           // the host gives a served request this long before it falls back to a launch
     int opt_serve_grid = 0;                   // workgroups of a resident server (0: as many as the calls have rows, in eights)
     int srv_grid = 0;                         // ... of the one that is resident

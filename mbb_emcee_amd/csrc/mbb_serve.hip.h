@@ -26,7 +26,7 @@
 // launch's -- and its reduction (spec_cfg bit 0; units beyond the waves' number are evaluated behind the constructor, as in
 // k_lnlike; without the bit -- few samples, a narrow workgroup -- the phases run one after the other).
 // The kernel leaves when told to (the doorbell says QUIT: any other use of the context, its destruction) or when
-// workgroup 0 has seen no request for `idle` polls (~1 us each; it then writes QUIT itself so that every workgroup
+// workgroup 0 has seen no request for `idle` microseconds (it then writes QUIT itself so that every workgroup
 // follows); every workgroup besides has a safety limit of its own (four times that).  Whatever goes wrong -- a request
 // written while the kernel was leaving, a workgroup that was not resident -- shows on the host as result slots that do
 // not turn within its budget: it then says QUIT, waits for the stream, and evaluates the rows by a launch.
@@ -43,7 +43,7 @@ __host__ __device__ constexpr size_t serve_lds(size_t nb, size_t npart, bool cov
 
 // Arguments (LikeArgs fields of variants that never meet share storage): pars = the parameter block, lnl = the pinned
 // result records [row]{lnl, status as a 64-bit integer}, pos6 = the doorbell (one 8-byte word: request number << 16 | rows), seed = the request the
-// launch itself carries (served at once), persist = idle limit in polls, chain6 = the host's "gone" word (pinned).
+// launch itself carries (served at once), persist = idle limit in microseconds, chain6 = the host's "gone" word (pinned).
 template <bool OPTHIN, bool NOALPHA, bool STAGE, bool OVL>
 __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
 {
@@ -468,14 +468,18 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
         // ---- the next request: thread 0 watches the doorbell, the workgroup follows it
         if (tid == 0) {
             unsigned long long v = cur;
-            const long long limit = (blockIdx.x == 0) ? idle : 4 * idle + 64;
-            long long polls = 0;
+            // (idle time by the clock all CUs share, 100 MHz -- not by counting polls: a poll takes 0.3-1 us depending on who
+            // else is polling, and a server that leaves after 0.35 ms instead of the millisecond asked for does not outlast a
+            // sibling's start)
+            const unsigned long long limit = 100ull * (unsigned long long)((blockIdx.x == 0) ? idle : 4 * idle + 64);
+            const unsigned long long t_idle = __builtin_amdgcn_s_memrealtime();
+            unsigned polls = 0;
             for (;;) {
                 v = __hip_atomic_load(door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (v != cur) break;
-                if (++polls > limit) {
+                if ((++polls & 7u) == 0u && __builtin_amdgcn_s_memrealtime() - t_idle > limit) {
                     v = (cur & ~0xffffull) | kServeQuit;
-                    // workgroup 0 has seen nothing for `idle` polls: it says so where everybody looks
+                    // workgroup 0 has seen nothing for `idle` microseconds: it says so where everybody looks
                     if (blockIdx.x == 0)
                         __hip_atomic_store(const_cast<unsigned long long *>(door), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
