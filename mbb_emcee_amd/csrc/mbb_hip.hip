@@ -422,7 +422,21 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
         if (!pool.empty()) { c->stream = pool.back(); pool.pop_back(); }
     }
     if (!c->stream) {
-        hipError_t es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        // The runtime deals the streams of one priority class to four hardware queues in turn, and a kernel that lands behind
+        // a RESIDENT one on its queue (k_serve between a sampler's calls) does not start until that one leaves -- measured:
+        // tools/lat_two_residents.hip, 20 ms (the resident kernel's own limit) instead of 50 us for every fourth stream.
+        // Streams of another class never share a queue with it.  So the library's streams are of the class applications use
+        // least, the least urgent one: whatever the application (torch, a prior of its own on the GPU) puts on its streams is
+        // not held up by a resident server.  (By itself the class costs nothing: M1 and M2 the same at any priority.)
+        int least = 0, most = 0;
+        hipError_t es = hipDeviceGetStreamPriorityRange(&least, &most);
+        if (es == hipSuccess && least != most) es = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, least);
+        else es = hipErrorNotSupported;
+        if (es != hipSuccess) {
+            (void)hipGetLastError();
+            c->stream = nullptr;
+            es = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        }
         if (es != hipSuccess) { delete c; return fail(MBB_ERR_HIP, "hipStreamCreateWithFlags", es); }
     }
     ++g_dev[device].live;

@@ -42,17 +42,25 @@ int main()
     printf("second resident kernel (128 workgroups, a CU each) launched while the first is resident: us until it says 'here' (20000+: not before the first left)\n");
     volatile unsigned long long *hv = h;
     unsigned long long id = 0;
-    for (int extra = 0; extra <= 8; ++extra) {
-        for (int mode = 0; mode < 3; ++mode) {            // 0: both default priority; 1: second at high priority; 2: second at low priority
+    for (int between : {2, 3, 7}) {
+        const int extra = 2;
+        for (int mode = 0; mode < 6; ++mode) {            // 0: both default; 1 / 2: second high / low; 3: second made WithPriority(0); 4: FIRST high, second default; 5: both high
             std::vector<hipStream_t> others(extra);
             for (auto &s : others) CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
             // (the other streams have been used: a stream gets its hardware queue with its first work)
             for (auto &s : others) { hipLaunchKernelGGL(k_stay, dim3(1), dim3(64), 1024, s, d + 8, d + 9, 0ull); }
             for (auto &s : others) CHK(hipStreamSynchronize(s));
             hipStream_t s1, s2;
-            CHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
-            if (mode == 0) CHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-            else CHK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, mode == 1 ? phi : plo));
+            if (mode >= 4) CHK(hipStreamCreateWithPriority(&s1, hipStreamNonBlocking, phi));
+            else CHK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+            // (... and `between` more made, and used, between the two that matter: if streams are dealt to the hardware queues in
+            // turn, the second of the two lands on the first's queue when `between` + 1 is a multiple of their number)
+            std::vector<hipStream_t> mids(between);
+            for (auto &s : mids) { if (mode == 5) CHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, phi)); else CHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+            for (auto &s : mids) { hipLaunchKernelGGL(k_stay, dim3(1), dim3(64), 1024, s, d + 8, d + 9, 0ull); }
+            for (auto &s : mids) CHK(hipStreamSynchronize(s));
+            if (mode == 0 || mode == 4) CHK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+            else CHK(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, mode == 1 || mode == 5 ? phi : (mode == 2 ? plo : 0)));
             double worst = 0.0;
             for (int rep = 0; rep < 5; ++rep) {
                 const unsigned long long a = ++id, b = ++id;
@@ -72,9 +80,10 @@ int main()
                 if (t < 0.0) t = 30000.0;
                 if (t > worst) worst = t;
             }
-            printf("  %d other streams made first, second stream %-16s : %9.1f us at worst of 5\n", extra,
-                   mode == 0 ? "default priority" : (mode == 1 ? "high priority" : "low priority"), worst);
+            printf("  %d streams made between the two, second stream %-19s : %9.1f us at worst of 5\n", between,
+                   mode == 0 ? "default priority" : mode == 1 ? "high priority" : mode == 2 ? "low priority" : mode == 3 ? "WithPriority(0)" : mode == 4 ? "default (1st high)" : "high (all high)", worst);
             CHK(hipStreamDestroy(s1)); CHK(hipStreamDestroy(s2));
+            for (auto &s : mids) CHK(hipStreamDestroy(s));
             for (auto &s : others) CHK(hipStreamDestroy(s));
         }
     }
