@@ -1,6 +1,7 @@
 // Two kernels of ONE process that stay on the GPU at the same time, each on a stream of its own: does the second start while the
 // first is resident?  (Two servers of two likelihoods side by side: profiles/r05/served_boundary.txt 16.)  By how many other
-// streams the process has made before (the runtime deals streams to a few hardware queues) and by the streams' priorities.
+// streams the process makes BETWEEN the two (the runtime deals the streams of a priority class to four hardware queues in turn)
+// and by the streams' priority classes.
 // Every kernel is 128 workgroups x 1024 threads with 100 KB of LDS (a CU each), says "here" in a pinned word and spins until told
 // to leave or for 20 ms at most.
 //     hipcc --offload-arch=gfx950 -O3 -o tools/lat_two_residents tools/lat_two_residents.hip && tools/lat_two_residents
