@@ -214,7 +214,7 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * parameter rows into device memory through the PCIe BAR), "serve" (default 1: after "serve_after" (3) boundary calls in a row
  * with nothing else in between -- a sampler's loop -- mbb_lnlike_call hands its rows to a kernel that STAYS on the GPU
  * between the calls and is rung through the BAR (k_serve: no launch per call; same results bit for bit), while a batch
- * is at most a row per CU.  One such kernel per device and process: any other entry point on the context, and any entry
+ * is at most two rows per CU (a workgroup of the kernel takes a row; a call of more rows than it has workgroups, two).  One such kernel per device and process: any other entry point on the context, and any entry
  * point of ANOTHER context of the process that comes to the device (which also ends this context's run of calls, and
  * doubles, up to 64, the calls in a row it needs before its next server -- back to "serve_after" once a server has
  * answered 256 requests: likelihoods used in turns do not spend their time starting and stopping kernels), tells it to

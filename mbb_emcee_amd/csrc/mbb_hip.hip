@@ -1319,9 +1319,9 @@ static int serve_request(mbb_ctx *c, int n, int grid)
     const long t_a = now_ns();
     // (the records exist once a server has been started; before that serve_start makes them)
     if (!c->h_srv) {
-        HIPCHK(hipHostMalloc((void **)&c->h_srv, (size_t)c->cu_count * 8 * kSrvStride, hipHostMallocMapped | hipHostMallocCoherent));
+        HIPCHK(hipHostMalloc((void **)&c->h_srv, (size_t)kServePasses * c->cu_count * 8 * kSrvStride, hipHostMallocMapped | hipHostMallocCoherent));
         HIPCHK(hipHostGetDevicePointer((void **)&c->dv_srv, c->h_srv, 0));
-        c->srv_cap = (size_t)c->cu_count;
+        c->srv_cap = (size_t)kServePasses * c->cu_count;
     }
     uint64_t *hr = reinterpret_cast<uint64_t *>(c->h_srv);
     for (int i = 0; i < n; ++i) hr[kSrvStride * i + 1] = (uint64_t)kStatusSentinel;
@@ -1396,7 +1396,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // a kernel that stays on the GPU (k_serve) instead of a launch each: while the batch is at most a row per CU and the
     // host path is the default one.  One server per device and process: whichever context comes to the device tells a
     // sibling's to leave first (use(), and the line below).
-    bool can_serve = c->opt_serve && push && n <= c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
+    bool can_serve = c->opt_serve && push && n <= kServePasses * c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
     // ... and across PROCESSES (emcee's pool, mbb_fit.py:80-81 threads > 1: the likelihood pickled into workers that share the
     // GPU): a server holds a CU per workgroup, and nothing of another process fits on those -- with round 4's server on every
     // CU one worker's call waited 42 ms for the other's whole loop (profiles/r05/pool_two_processes_before.txt).  So a server is

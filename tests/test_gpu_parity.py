@@ -1330,12 +1330,23 @@ def test_served_boundary_equals_the_launches(mbb, g_lnl):
             for n in (125, 125, 125, 125, cus, 33, 1):
                 assert np.array_equal(like(allp[:n]), want[:n], equal_nan=True), (variant, cov, ahead, n)
             assert ctx.info("serve_fallbacks") == 0
-        # more rows than CUs: by a launch (the server leaves), then served again after a few calls in a row
-        big = like(allp[:cus + 8])
-        assert ctx.info("serving") == 0 and np.array_equal(big[:cus], want, equal_nan=True)
-        for _ in range(4):
+        # more rows than CUs: two rows a workgroup (a 1000-walker ensemble's half-steps through a host sampler); more than
+        # twice the CUs: by a launch (the server leaves), then served again after a few calls in a row
+        wide = np.tile(allp, (2, 1))
+        ctx.set_option("serve", 0)
+        want_wide = like(wide[:2 * cus + 8]).copy()
+        ctx.set_option("serve", 2)
+        for _ in range(3):
             assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
         assert ctx.info("serving") == 1
+        for n in (cus + 8, 2 * cus, cus + 1, 300):
+            assert np.array_equal(like(wide[:n]), want_wide[:n], equal_nan=True), (variant, cov, n)
+            assert ctx.info("serving") == 1 and ctx.info("serve_grid") == cus, n
+        big = like(wide[:2 * cus + 8])
+        assert ctx.info("serving") == 0 and np.array_equal(big, want_wide, equal_nan=True)
+        for _ in range(4):
+            assert np.array_equal(like(allp[:125]), want[:125], equal_nan=True)
+        assert ctx.info("serving") == 1 and ctx.info("serve_fallbacks") == 0
         # anything else on the context: it leaves first, and what was set is what the next calls see
         like.set_uplim("T", 12.0)
         changed = like(allp[:125])
