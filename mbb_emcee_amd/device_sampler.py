@@ -175,6 +175,49 @@ class DeviceEnsembleSampler(object):
         self._last = (pos, lnprob)
         return pos, lnprob, self.seed
 
+    def sample(self, p0, lnprob0=None, rstate0=None, iterations=1, storechain=True, chunk=64):
+        """emcee's generator form (``for pos, lnprob, rstate in sampler.sample(p0, iterations=N)``): the ensemble after
+        every step.  The steps are made ``chunk`` at a time in one launch on the device -- a launch has a fixed cost of
+        ~20 us beside ~6 us per step -- and handed out one by one: the chain is the one the same sequence of
+        run_mcmc(.., chunk) calls makes (with ``chunk`` >= ``iterations``: run_mcmc(p0, iterations)'s; the draws of a step are
+        keyed by the sampler's step count AND the step's place in its launch, so another grouping is another, equally valid,
+        chain).  Breaking out of the loop early leaves the sampler ahead of the step that was handed out last by at most
+        ``chunk`` - 1 steps."""
+        iterations, chunk = int(iterations), max(1, int(chunk))
+        ax = 1 if self.nsources == 1 else 2
+        kept_c, kept_l = self._chain, self._lnprob
+        n_prev = kept_c.shape[ax]
+        if storechain:
+            # (room for the whole run once, filled chunk by chunk: no chain is copied more than that)
+            big_c = np.empty(kept_c.shape[:ax] + (n_prev + iterations, self.dim))
+            big_l = np.empty(kept_l.shape[:ax] + (n_prev + iterations,))
+            big_c[..., :n_prev, :] = kept_c
+            big_l[..., :n_prev] = kept_l
+        pos0, l0 = p0, lnprob0
+        done = 0
+        try:
+            while done < iterations:
+                k = min(chunk, iterations - done)
+                self._chain, self._lnprob = kept_c[..., :0, :], kept_l[..., :0]
+                self.run_mcmc(pos0, k, lnprob0=l0, storechain=True)
+                steps, lnps = self._chain, self._lnprob          # (this chunk's own arrays)
+                pos0 = l0 = None
+                if storechain:
+                    big_c[..., n_prev + done:n_prev + done + k, :] = steps
+                    big_l[..., n_prev + done:n_prev + done + k] = lnps
+                done += k
+                for j in range(k):
+                    if storechain:
+                        self._chain, self._lnprob = big_c[..., :n_prev + done, :], big_l[..., :n_prev + done]
+                    else:
+                        self._chain, self._lnprob = kept_c, kept_l
+                    yield steps[..., j, :], lnps[..., j], self.seed
+        finally:
+            if storechain:
+                self._chain, self._lnprob = big_c[..., :n_prev + done, :], big_l[..., :n_prev + done]
+            else:
+                self._chain, self._lnprob = kept_c, kept_l
+
     def advance_async(self, N):
         """Enqueue N steps without storing or synchronising (benchmarks)."""
         ctx, h = self._handle()

@@ -605,6 +605,58 @@ def test_device_sampler_statistics_match_host_sampler(mbb):
     assert abs(a0 - a1) < 0.08 and 0.2 < a1 < 0.9
 
 
+def test_device_sampler_generator_form_equals_run_mcmc(mbb, g_lnl):
+    """emcee's generator form, ``for pos, lnprob, rstate in sampler.sample(p0, iterations=N)`` (the host sampler has it:
+    ensemble.py), on the device sampler: the steps are made a chunk at a time in one launch and handed out one by one.  The
+    chain is the one the same sequence of run_mcmc calls makes, bit for bit -- with a chunk of the whole run, run_mcmc's own --
+    stored or not, continued by run_mcmc, broken out of early; and whatever the chunk it samples the same posterior."""
+    like = _cfg2_like(mbb, g_lnl)
+    rng = np.random.RandomState(8)
+    p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(64, 5)))
+    for chunk in (1, 7, 64, 1000):
+        ref = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+        pos, left = p0, 100
+        while left > 0:                                              # the same steps by run_mcmc, chunk by chunk
+            ref.run_mcmc(pos, min(chunk, left)); pos = None; left -= min(chunk, left)
+        ref.run_mcmc(None, 50)
+        s = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+        seen = 0
+        for pos, lnp, _ in s.sample(p0, iterations=100, chunk=chunk):
+            assert np.array_equal(pos, ref.chain[:, seen, :]) and np.array_equal(lnp, ref.lnprobability[:, seen]), (chunk, seen)
+            seen += 1
+            assert s.chain.shape[1] >= seen                           # (what has been handed out is in the chain)
+        assert seen == 100 and s.chain.shape == (64, 100, 5) and s.iterations == 100
+        s.run_mcmc(None, 50)                                          # ... and goes on as run_mcmc does
+        assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.lnprobability, ref.lnprobability), chunk
+        assert np.array_equal(s.naccepted, ref.naccepted)
+    whole = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+    whole.run_mcmc(p0, 100)
+    assert np.array_equal(s.chain[:, :100], whole.chain)              # (the last chunk above was the whole run)
+    # nothing stored: the same ensembles, the chain untouched
+    ref = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+    ref.run_mcmc(p0, 16); ref.run_mcmc(None, 16); ref.run_mcmc(None, 8)
+    s = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+    last = None
+    for k, (pos, lnp, _) in enumerate(s.sample(p0, iterations=40, storechain=False, chunk=16)):
+        assert np.array_equal(pos, ref.chain[:, k, :])
+        last = pos.copy()
+    assert s.chain.shape == (64, 0, 5) and s.iterations == 40 and np.array_equal(last, ref.chain[:, 39, :])
+    # broken out of early: the chain holds whole chunks
+    s = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+    for k, (pos, lnp, _) in enumerate(s.sample(p0, iterations=100, chunk=10)):
+        if k == 24:
+            break
+    assert s.chain.shape[1] == 30 and s.iterations == 30
+    # the posterior is the same whatever the chunk (means of the second half of longer runs, in units of the spread)
+    a, b = mbb.DeviceEnsembleSampler(64, 5, like, seed=5), mbb.DeviceEnsembleSampler(64, 5, like, seed=5)
+    a.run_mcmc(p0, 1200)
+    for _ in b.sample(p0, iterations=1200, chunk=13):
+        pass
+    fa, fb = a.chain[:, 600:].reshape(-1, 5), b.chain[:, 600:].reshape(-1, 5)
+    assert np.all(np.abs(fa.mean(0) - fb.mean(0)) < 0.25 * fa.std(0)), (fa.mean(0), fb.mean(0), fa.std(0))
+    del s, ref, whole, a, b
+
+
 def test_device_sampler_errors(mbb, g_lnl):
     like = _cfg2_like(mbb, g_lnl)
     with pytest.raises(ValueError):
