@@ -351,7 +351,7 @@ def dominant_kernel_roofline(form, pairs, staged, k_us, steps, kern_label, nq, n
     return roof, hbm
 
 
-def user_runs(like, pos):
+def user_runs(like, pos, bench_steps=None):
     import mbb_emcee_amd as mbb
     from tools.bench_configs import CFG1_WAVE
     ctx = like._sync_device()
@@ -360,7 +360,8 @@ def user_runs(like, pos):
     smp = mbb.DeviceEnsembleSampler(NW_PER_GPU, 5, like, seed=11)
     smp.run_mcmc(pos, 60, storechain=False)
     stored = {}
-    for k in (250, 2000):
+    lengths = [250, 2000] + ([int(bench_steps)] if bench_steps and int(bench_steps) not in (250, 2000) else [])
+    for k in lengths:
         cur, lnp = smp.run_mcmc(None, k)[:2]                   # (warm: the chain buffer of this length exists)
         ts = []
         for _ in range(5):
@@ -628,9 +629,12 @@ def short_line(full):
     if cfg.get("collective_fallback_from"):
         c["collective_fallback_from"] = [_txt(t, 80) for t in cfg["collective_fallback_from"][:3]]
     out["config"] = c
-    for k in ("half_step_us", "kernel_avg_us", "acceptance_fraction"):
+    for k in ("value_median_of_9", "us_per_step_median_of_9", "stored_chain_us_per_step", "stored_chain_us_per_step_at_K",
+              "half_step_us", "kernel_avg_us", "acceptance_fraction"):
         if k in full:
             out[k] = _num(full[k])
+    if isinstance(full.get("us_per_step_min_max_of_9"), (list, tuple)):
+        out["us_per_step_min_max_of_9"] = [_num(float(v), 5) for v in full["us_per_step_min_max_of_9"][:2]]
     r = full.get("roofline")
     if isinstance(r, dict):
         o = _pick(r, ("bound",))
@@ -653,7 +657,13 @@ def short_line(full):
         out["roofline_hbm"] = _pick(h, ("achieved", "peak", "unit", "frac", "traffic_ratio"))
     b = full.get("boundary_M1")
     if isinstance(b, dict):
-        out["boundary_M1"] = _pick(b, ("rows", "p50_us", "p90_us", "evals_per_s", "launch_per_call_p50_us", "two_processes_p50_us"))
+        o = _pick(b, ("rows", "p50_us", "p90_us", "p99_us", "max_us", "evals_per_s", "calls", "slow_calls", "slow_runs",
+                      "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes",
+                      "launch_per_call_p50_us", "two_processes_p50_us"), 5)
+        if isinstance(b.get("last_leg"), dict):
+            o["last_leg"] = _pick(b["last_leg"], ("median_us", "p90_us", "p99_us", "max_us", "slow_calls", "slow_runs",
+                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes"), 5)
+        out["boundary_M1"] = o
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         o = _pick(cb, ("value", "unit", "cores", "kind", "single_thread_value"))
@@ -782,13 +792,12 @@ def base_line(args, world):
 # prints ONE line.  A rank that dies while the exchanges the timed run did not use are
 # being rehearsed therefore cannot take the measured line with it.
 # ---------------------------------------------------------------------------------------
-def free_port():
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+def rendezvous_file():
+    """Where the ranks this supervisor starts meet: a FILE (torch's FileStore) in a fresh directory.  Nobody picks a
+    port -- round 5's harness picked one, closed it and handed the number on; it was taken when the listener came
+    (GPUTEST_r05: EADDRINUSE) -- gloo's own listeners bind port 0 and publish what they got through the file."""
+    import tempfile
+    return os.path.join(tempfile.mkdtemp(prefix="mbb_bench_rdzv_"), "store")
 
 
 def supervise(args):
@@ -811,15 +820,20 @@ def supervise(args):
     # from whatever rank 0 has handed over by then: the measured value if there is one, an error otherwise.
     t_start = time.time()
     budget = float(os.environ.get("MBB_BENCH_DEADLINE_S", SUPERVISOR_DEADLINE_S))
-    port = os.environ.get("MASTER_PORT") or str(free_port())
+    # under torch.distributed.run the launcher's own store is there (MASTER_PORT names a port that IS listening: the
+    # ranks are its clients); started bare, the ranks meet through a file
+    rdzv = None if (launched and os.environ.get("MASTER_PORT")) else rendezvous_file()
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs, lines = {}, []
     for r in ranks:
         env = dict(os.environ, MBB_BENCH_WORKER="1", WORLD_SIZE=str(world), RANK=str(r),
-                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
                    MBB_BENCH_T0=repr(t_start), MBB_BENCH_DEADLINE_S=repr(budget))
         if not launched:
             env["LOCAL_RANK"] = str(r)
+        if rdzv:
+            env["MBB_BENCH_RDZV_FILE"] = rdzv
+            env.setdefault("GLOO_SOCKET_IFNAME", "lo")            # one node: the loopback interface, no hostname look-up
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         try:
             # rank 0's stdout is collected; the other ranks have nothing to say there
@@ -904,42 +918,17 @@ def supervise(args):
     return worst
 
 
-def fake_worker(args, how):
-    """Test hook (tests/test_host_cpu.py; MBB_BENCH_FAKE_WORKER): a rank that touches nothing and behaves as
-    told, so that the supervisor's collecting, merging, waiting and ending of ranks can be tested without a GPU."""
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if rank == 0 and "noline" not in how:
-        line = dict(base_line(args, world), value=1.0e6 * world, ms_per_step=1.0)
-        if "full" in how:
-            # every leg populated: round 4's whole line (20.7 KB, the one the driver could not parse)
-            line = dict(json.load(open(os.path.join(ROOT, "profiles", "r04", "bench_v5.json"))), **line)
-        emit_line(line)
-    under_supervisor = os.environ.get("MBB_BENCH_WORKER") == "1"       # (a one-GPU run has no parts)
-    if rank == 0 and "part" in how and under_supervisor:
-        emit({"_part": "exchange_validation", "data": {"rccl": {"ok": True, "us_per_step": 20.0}}})
-    if rank == 0 and "full" in how and under_supervisor:
-        long_why = "rehearsal: the ranks' copies of the ensemble differ after 60 steps " * 20
-        emit({"_part": "exchange_validation", "data": {"ipc": {"ok": False, "why": long_why}, "ipc-launches": {"ok": True, "us_per_step": 30.0, "why": long_why},
-                                                       "rccl": {"ok": True, "us_per_step": 20.0, "steps": 500, "kernel_form": 1, "why": long_why}}})
-        emit({"_part": "boundary_sharded", "data": {"ok": True, "what": long_why, "rows_%d" % (125 * world): {"median_us": 31.123456789, "p90_us": 40.0, "calls": 200},
-                                                    "rows_%d" % (250 * world): {"median_us": 35.123456789, "p90_us": 45.0, "calls": 200}}})
-    if rank == 1 and "crash1" in how:
-        os._exit(7)
-    if rank == 1 and "hang1" in how:
-        time.sleep(600)
-    if rank == 0 and "hang0" in how:
-        sys.stdout.flush()
-        time.sleep(600)
-    if rank == 0 and "fail0" in how:
-        os._exit(3)
-    return 0
-
-
 def main():
     args = parse_args()
-    if os.environ.get("MBB_BENCH_FAKE_WORKER") and (os.environ.get("MBB_BENCH_WORKER") == "1" or
-                                                    (args.gpus == 1 and os.environ.get("MBB_BENCH_WORKER_FAKE_TOP"))):
-        sys.exit(fake_worker(args, os.environ["MBB_BENCH_FAKE_WORKER"]))
+    hook = os.environ.get("MBB_BENCH_RANK_HOOK")
+    if hook and (os.environ.get("MBB_BENCH_WORKER") == "1" or (args.gpus == 1 and os.environ.get("MBB_BENCH_WORKER_FAKE_TOP"))):
+        # tests only (tests/_fake_bench_rank.py): a stand-in for a rank, so that the supervisor's collecting, merging,
+        # waiting and ending of ranks and the printing of the line can be tested without a GPU
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_bench_rank_hook", hook)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        sys.exit(mod.run(sys.modules[__name__], args))
     if os.environ.get("MBB_BENCH_WORKER") == "1" or (args.gpus == 1 and "WORLD_SIZE" not in os.environ):
         return worker(args)
     sys.exit(supervise(args))
@@ -1023,8 +1012,10 @@ def worker_body(args, rank, world, local_rank, base, fail):
             import datetime
             # (a collective of the side channel that a lost peer never joins ends by itself well inside the
             # supervisor's deadline)
+            rdzv = os.environ.get("MBB_BENCH_RDZV_FILE")
             dist.init_process_group(backend="gloo", rank=rank, world_size=world,
-                                    timeout=datetime.timedelta(seconds=120))
+                                    timeout=datetime.timedelta(seconds=120),
+                                    **({"init_method": "file://" + rdzv} if rdzv else {}))
             dist.barrier()
         finally:
             sys.stdout.flush()
@@ -1299,6 +1290,13 @@ def worker_body(args, rank, world, local_rank, base, fail):
         out = dict(base)
         out.update({"value": nwt * args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps,
                     "mcmc_steps_per_s": args.steps / elapsed,
+                    # (`value` is ONE region of K steps; the median of it and the eight regions right behind it says what
+                    # a typical one is)
+                    **({"value_median_of_9": nwt * args.steps / float(np.median([elapsed] + [w for w, _ in run["again"]])),
+                        "us_per_step_median_of_9": 1e6 * float(np.median([elapsed] + [w for w, _ in run["again"]])) / args.steps,
+                        "us_per_step_min_max_of_9": [1e6 * min([elapsed] + [w for w, _ in run["again"]]) / args.steps,
+                                                     1e6 * max([elapsed] + [w for w, _ in run["again"]]) / args.steps]}
+                       if run.get("again") else {}),
                     "stream_us_per_step": stream_ms * 1e3 / args.steps,
                     **({"same_region_again_us": {"wall": [round(w * 1e6, 2) for w, _ in run["again"]],
                                                  "stream": [round(m * 1e3, 2) for _, m in run["again"]],
@@ -1514,6 +1512,29 @@ def sharded_boundary(ctx, like, rank, world, allw, nwt, barrier, all_ok, bcast, 
     return res
 
 
+def boundary_loop(like, ctx, p, n, ncalls=400, warm=50):
+    """`ncalls` synchronous boundary calls of the rows `p` in a loop, each timed by the wall clock: median, tail, which
+    calls were slow and what the library's serve counters moved by over exactly these calls."""
+    for _ in range(warm):
+        like(p)
+    names = ("serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes")
+    before = [ctx.info(k) for k in names]
+    ts = np.empty(ncalls)
+    clock = time.perf_counter
+    for i in range(ncalls):
+        t0 = clock(); like(p); ts[i] = clock() - t0
+    after = [ctx.info(k) for k in names]
+    med = float(np.median(ts))
+    slow = np.flatnonzero(ts > 1.5 * med)
+    runs = int(np.sum(np.diff(slow) > 1) + 1) if slow.size else 0
+    res = {"median_us": med * 1e6, "p90_us": float(np.percentile(ts, 90)) * 1e6, "p99_us": float(np.percentile(ts, 99)) * 1e6,
+           "max_us": float(ts.max()) * 1e6, "evals_per_s": n / med, "calls": ncalls,
+           "slow_calls": int(slow.size), "slow_runs": runs,
+           "slow_call_indices": [int(i) for i in slow[:40]], "slow_call_us": [round(float(ts[i]) * 1e6, 2) for i in slow[:40]]}
+    res.update({k: int(a - b) for k, a, b in zip(names, after, before)})
+    return res
+
+
 def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=1, staged=True, partial=None, kern_short=None):
     """Everything on the line besides the timed region (rank 0, one GPU).  `partial`: the caller's line, filled in
     leg by leg, so that what was measured before a leg failed is kept."""
@@ -1531,14 +1552,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
         sub = {}
         for n in (half, NW_PER_GPU, 1):
             p = np.ascontiguousarray(pos[:n]) if n > 1 else np.ascontiguousarray(pos[0])
-            for _ in range(50):
-                like(p)
-            ts = []
-            for _ in range(400):
-                t0 = time.perf_counter(); like(p); ts.append(time.perf_counter() - t0)
-            med = float(np.median(ts))
-            sub["rows_%d" % n] = {"median_us": med * 1e6, "p90_us": float(np.percentile(ts, 90)) * 1e6,
-                                  "evals_per_s": n / med, "calls": len(ts)}
+            sub["rows_%d" % n] = boundary_loop(like, ctx, p, n)
         sub["served_by_resident_kernel"] = bool(ctx.info("serving"))
         sub["serve_fallbacks"] = ctx.info("serve_fallbacks")
         bnd[mode] = sub
@@ -1550,12 +1564,20 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
                    "default for a sampler's loop of calls; `launch_per_call`: every call a kernel launch")
     out["boundary"] = bnd
     # M1 where a reader of the line looks first: what an external sampler such as emcee gets per half-step of the
-    # bench's ensemble (125 rows), next to `value`, which is the device-resident sampler's rate (M2)
-    out["boundary_M1"] = {"rows": half, "p50_us": bnd["rows_%d" % half]["median_us"], "p90_us": bnd["rows_%d" % half]["p90_us"],
-                          "evals_per_s": bnd["rows_%d" % half]["evals_per_s"],
+    # bench's ensemble (125 rows), next to `value`, which is the device-resident sampler's rate (M2).  With the tail and
+    # what the library did meanwhile: a slow call is either the library's doing (a request that fell back to a launch, a
+    # server sent away when its lease was up or made anew for another width: the deltas of its counters over exactly
+    # these calls) or the box's (none of those, the slow calls in a few runs of neighbours: a host thread descheduled)
+    b125 = bnd["rows_%d" % half]
+    out["boundary_M1"] = {"rows": half, "p50_us": b125["median_us"], "p90_us": b125["p90_us"],
+                          "evals_per_s": b125["evals_per_s"],
+                          **{k: b125[k] for k in ("p99_us", "max_us", "calls", "slow_calls", "slow_runs", "serve_requests",
+                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes")},
                           "launch_per_call_p50_us": bnd["launch_per_call"]["rows_%d" % half]["median_us"],
                           "what": "synchronous likelihood.__call__(float64[125, 5]) -> float64[125], host arrays in and out, in a "
-                                  "loop of calls (the rows are served by a kernel resident between the calls)",
+                                  "loop of calls (the rows are served by a kernel resident between the calls); slow_calls: "
+                                  "those beyond 1.5 x the median, slow_runs: in how many runs of neighbours they came; serve_*: "
+                                  "what the library's counters moved by over exactly these calls",
                           # (how the three host steps of a call -- rows in, native call, results out -- were made)
                           "host_glue": ("CPython extension (mbb_emcee_amd/csrc/mbb_fastcall.c)"
                                         if like._fast is not None and like._fast[7] is not None else "numpy + ctypes")}
@@ -1716,7 +1738,14 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     # the device-resident sampler (the default) and with the host stretch move that calls
     # likelihood.__call__ once per half-step (what an external sampler such as emcee does)
     if not args.no_fit:
-        out["user_runs"] = user_runs(like, pos)
+        out["user_runs"] = user_runs(like, pos, bench_steps=args.steps)
+        st = out["user_runs"].get("sampler_M2_stored_chain", {})
+        # what mbb_fitter.run / run_mcmc(storechain=True) delivers -- the chain on the host in emcee's layout (consumed at
+        # results.py:154-155) -- beside `value`, which is the unstored advance: for a user's 2000 steps and for this run's K
+        if "steps_2000" in st:
+            out["stored_chain_us_per_step"] = st["steps_2000"]["wall_us_per_step"]
+        if "steps_%d" % args.steps in st:
+            out["stored_chain_us_per_step_at_K"] = st["steps_%d" % args.steps]["wall_us_per_step"]
         out["postprocess"] = postprocess_leg(like, pos, cpu=not args.no_cpu)
         try:
             ctx.set_option("serve", 1)            # (this process steps aside: nothing of it resident, it makes no calls meanwhile)
@@ -1733,6 +1762,18 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     if not args.no_configs:
         from tools.bench_configs import measure as cfg_measure
         out["configs"] = {c: cfg_measure(c, roofline_fn=config_roofline, cpu=not args.no_cpu) for c in ("cfg1", "cfg4")}
+
+    # ---- M1 once more, as the LAST measurement on the GPU of this run: is a tail in the first leg the leg's place (right
+    # behind the timed region) or the box?
+    try:
+        ctx.set_option("serve", 1)
+        again = boundary_loop(like, ctx, np.ascontiguousarray(pos[:half]), half)
+        if isinstance(out.get("boundary_M1"), dict):
+            out["boundary_M1"]["last_leg"] = {k: again[k] for k in ("median_us", "p90_us", "p99_us", "max_us", "slow_calls", "slow_runs",
+                                                                     "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes")}
+        out["boundary"]["last_leg_rows_%d" % half] = again
+    except Exception as e:      # noqa -- a side leg
+        out["boundary"]["last_leg_error"] = repr(e)
 
     if not args.no_cpu:
         cb, ref = cpu_baseline(like, flux, pos)

@@ -141,7 +141,15 @@ static int load_rccl()
     // A copy that is in the process already first (by its soname): a launcher that has imported torch brings torch's
     // own librccl / libamdhip64 / libhsa-runtime64 along, this library then runs on THAT HIP runtime (same soname), and
     // a second RCCL from the system path would bring a second HSA runtime with it.
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    // MBB_RCCL_LIB names the library outright: a site's own RCCL build -- and what the one-GPU tests use to run the
+    // N > 1 code with ranks that share a device (tests/rccl_standin/).  A path that does not load is an error, never
+    // a reason to look elsewhere.
+    void *h = nullptr;
+    if (const char *named = getenv("MBB_RCCL_LIB")) {
+        if (*named && !(h = dlopen(named, RTLD_NOW | RTLD_LOCAL)))
+            return fail(MBB_ERR_RCCL, "cannot load the library MBB_RCCL_LIB names");
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);

@@ -33,7 +33,10 @@ class TorchComm(object):
 
 def main():
     import torch.distributed as dist
-    dist.init_process_group(backend="gloo")
+    # ranks started by the test itself; they meet through a FILE the parent named: no port is picked by anybody but
+    # gloo's own listeners (round 5: a port chosen, closed and handed to a launcher was taken when it went to listen)
+    dist.init_process_group(backend="gloo", init_method="file://" + os.environ["MBB_TEST_RDZV_FILE"],
+                            rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank, world = dist.get_rank(), dist.get_world_size()
     from mbb_emcee_amd.parallel import ShardedLikelihood, block_bounds
     from mbb_emcee_amd.ensemble import EnsembleSampler

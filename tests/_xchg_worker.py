@@ -10,12 +10,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    import torch.distributed as dist
-    dist.init_process_group(backend="gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    from _filecomm import FileComm
+    dist = FileComm()                                  # ranks started by the test itself: files, no port, no torch
+    rank, world = dist.rank, dist.world
     import mbb_emcee_amd as mbb
     from mbb_emcee_amd import parallel
     g = np.load(os.path.join(ROOT, "tests", "golden", "lnlike.npz"))
@@ -72,10 +73,9 @@ def main():
         assert np.array_equal(a, b) and np.array_equal(la, lb)
         # the whole chain, gathered by the caller over the side channel
         full = smp.chain.copy()
-        import torch
-        t = torch.from_numpy(full)
-        dist.all_reduce(t)                                 # disjoint rows, zeros elsewhere: the sum is the gather
-        assert np.array_equal(t.numpy()[:, :nsteps], rchain)
+        parts = [np.frombuffer(b, dtype=full.dtype).reshape(full.shape) for b in dist.allgather_bytes(full.tobytes())]
+        full = np.sum(parts, axis=0)                       # disjoint rows, zeros elsewhere: the sum is the gather
+        assert np.array_equal(full[:, :nsteps], rchain)
         dist.barrier()
         launches_before = ctx.info("xchg_launches")
         if one_launch:
@@ -93,7 +93,6 @@ def main():
         import gc
         gc.collect()
         ctx.xchg_close()
-        dist.destroy_process_group()
         if rank == 0:
             print("XCHG_OK")
         return
@@ -119,10 +118,16 @@ def main():
     import gc
     gc.collect()
     ctx.xchg_close()
-    dist.destroy_process_group()
     if rank == 0:
         print("XCHG_OK")
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        try:                                           # the other ranks stop waiting for this one
+            open(os.path.join(os.environ["MBB_TEST_RDZV_DIR"], "abort"), "w").close()
+        except Exception:
+            pass
+        raise

@@ -85,6 +85,12 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
+def pytest_collection_modifyitems(config, items):
+    """Tests that start other processes (tests/test_zz_gpu_processes.py) run LAST whatever order the files were named in
+    on the command line: a harness of processes that fails under -x must not hide kernel tests behind it."""
+    items.sort(key=lambda it: 1 if "test_zz_gpu_processes" in it.nodeid else 0)      # (stable: nothing else moves)
+
+
 def pytest_deselected(items):
     if items:
         cfg = items[0].config

@@ -269,6 +269,8 @@ def _run_bench(argv, env_extra=None):
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MBB_BENCH_WORKER")}
     env.update(env_extra or {})
+    if "MBB_BENCH_FAKE_WORKER" in env:
+        env["MBB_BENCH_RANK_HOOK"] = os.path.join(ROOT, "tests", "_fake_bench_rank.py")
     pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env,
                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     out = [ln for ln in pr.stdout.decode().splitlines() if ln.strip()]
@@ -413,7 +415,8 @@ def test_bench_prints_the_short_line_and_the_side_file(world, tmp_path):
     (root / "profiles" / "r04").mkdir(parents=True)
     shutil.copy(os.path.join(ROOT, "profiles", "r04", "bench_v5.json"), root / "profiles" / "r04" / "bench_v5.json")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MBB_BENCH_WORKER")}
-    env.update({"MBB_BENCH_FAKE_WORKER": "full,part", "MBB_BENCH_GRACE_S": "5", "PYTHONPATH": ROOT})
+    env.update({"MBB_BENCH_FAKE_WORKER": "full,part", "MBB_BENCH_GRACE_S": "5", "PYTHONPATH": ROOT,
+                "MBB_BENCH_RANK_HOOK": os.path.join(ROOT, "tests", "_fake_bench_rank.py")})
     if world == 1:
         env["MBB_BENCH_WORKER_FAKE_TOP"] = "1"
     pr = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5"], env=env,
@@ -606,15 +609,24 @@ def test_block_bounds():
 def test_sharded_two_ranks_gloo():
     """world_size 2 over gloo: partition, pad, all-gather, reassemble and a whole
     sharded sampler run equal the single-process result bit for bit."""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "_dist_worker.py")]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert "DIST_OK" in out.stdout
+    import tempfile
+    d = tempfile.mkdtemp(prefix="mbb_gloo_")
+    env = dict(os.environ, OMP_NUM_THREADS="1", WORLD_SIZE="2", MBB_TEST_RDZV_FILE=os.path.join(d, "rdzv"),
+               GLOO_SOCKET_IFNAME="lo")
+    for k in ("MASTER_PORT", "MASTER_ADDR", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    texts = []
+    for pr in procs:
+        try:
+            texts.append(pr.communicate(timeout=300)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()                                              # exactly the processes started above
+            raise AssertionError("a rank did not finish within 300 s")
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(t[-3000:] for t in texts)
+    assert "DIST_OK" in texts[0]
 
 
 # ------------------------------------------------- host-only table builders (C++), sanitizers
