@@ -29,11 +29,9 @@ using mbbm::m_exp;
 using mbbm::m_expm1;
 using mbbm::m_log;
 using mbbm::m_exp_t;
-using mbbm::m_expm1_t;
-using mbbm::Exp2Entry;
 using mbbm::kExp2Tab;
 using mbbm::kExp2N;
-using mbbm::poly8_eval;
+using mbbm::polyrow_eval;
 
 // modified_blackbody.py:15-18
 constexpr double kH = 6.6260693e-34;      // J s
@@ -66,7 +64,8 @@ struct WalkerK {
     double lhokt9;   // log(hokt9)
     double beta;
     double bp3;      // beta + 3                               fnu.pyx:19
-    double bp2;      // beta + 2 (x^(beta+3)/expm1(x) = x^(beta+2) b(x), b = x/expm1(x))
+    double cq;       // normfac (h/kT)^2: the band scale of the fused kernels' quadrature, which sums f_nu / x^2 against
+                     // weights w nu^2 (mbb_host_tables.h) -- rounds 2-5 kept beta + 2 here
     double alpha;
     double lx0;      // log(x0), thick only
     double xmerge;   // +inf when there is no Wien-side power law
@@ -453,7 +452,7 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
     w.lhokt9 = s.lhokt9;
     w.beta = beta;
     w.bp3 = beta + 3.0;
-    w.bp2 = beta + 2.0;
+    w.cq = s.normfac * (s.hokt9 * s.hokt9);
     w.alpha = NOALPHA ? 0.0 : alpha;
     w.lx0 = OPTHIN ? 0.0 : s.lx0;
     w.xmerge = NOALPHA ? __builtin_inf() : s.xmerge;
@@ -463,234 +462,84 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
 }
 
 // The tables of the sample loop, all in LDS: 2^(j/256) for exp (mbb_math.hip.h) and the
-// piecewise polynomials of b(x) = x/expm1(x) and c(y) = (1 - e^-y)/y (mbb_host_tables.h).
-struct SampleTabs { const Exp2Entry *e; const double *b; const double *c; };
+// piecewise polynomials of b(x) = x/expm1(x) and C(y) = 1 - e^-y (mbb_host_tables.h).
+struct SampleTabs { const double *e; const double *b; const double *c; };
 
-constexpr double kLn40 = 3.6888794541139363;       // e^-40 < 2^-57: 1 - e^-y is 1 beyond
+constexpr double kLnCMax = 3.6109179126442243;       // log(kPolyCMax = 37): e^-37 < 2^-53, 1 - e^-y is 1 beyond
+static_assert(mbbm::kPolyCMax == 37, "kLnCMax is log(37)");
+constexpr double kXFar8 = 8.0 * mbbm::kPolyBMax;   // in units of X = 8 x: where the table of b ends
 
 // One quadrature sample: f_nu at frequency nu (GHz), lnnu = log(nu).
 // fnu.pyx:9-108, the four kernels.
-// TAB = true (the passband loop of the fused kernel; `tabs` points into LDS): the Planck
-// factor x^3/expm1(x) is x^2 b(x) and the optical-depth factor 1 - e^-y is y c(y), with b
-// and c read off piecewise degree-7 polynomials -- 11 operations each instead of an
-// expm1 (19) plus, for b, a division (10) -- so a sample costs one exp (the power
-// x^(beta+2), (x/x0)^beta or x^-alpha), never a division.  For x > 64, beyond the table,
-// 1 - e^-x is 1 to the last bit and b(x) = x e^-x.
+// TAB = true (the passband loop of the fused kernels; `tabs` points into LDS; always with
+// SCALE = false): the value is f_nu / (normfac x^2) -- the Planck factor x^3/expm1(x) is
+// x^2 b(x), and the x^2 = (h/kT)^2 nu^2 is not formed per sample: nu^2 is in the weight
+// table, (h/kT)^2 goes with normfac into the one factor per band (WalkerK::cq).  b(x) and
+// the optical-depth factor C(y) = 1 - e^-y are read off piecewise degree-7 polynomials --
+// 10 operations each (row, fraction, address, 7 fma) instead of an expm1 (19) plus, for b,
+// a division (10) -- so a sample costs one exp (the power (x/x0)^beta, x^beta or
+// x^-(alpha+2)), never a division, and the thick model's sample is C(y) b(x): two
+// look-ups and ONE multiplication (rounds 2-5: (y c(y)) ((x x) b(x)), four).  Both tables
+// are indexed by eight times their argument: X = (8 h/kT) nu costs what x did, and 8 y
+// comes out of the exp for free (m_exp_t's KADD).  For x > 48, beyond the table, 1 - e^-x
+// is 1 to the last bit and b(x) = x e^-x.
 // TAB = false (one-off evaluations): polynomial exp/expm1 and a true division, the
 // same formulas as the reference term by term; the parity tests hold the two against
 // each other on the passband grids.
 // SCALE = false: without the factor normfac -- the fused kernel applies it once per band
 // instead of once per sample (the Wien side is then kappa x^-alpha).
-// The two sides of a sample on their own, straight-line (no branch): the fused kernel
-// calls them for chunk pairs that lie wholly on one side of the merge point, so that
-// the compiler can interleave the two samples' chains and table reads.
-// Blackbody side, 0 < x <= 64, without the factor normfac.
-template <bool OPTHIN>
-__device__ __forceinline__ double fnu_bb_tab(const WalkerK &w, double x, double lx, const SampleTabs *tabs)
-{
-    const double bx = poly8_eval(tabs->b, x);
-    if (OPTHIN) {
-        return m_exp_t(w.bp2 * lx, tabs->e) * bx;                               // :24-25, :51
-    } else {
-        const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);  // :74, :105
-        return (y * poly8_eval(tabs->c, y)) * ((x * x) * bx);                   // :75-76, :106
-    }
-}
-
-// Wien side (x > xmerge), without the factor normfac: kappa x^-alpha    :48-49, :102-103
-__device__ __forceinline__ double fnu_wien_tab(const WalkerK &w, double lx, const SampleTabs *tabs)
-{
-    return w.kap * m_exp_t<true, false>(-w.alpha * lx, tabs->e);
-}
-
-// N samples of the blackbody side at once, their chains interleaved step by step: a
-// sample is one long dependent chain (power -> exp -> polynomial, ~30 fp64 operations
-// and two LDS look-ups deep), and a wave alone issues a dependent operation only every
-// ~9 cycles, so one sample at a time leaves the SIMD half idle unless five or more
-// waves share it (tools/probe_clock.py).  The compiler does not interleave such
-// chains by itself; the scheduling fences pin the order written here.  The values are
-// exactly those of fnu_bb_tab.
 #define MBB_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <bool OPTHIN, int N>
-__device__ __forceinline__ void fnu_bb_tab_n(const WalkerK &w, const double (&x)[N], const double (&lx)[N],
-                                             const SampleTabs *tabs, double (&f)[N])
+// Blackbody side, 0 < x <= 48 (X = 8x): f_nu / (normfac x^2).  The exponent of the power comes straight from
+// log(nu) by one fma with two constants of the walker -- log x itself is never formed.
+constexpr double kLn8 = 2.0794415416798357;
+template <bool OPTHIN>
+__device__ __forceinline__ double fnu_bb_tab(const WalkerK &w, double X, double lnnu, const SampleTabs *tabs)
 {
-    constexpr double kMagic8 = 844424930131968.0;          // 1.5 2^49: ulp 1/8 (poly8_eval)
-    constexpr double kMagicE = 6755399441055744.0;         // 1.5 2^52 (reduce_ln2_256)
-    double tb[N], arg[N], sh[N], r[N], q[N], bx[N], y[N];
-    const double *cb[N];
-    int n[N];
-    // b(x): interval and offset; the exponent of the power
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const double s8 = x[i] + kMagic8;
-        cb[i] = tabs->b + 8 * __double2loint(s8);
-        tb[i] = x[i] - (s8 - kMagic8);
-        if (OPTHIN) arg[i] = fmin(fmax(w.bp2 * lx[i], -800.0), 800.0);
-        else arg[i] = fmax(fmin(w.beta * (lx[i] - w.lx0), kLn40), -800.0);
-    }
-    MBB_FENCE();
-    double c7[N], c6[N], c5[N], c4[N], c3[N], c2[N], c1[N], c0[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        c7[i] = cb[i][7]; c6[i] = cb[i][6]; c5[i] = cb[i][5]; c4[i] = cb[i][4];
-        c3[i] = cb[i][3]; c2[i] = cb[i][2]; c1[i] = cb[i][1]; c0[i] = cb[i][0];
-        sh[i] = fma(arg[i], 3.69329930467574627e+02, kMagicE);
-        n[i] = __double2loint(sh[i]);
-    }
-    MBB_FENCE();
-    Exp2Entry te[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        te[i] = tabs->e[n[i] & (kExp2N - 1)];
-        const double nd = sh[i] - kMagicE;
-        r[i] = fma(nd, -2.70760617406228627e-03, arg[i]);
-    }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = fma(sh[i] - kMagicE, -9.05877661658710765e-20, r[i]);
-    MBB_FENCE();
-    double r2[N], a0[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { r2[i] = r[i] * r[i]; a0[i] = fma(r[i], 1.0 / 6.0, 0.5); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { a0[i] = fma(r2[i], 1.0 / 24.0, a0[i]); bx[i] = fma(c7[i], tb[i], c6[i]); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { q[i] = fma(r2[i], a0[i], r[i]); bx[i] = fma(bx[i], tb[i], c5[i]); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { q[i] = fma(te[i].hi, q[i], te[i].lo); bx[i] = fma(bx[i], tb[i], c4[i]); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { q[i] = te[i].hi + q[i]; bx[i] = fma(bx[i], tb[i], c3[i]); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) { y[i] = ldexp(q[i], n[i] >> 8); bx[i] = fma(bx[i], tb[i], c2[i]); }
-    MBB_FENCE();
+    const double b = polyrow_eval(tabs->b, X);
     if (OPTHIN) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) bx[i] = fma(bx[i], tb[i], c1[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) bx[i] = fma(bx[i], tb[i], c0[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) f[i] = y[i] * bx[i];           // x^(beta+2) b(x)      :24-25, :51
+        return m_exp_t(fma(w.beta, lnnu, w.beta * w.lhokt9), tabs->e) * b;      // x^beta b(x)          :24-25, :51
     } else {
-        // c(y): interval and offset, its coefficients; the b chain goes on meanwhile
-        double tc[N];
-        const double *cc[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double s8 = y[i] + kMagic8;
-            cc[i] = tabs->c + 8 * __double2loint(s8);
-            tc[i] = y[i] - (s8 - kMagic8);
-            bx[i] = fma(bx[i], tb[i], c1[i]);
-        }
-        MBB_FENCE();
-        double d7[N], d6[N], d5[N], d4[N], d3[N], d2[N], d1[N], d0[N], cy[N], xx[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            d7[i] = cc[i][7]; d6[i] = cc[i][6]; d5[i] = cc[i][5]; d4[i] = cc[i][4];
-            d3[i] = cc[i][3]; d2[i] = cc[i][2]; d1[i] = cc[i][1]; d0[i] = cc[i][0];
-            bx[i] = fma(bx[i], tb[i], c0[i]);
-            xx[i] = x[i] * x[i];
-        }
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) { cy[i] = fma(d7[i], tc[i], d6[i]); xx[i] = xx[i] * bx[i]; }
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d5[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d4[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d3[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d2[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d1[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) cy[i] = fma(cy[i], tc[i], d0[i]);
-        MBB_FENCE();
-#pragma unroll
-        for (int i = 0; i < N; ++i) f[i] = (y[i] * cy[i]) * xx[i];    // (1 - e^-y) x^2 b(x)   :75-76, :106
+        // 8 y = 8 (x/x0)^beta = exp(beta (log x - log x0) + log 8), y held at kPolyCMax             :74, :105
+        const double Y = m_exp_t(fmin(fma(w.beta, lnnu, fma(w.beta, w.lhokt9 - w.lx0, kLn8)), kLnCMax + kLn8), tabs->e);
+        return polyrow_eval(tabs->c, Y) * b;                                    // (1 - e^-y) b(x)      :75-76, :106
     }
 }
 
-// N samples of the Wien side at once (see fnu_bb_tab_n); the values of fnu_wien_tab.
-template <int N>
-__device__ __forceinline__ void fnu_wien_tab_n(const WalkerK &w, const double (&lx)[N], const SampleTabs *tabs,
-                                               double (&f)[N])
+// Wien side (x > xmerge): x^-(alpha+2), and with kappa: f_nu / (normfac x^2) = kappa x^-alpha / x^2    :48-49, :102-103
+__device__ __forceinline__ double wien_pow_tab(const WalkerK &w, double lnnu, const SampleTabs *tabs)
 {
-    constexpr double kMagicE = 6755399441055744.0;
-    double arg[N], sh[N], r[N], q[N];
-    int n[N];
-    Exp2Entry te[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        arg[i] = fmax(-w.alpha * lx[i], -800.0);
-        sh[i] = fma(arg[i], 3.69329930467574627e+02, kMagicE);
-        n[i] = __double2loint(sh[i]);
-    }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        te[i] = tabs->e[n[i] & (kExp2N - 1)];
-        r[i] = fma(sh[i] - kMagicE, -2.70760617406228627e-03, arg[i]);
-    }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) r[i] = fma(sh[i] - kMagicE, -9.05877661658710765e-20, r[i]);
-    MBB_FENCE();
-    double r2[N], a0[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { r2[i] = r[i] * r[i]; a0[i] = fma(r[i], 1.0 / 6.0, 0.5); }
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) a0[i] = fma(r2[i], 1.0 / 24.0, a0[i]);
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = fma(r2[i], a0[i], r[i]);
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = fma(te[i].hi, q[i], te[i].lo);
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) q[i] = te[i].hi + q[i];
-    MBB_FENCE();
-#pragma unroll
-    for (int i = 0; i < N; ++i) f[i] = w.kap * ldexp(q[i], n[i] >> 8);
+    const double ma2 = -(w.alpha + 2.0);
+    return m_exp_t(fma(ma2, lnnu, ma2 * w.lhokt9), tabs->e);
+}
+__device__ __forceinline__ double fnu_wien_tab(const WalkerK &w, double lnnu, const SampleTabs *tabs)
+{
+    return w.kap * wien_pow_tab(w, lnnu, tabs);
 }
 
 template <bool OPTHIN, bool NOALPHA, bool TAB = false, bool SCALE = true>
 __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double lnnu,
                                              const SampleTabs *tabs = nullptr)
 {
-    const double x = w.hokt9 * nu;                                  // > 0
-    const double lx = w.lhokt9 + lnnu;
     auto scaled = [&](double v) { if constexpr (SCALE) return w.cbb * v; else return v; };
     if constexpr (TAB) {
-        // range clamps only where the argument can leave [-800, 800]
+        static_assert(!SCALE, "the table path yields f_nu / (normfac x^2): the band scale is WalkerK::cq");
+        // (8 h/kT) nu = 8 x, bit for bit (a power of two); the comparisons in those units
+        const double X = (8.0 * w.hokt9) * nu;                          // > 0
         if (!NOALPHA) {
-            if (x > w.xmerge) return (SCALE ? w.cbb : 1.0) * fnu_wien_tab(w, lx, tabs);
+            if (X > 8.0 * w.xmerge) return fnu_wien_tab(w, lnnu, tabs);
         }
-        if (x <= 64.0) return scaled(fnu_bb_tab<OPTHIN>(w, x, lx, tabs));
-        const double bx = x * m_exp_t<true, false>(-x, tabs->e);   // beyond the table: b(x) = x e^-x
+        if (X <= kXFar8) return fnu_bb_tab<OPTHIN>(w, X, lnnu, tabs);
+        const double x = 0.125 * X;
+        const double b = x * m_exp_t(-x, tabs->e);                      // beyond the table: b(x) = x e^-x
         if (OPTHIN) {
-            return scaled(m_exp_t(w.bp2 * lx, tabs->e) * bx);
+            return m_exp_t(fma(w.beta, lnnu, w.beta * w.lhokt9), tabs->e) * b;
         } else {
-            const double y = m_exp_t<true, false>(fmin(w.beta * (lx - w.lx0), kLn40), tabs->e);
-            return scaled((y * poly8_eval(tabs->c, y)) * ((x * x) * bx));
+            const double Y = m_exp_t(fmin(fma(w.beta, lnnu, fma(w.beta, w.lhokt9 - w.lx0, kLn8)), kLnCMax + kLn8), tabs->e);
+            return polyrow_eval(tabs->c, Y) * b;
         }
     } else {
+        const double x = w.hokt9 * nu;                                  // > 0
+        const double lx = w.lhokt9 + lnnu;
         if (!NOALPHA) {
             if (x > w.xmerge) return (SCALE ? w.cpl : w.kap) * m_exp(-w.alpha * lx);
         }

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
 {
     CLikeArgs *const ka = MBB_KERNARGS();
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_tab[kExp2N];
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     const int tid = threadIdx.x, lane = tid & 63, wave = MBB_WAVE_ID(tid);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
                 if (st == ROW_OK) {
                     double *mf = mflux + (size_t)j * nb;
                     const double *pj2 = partial + j * npart;
-                    const double cbb = wk[j].cbb;
+                    const double cbb = wk[j].cq;
                     auto band = [&](const int b) {
                         double sum = 0.0;
                         const int2 rng = s_band[b];
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(1024) k_flowa(const LikeArgs a_val)
             }
             if (ci == 0) FA_EV(j, 9);
             WalkerK k;
-            k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+            k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.cq = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
             k.status = ROW_SKIP;
             k.pad = 0;
             double pen_u = 0.0, pen_g = 0.0;

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
     static_assert(NP == 1, "one pair of walkers per workgroup (the two-pair shape is not built or tested any more)");
     CLikeArgs *const ka = MBB_KERNARGS();
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_tab[kExp2N];
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     const int tid = threadIdx.x, lane = tid & 63, wave = MBB_WAVE_ID(tid);
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             auto sums = [&]() {
                 lds_wait(ctl + kFmPen + b, it + 1);                    // (C posts the penalties behind the record)
                 st = wkb->status;
-                cbb = wkb->cbb; pen_u = pr[7]; pen_g = pr[8];
+                cbb = wkb->cq; pen_u = pr[7]; pen_g = pr[8];
 #pragma unroll
                 for (int i = 0; i < 5; ++i) { q[i] = pr[i]; old5[i] = pr[9 + i]; }
                 lnz4 = pr[5]; lnu = pr[6];
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
             double lo[4];
             vlog<true>(lo, p[0], p[2], zz, u3);
             WalkerK k;
-            k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+            k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.cq = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
             k.status = ROW_SKIP;
             k.pad = 0;
             double pen_u = 0.0, pen_g = 0.0;

@@ -96,8 +96,8 @@ static size_t flowm_lds_bytes(size_t nb, size_t npart, bool cov_in_lds, size_t n
 #include "mbb_host_tables.h"
 #include "mbb_registry.h"
 
-static_assert(kPolyBDoubles == mbbh::kPolyBCount * (mbbh::kPolyDeg + 1), "poly table size");
-static_assert(kPolyCDoubles == mbbh::kPolyCCount * (mbbh::kPolyDeg + 1), "poly table size");
+static_assert(kPolyBDoubles == mbbh::kPolyBCount * mbbh::kPolyStride && mbbh::kPolyStride == mbbm::kPolyStride, "poly table size");
+static_assert(kPolyCDoubles == mbbh::kPolyCCount * mbbh::kPolyStride, "poly table size");
 static_assert(sizeof(mbbh::Unit) == sizeof(int4) && sizeof(mbbh::SlotRange) == sizeof(int2), "layout");
 
 
@@ -711,7 +711,7 @@ static int ensure_capacity(mbb_ctx *c, size_t n, bool want_flux)
 // (mbb_kernels.hip.h); the rest of the CU's 160 KB is what a launch may ask for dynamically.
 static size_t static_lds(const mbb_ctx *c)
 {
-    return sizeof(Exp2Entry) * kExp2N + sizeof(double) * kPolyBDoubles +
+    return sizeof(double) * kExp2N + sizeof(double) * kPolyBDoubles +
            sizeof(double) * (c->opthin ? 2 : kPolyCDoubles);
 }
 static size_t dynamic_lds_limit(const mbb_ctx *c) { return 160 * 1024 - static_lds(c) - 2048; }

@@ -24,7 +24,9 @@ int build_band_layout(const double *freq, const double *weight, const int32_t *o
     }
     L = BandLayout();
     std::vector<double> &nu = L.nu, &lnnu = L.lnnu, &wt = L.wt;
-    auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i]); };
+    // the weight goes in times nu^2: the sample loop sums f_nu / x^2 (x = h nu / kT: the factor x^2 of the Planck term is
+    // nu^2 times a constant of the walker, applied once per band with normfac) -- two multiplications per sample saved
+    auto push = [&](int i) { nu.push_back(freq[i]); lnnu.push_back(log(freq[i])); wt.push_back(weight[i] * (freq[i] * freq[i])); };
     auto pad = [&]() { nu.push_back(1.0); lnnu.push_back(0.0); wt.push_back(0.0); };
     // A band with a passband is cut into chunks of 64 samples; segments of <= segc chunks
     // are one unit of work and one result slot each.  What is left over at the end of a
@@ -167,59 +169,89 @@ namespace {
 
 typedef long double ld;
 
-ld b_fun(ld x)        // x / expm1(x), b(0) = 1
+ld b_fun(ld x)        // x / expm1(x), 1 at 0
 {
     if (fabsl(x) < 1e-6L) return 1.0L - x / 2 + x * x / 12;       // next term x^4/720
     return x / expm1l(x);
 }
 
-ld c_fun(ld y)        // (1 - exp(-y)) / y, c(0) = 1
+ld c_over_y(ld y)     // C(y) / y = (1 - exp(-y)) / y, 1 at 0
 {
     if (fabsl(y) < 1e-6L) return 1.0L - y / 2 + y * y / 6;        // next term y^3/24
     return -expm1l(-y) / y;
 }
 
-void fit_table(ld (*f)(ld), int count, std::vector<double> &out)
+ld C_fun(ld y) { return -expm1l(-y); }                            // 1 - exp(-y)
+
+// Coefficients, lowest order first, of the polynomial of degree n - 1 in t (0 <= t <= 1) that
+// interpolates g(t) at the n Chebyshev nodes of [0, 1].  Solved in s = 2 t - 1, where the
+// Vandermonde matrix of the nodes is benign (Gauss-Jordan with partial pivoting in long
+// double), then expanded in t by the binomial theorem.
+template <typename G>
+void cheb_fit(G g, int n, ld *out)
 {
-    constexpr int N = kPolyDeg + 1;
-    const ld h = 0.125L, hh = h / 2;
-    // Chebyshev nodes on [-1, 1] and the inverse of their Vandermonde matrix (Gauss-Jordan
-    // with partial pivoting in long double; 8 x 8, condition ~ 1e3)
-    ld s[N], V[N][2 * N];
+    constexpr int NMAX = kPolyDeg + 1;
+    ld s[NMAX], V[NMAX][2 * NMAX], a[NMAX];
     const ld pi = acosl(-1.0L);
-    for (int k = 0; k < N; ++k) s[k] = cosl((2 * k + 1) * pi / (2 * N));
-    for (int r = 0; r < N; ++r) {
+    for (int k = 0; k < n; ++k) s[k] = cosl((2 * k + 1) * pi / (2 * n));
+    for (int r = 0; r < n; ++r) {
         ld p = 1.0L;
-        for (int c = 0; c < N; ++c) { V[r][c] = p; p *= s[r]; }
-        for (int c = 0; c < N; ++c) V[r][N + c] = (r == c) ? 1.0L : 0.0L;
+        for (int c = 0; c < n; ++c) { V[r][c] = p; p *= s[r]; }
+        for (int c = 0; c < n; ++c) V[r][n + c] = (r == c) ? 1.0L : 0.0L;
     }
-    for (int col = 0; col < N; ++col) {
+    for (int col = 0; col < n; ++col) {
         int piv = col;
-        for (int r = col + 1; r < N; ++r)
+        for (int r = col + 1; r < n; ++r)
             if (fabsl(V[r][col]) > fabsl(V[piv][col])) piv = r;
         if (piv != col)
-            for (int c = 0; c < 2 * N; ++c) std::swap(V[piv][c], V[col][c]);
+            for (int c = 0; c < 2 * n; ++c) std::swap(V[piv][c], V[col][c]);
         const ld d = V[col][col];
-        for (int c = 0; c < 2 * N; ++c) V[col][c] /= d;
-        for (int r = 0; r < N; ++r) {
+        for (int c = 0; c < 2 * n; ++c) V[col][c] /= d;
+        for (int r = 0; r < n; ++r) {
             if (r == col) continue;
             const ld m = V[r][col];
             if (m != 0.0L)
-                for (int c = 0; c < 2 * N; ++c) V[r][c] -= m * V[col][c];
+                for (int c = 0; c < 2 * n; ++c) V[r][c] -= m * V[col][c];
         }
     }
-    out.assign((size_t)count * N, 0.0);
-    for (int i = 0; i < count; ++i) {
-        const ld xc = (ld)i * h;
-        ld val[N];
-        for (int k = 0; k < N; ++k) val[k] = f(xc + hh * s[k]);
-        ld scale = 1.0L;
-        for (int k = 0; k < N; ++k) {                 // coefficient of (t / hh)^k, rescaled to t^k
-            ld a = 0.0L;
-            for (int j = 0; j < N; ++j) a += V[k][N + j] * val[j];
-            out[(size_t)i * N + k] = (double)(a / scale);
-            scale *= hh;
+    ld val[NMAX];
+    for (int k = 0; k < n; ++k) val[k] = g((1.0L + s[k]) / 2);
+    for (int k = 0; k < n; ++k) {                     // coefficient of s^k
+        a[k] = 0.0L;
+        for (int j = 0; j < n; ++j) a[k] += V[k][n + j] * val[j];
+    }
+    // sum_k a_k (2 t - 1)^k = sum_j t^j 2^j sum_{k >= j} a_k C(k, j) (-1)^(k - j)
+    for (int j = 0; j < n; ++j) {
+        ld cj = 0.0L;
+        for (int k = j; k < n; ++k) {
+            ld binom = 1.0L;
+            for (int m = 0; m < j; ++m) binom = binom * (ld)(k - m) / (ld)(m + 1);
+            cj += a[k] * binom * (((k - j) & 1) ? -1.0L : 1.0L);
         }
+        out[j] = ldexpl(cj, j);
+    }
+}
+
+// `zero_order`: the order of the function's zero at the origin (row 0 is t^zero_order times the interpolant of
+// `over`, the function divided by that power of its argument)
+void fit_table(ld (*f)(ld), ld (*over)(ld), int zero_order, int count, std::vector<double> &out)
+{
+    constexpr int N = kPolyDeg + 1;
+    const ld h = 0.125L;
+    out.assign((size_t)count * kPolyStride, 0.0);
+    for (int i = 0; i < count; ++i) {
+        ld c[N] = {0};
+        if (i == 0) {
+            // f(h t) = (h t)^z over(h t): coefficients of t^z .. t^7 from the interpolant of h^z over(h t)
+            ld q[N];
+            const ld hz = powl(h, (ld)zero_order);
+            cheb_fit([&](ld t) { return hz * over(h * t); }, N - zero_order, q);
+            for (int k = zero_order; k < N; ++k) c[k] = q[k - zero_order];
+        } else {
+            const ld x0 = (ld)i * h;
+            cheb_fit([&](ld t) { return f(x0 + h * t); }, N, c);
+        }
+        for (int k = 0; k < N; ++k) out[(size_t)i * kPolyStride + k] = (double)c[k];
     }
 }
 
@@ -227,8 +259,8 @@ void fit_table(ld (*f)(ld), int count, std::vector<double> &out)
 
 void build_poly_tables(std::vector<double> &b, std::vector<double> &c)
 {
-    fit_table(b_fun, kPolyBCount, b);
-    fit_table(c_fun, kPolyCCount, c);
+    fit_table(b_fun, b_fun, 0, kPolyBCount, b);
+    fit_table(C_fun, c_over_y, 1, kPolyCCount, c);
 }
 
 }  // namespace mbbh
@@ -238,7 +270,7 @@ extern "C" int mbbh_poly_counts(int *nb_intervals, int *nc_intervals, int *ncoef
 {
     *nb_intervals = mbbh::kPolyBCount;
     *nc_intervals = mbbh::kPolyCCount;
-    *ncoef = mbbh::kPolyDeg + 1;
+    *ncoef = mbbh::kPolyStride;          // doubles per row: eight coefficients and the padding
     return 0;
 }
 

@@ -17,8 +17,8 @@
 
 using namespace mbbd;
 
-constexpr int kPolyBDoubles = (64 * 8 + 1) * 8;      // mbbh::kPolyBCount intervals x 8 coefficients
-constexpr int kPolyCDoubles = (40 * 8 + 1) * 8;      // mbbh::kPolyCCount
+constexpr int kPolyBDoubles = (mbbm::kPolyBMax * 8 + 1) * mbbm::kPolyStride;      // mbbh::kPolyBCount rows of kPolyStride doubles
+constexpr int kPolyCDoubles = (mbbm::kPolyCMax * 8 + 1) * mbbm::kPolyStride;      // mbbh::kPolyCCount
 
 // ---------------------------------------------------------------------------
 // kernel arguments
@@ -44,8 +44,8 @@ struct LikeArgs {
     const double *nu;         // [nchunk*64] GHz   (padding: 1.0)
     const double *lnnu;       // [nchunk*64] log(nu)  (padding: 0.0)
     const double *wt;         // [nchunk*64] sedmult*normfac (padding: 0.0)
-    const double *poly_b;     // [kPolyBCount*8] piecewise polynomials of x/expm1(x) (mbb_host_tables.h)
-    const double *poly_c;     // [kPolyCCount*8] ... of (1 - e^-y)/y
+    const double *poly_b;     // [kPolyBCount*kPolyStride] piecewise polynomials of x^3/expm1(x) (mbb_host_tables.h)
+    const double *poly_c;     // [kPolyCCount*kPolyStride] ... of 1 - e^-y
     const int4 *unit_tab;     // [nunit] {result slot, first chunk, end chunk, kind} in dealing order;
                               // kind 0: a segment, reduced to one slot; 1: a chunk of 64 single-sample
                               // bands, lane l's value goes to slot + l
@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
         else __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[kExp2N];                     // 2^(j/256) for the sample loop
-    __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x/expm1(x), piecewise degree 7
-    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];   // (1 - e^-y)/y (thick only)
+    __shared__ __align__(16) double s_tab[kExp2N];                     // 2^(j/256) for the sample loop
+    __shared__ __align__(16) double s_pb[kPolyBDoubles];    // x^3/expm1(x), piecewise degree 7
+    __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];   // 1 - e^-y (thick only)
     const int W = a.wpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwave = blockDim.x >> 6;
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                 double lo[4];
                 vlog<true>(lo, p[0], p[2], zz, u3);
                 WalkerK k;
-                k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+                k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.cq = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
                 k.status = ROW_SKIP;
                 k.pad = 0;
                 double pen_u = 0.0, pen_g = 0.0;
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                                                tag ^ (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
                         };
-                        put(0, k.hokt9); put(1, k.lhokt9); put(2, k.beta); put(3, k.bp3); put(4, k.bp2); put(5, k.alpha);
+                        put(0, k.hokt9); put(1, k.lhokt9); put(2, k.beta); put(3, k.bp3); put(4, k.cq); put(5, k.alpha);
                         put(6, k.lx0); put(7, k.xmerge); put(8, k.cbb); put(9, k.cpl); put(10, k.kap); put(11, k.peak);
                         put(12, __longlong_as_double((long long)(((unsigned long long)(unsigned int)k.pad << 32) | (unsigned int)k.status)));
 #pragma unroll
@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                 if (i0 < n2) { p00 = g0[i0]; p10 = g1[i0]; p20 = g2[i0]; }
                 if (i1 < n2) { p01 = g0[i1]; p11 = g1[i1]; p21 = g2[i1]; }
             }
-            if (i0 < kExp2N) ve = reinterpret_cast<const double2 *>(kExp2Tab)[i0];
+            if (i0 < kExp2N / 2) ve = reinterpret_cast<const double2 *>(kExp2Tab)[i0];
             if (i0 < nB) vb0 = gb[i0];
             if (i1 < nB) vb1 = gb[i1];
             if (i2 < nB) vb2 = gb[i2];
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                 if (i0 < n2) { l0[i0] = p00; l1[i0] = p10; l2[i0] = p20; }
                 if (i1 < n2) { l0[i1] = p01; l1[i1] = p11; l2[i1] = p21; }
             }
-            if (i0 < kExp2N) reinterpret_cast<double2 *>(s_tab)[i0] = ve;
+            if (i0 < kExp2N / 2) reinterpret_cast<double2 *>(s_tab)[i0] = ve;
             if (i0 < nB) lb[i0] = vb0;
             if (i1 < nB) lb[i1] = vb1;
             if (i2 < nB) lb[i2] = vb2;
@@ -696,7 +696,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
                 if (i1 < nC) lc[i1] = vc1;
             }
             if (t0 < nb) { s_flux[t0] = fiv.x; s_ivar[t0] = fiv.y; s_band[t0] = brv; }
-            for (int i = t0 + nt; i < kExp2N; i += nt) s_tab[i] = kExp2Tab[i];
+            for (int i = t0 + nt; i < kExp2N / 2; i += nt) reinterpret_cast<double2 *>(s_tab)[i] = reinterpret_cast<const double2 *>(kExp2Tab)[i];
             for (int i = t0 + 3 * nt; i < nB; i += nt) lb[i] = gb[i];
             for (int i = t0 + 2 * nt; i < nC; i += nt) lc[i] = gc[i];
             for (int i = t0 + 2 * nt; i < n2; i += nt) { l0[i] = g0[i]; l1[i] = g1[i]; l2[i] = g2[i]; }
@@ -970,9 +970,23 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
         double acc = 0.0;
         int c = c0;
         for (; c + 2 <= c1; c += 2) {          // two chunks per step
-            const int i0 = c * 64 + lane, i1 = i0 + 64;
-            const double n0 = T_nu(i0), l0 = T_ln(i0), q0 = T_wt(i0);
-            const double n1 = T_nu(i1), l1 = T_ln(i1), q1 = T_wt(i1);
+            double n0, l0, q0, n1, l1, q1;
+            if constexpr (STAGE) {
+                const int i0 = c * 64 + lane, i1 = i0 + 64;
+                n0 = s_nu[i0]; l0 = s_lnnu[i0]; q0 = s_wt[i0];
+                n1 = s_nu[i1]; l1 = s_lnnu[i1]; q1 = s_wt[i1];
+            } else {
+                // (the chunk is the wave's, uniform: a scalar base per table and the lane as a 32-bit offset -- indexed by
+                // chunk * 64 + lane the compiler formed three 64-bit addresses per chunk pair on the vector unit)
+                const int cu = __builtin_amdgcn_readfirstlane(c);
+                typedef const __attribute__((address_space(1))) double *gptr;       // (global memory, said so: the pin below hides where the pointers came from)
+                gptr pn = (gptr)(a.nu + (size_t)cu * 64), pl = (gptr)(a.lnnu + (size_t)cu * 64), pw = (gptr)(a.wt + (size_t)cu * 64);
+                // (pinned in scalar registers: left alone the compiler re-associates base + lane into a vector of its own
+                // per table and adds the chunk on the vector unit)
+                asm volatile("" : "+s"(pn), "+s"(pl), "+s"(pw));
+                n0 = pn[lane]; l0 = pl[lane]; q0 = pw[lane];
+                n1 = pn[lane + 64]; l1 = pl[lane + 64]; q1 = pw[lane + 64];
+            }
             const double f0 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
             const double f1 = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
             acc = fma(f0, q0, acc);
@@ -1058,7 +1072,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
     if (wave < W) {
         st_first = wk[wave].status;
         pad_first = wk[wave].pad;
-        cbb_first = wk[wave].cbb;
+        cbb_first = wk[wave].cq;
         pen_u_first = pen[2 * wave];
         pen_g_first = pen[2 * wave + 1];
         if (a.lnl) lnl_first = a.lnl + (w0 + wave);
@@ -1084,7 +1098,7 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
         if (st == ROW_OK) {
             double *mf = mflux + (size_t)j * nb;
             const double *pj = partial + j * npart;
-            const double cbb = FIRST ? cbb_first : wk[j].cbb;  // normfac: the samples were summed without it
+            const double cbb = FIRST ? cbb_first : wk[j].cq;   // normfac (h/kT)^2: the samples were summed without them
             auto band = [&](const int b, auto firstb_c) {      // band flux, fixed order
                 constexpr bool FB = decltype(firstb_c)::value;
                 double sum = 0.0;
@@ -1407,7 +1421,7 @@ __global__ void __launch_bounds__(1024) k_roof(const LikeArgs a, const WalkerK *
     // loop of workgroup 0: the clock the chip holds under this load (MI355X_MICROARCH.md,
     // "DVFS give-back" item 6); stored where nothing else reads it
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_tab[kExp2N];
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     const int tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
@@ -1429,15 +1443,17 @@ __global__ void __launch_bounds__(1024) k_roof(const LikeArgs a, const WalkerK *
             const int nx = (pr + 1 < npair) ? (pr + 1) * 128 + lane : lane;
             const double pn0 = a.nu[nx], pl0 = a.lnnu[nx], pq0 = a.wt[nx];
             const double pn1 = a.nu[nx + 64], pl1 = a.lnnu[nx + 64], pq1 = a.wt[nx + 64];
-            const double xs[2] = {k.hokt9 * n0, k.hokt9 * n1};
-            const double lxs[2] = {k.lhokt9 + l0, k.lhokt9 + l1};
-            const bool wien0 = !NOALPHA && xs[0] > k.xmerge, wien1 = !NOALPHA && xs[1] > k.xmerge;
-            const bool far = !(xs[0] <= 64.0) || !(xs[1] <= 64.0);
+            const double hk8 = 8.0 * k.hokt9;
+            const double Xs[2] = {hk8 * n0, hk8 * n1};
+            const bool wien0 = !NOALPHA && Xs[0] > 8.0 * k.xmerge, wien1 = !NOALPHA && Xs[1] > 8.0 * k.xmerge;
+            const bool far = !(Xs[0] <= kXFar8) || !(Xs[1] <= kXFar8);
             double fs[2];
             if (__builtin_amdgcn_ballot_w64(wien0 || wien1 || far) == 0) {
-                fnu_bb_tab_n<OPTHIN, 2>(k, xs, lxs, &tabs, fs);
+                fs[0] = fnu_bb_tab<OPTHIN>(k, Xs[0], l0, &tabs);
+                fs[1] = fnu_bb_tab<OPTHIN>(k, Xs[1], l1, &tabs);
             } else if (!NOALPHA && __builtin_amdgcn_ballot_w64(!(wien0 && wien1)) == 0) {
-                fnu_wien_tab_n<2>(k, lxs, &tabs, fs);
+                fs[0] = fnu_wien_tab(k, l0, &tabs);
+                fs[1] = fnu_wien_tab(k, l1, &tabs);
             } else {
                 fs[0] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n0, l0, &tabs);
                 fs[1] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, n1, l1, &tabs);
@@ -1471,7 +1487,7 @@ __global__ void __launch_bounds__(256) k_walker_pre(const LikeArgs a)
     for (int i = 0; i < 5; ++i) p[i] = a.pars[(size_t)w * 5 + i];
     const double lT = m_log(p[0]), lL = OPTHIN ? 0.0 : m_log(p[2]);      // vlog<true> of k_lnlike's phase 1: the same m_log
     WalkerK k;
-    k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.bp2 = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
+    k.hokt9 = k.lhokt9 = k.beta = k.bp3 = k.cq = k.alpha = k.lx0 = k.xmerge = k.cbb = k.cpl = k.kap = k.peak = 0.0;
     k.status = ROW_SKIP;
     k.pad = 0;
     double pen_u = 0.0, pen_g = 0.0;

@@ -72,37 +72,36 @@ MBB_HD double m_expm1(double x)
 }
 
 // ---- table-driven variants for the sample loop --------------------------------
-// x = (256 k + j) ln2/256 + r, |r| <= ln2/512:  e^x = 2^k 2^(j/256) e^r with
-// 2^(j/256) from a 256-entry hi/lo table (4 KB, held in LDS by the kernels;
-// tools/gen_exp2_table.py) and a degree-4 polynomial for e^r - 1 (truncation
-// r^5/120 <= 3.8e-17): 4 polynomial operations instead of 15.
-struct Exp2Entry { double hi, lo; };
+// x = (256 k + j) ln2/256 + r, |r| <= ln2/512:  e^x = 2^k 2^(j/256) e^r with 2^(j/256)
+// from a 256-entry table of doubles (2 KB, held in LDS by the kernels; the `hi` words of
+// tools/gen_exp2_table.py's table: 2^(j/256) rounded to nearest) and a degree-4
+// polynomial for e^r - 1 (truncation r^5/120 <= 3.8e-17): 4 polynomial operations
+// instead of 15, one fma for the table value.  (Rounds 2-5 carried a hi/lo pair per
+// entry and one more operation per exp: 0.6 ulp instead of 1.1 here, which nothing
+// downstream sees -- the stated tolerance is 1e-12 -- at 8 more bytes of LDS per sample.)
 constexpr int kExp2N = 256;
 #ifdef MBB_MATH_HOST
-static const Exp2Entry kExp2Tab[kExp2N] = {
+static const double kExp2Tab[kExp2N] = {
 #else
-__device__ const Exp2Entry kExp2Tab[kExp2N] = {
+__device__ __align__(16) const double kExp2Tab[kExp2N] = {
 #endif
 #include "mbb_exp2_tab.inc"
 };
 
-// LO / HI: clamp x to [-800, 800] on that side; a caller that knows its argument's
-// range leaves the clamp out
-template <bool LO = true, bool HI = true>
+// n = round(x 256/ln2) as an integer, r = x - n ln2/256.  The integer comes out of a
+// SATURATING conversion (v_cvt_i32_f64), so an argument far outside exp's range needs no
+// clamp: n pins at INT_MIN / INT_MAX, ldexp by n >> 8 = -+8388608 gives 0 / inf, and r --
+// formed from the unsaturated double -- stays small.  (Rounds 2-5 rounded by adding
+// 1.5 2^52 and read the integer off the mantissa: two operations instead of three, but
+// wrong beyond |x| = 5.8e6, hence a v_max and a v_min in front of every exp.)
 MBB_HD double reduce_ln2_256(double x, int &n)
 {
-    if (LO) x = fmax(x, -800.0);
-    if (HI) x = fmin(x, 800.0);
-    // round(x 256/ln2) by adding 1.5 2^52: the integer lands in the low mantissa
-    // bits (read as an int) and the subtraction gives it back as a double -- one
-    // add instead of a round and a convert
-    const double shifted = fma(x, 3.69329930467574627e+02, 6755399441055744.0);
+    const double nd = rint(x * 3.69329930467574627e+02);      // 256 / ln2
+    n = (int)nd;
 #ifdef MBB_MATH_HOST
-    union { double d; int64_t i; } u; u.d = shifted; n = (int)(u.i & 0xffffffff);
-#else
-    n = __double2loint(shifted);
+    if (nd >= 2147483647.0) n = 2147483647;                    // (what the device's conversion does by itself)
+    if (nd <= -2147483648.0) n = -2147483647 - 1;
 #endif
-    const double nd = shifted - 6755399441055744.0;
     double r = fma(nd, -2.70760617406228627e-03, x);           // ln2/256 hi
     r = fma(nd, -9.05877661658710765e-20, r);                  // ln2/256 lo
     return r;
@@ -115,41 +114,43 @@ MBB_HD double expm1_small(double r)        // |r| <= ln2/512: r + r^2/2 + r^3/6 
     return fma(r2, fma(r2, 1.0 / 24.0, a0), r);
 }
 
-template <bool LO = true, bool HI = true>
-MBB_HD double m_exp_t(double x, const Exp2Entry *tab)
+// e^x for any finite x (0 below the range, inf above); tab[j] = 2^(j/256)
+MBB_HD double m_exp_t(double x, const double *tab)
 {
     int n;
-    const double q = expm1_small(reduce_ln2_256<LO, HI>(x, n));
-    const Exp2Entry t = tab[n & (kExp2N - 1)];
-    return ldexp(t.hi + fma(t.hi, q, t.lo), n >> 8);
+    const double q = expm1_small(reduce_ln2_256(x, n));
+    const double t = tab[n & (kExp2N - 1)];
+    return ldexp(fma(t, q, t), n >> 8);
 }
 
-template <bool LO = true, bool HI = true>
-MBB_HD double m_expm1_t(double x, const Exp2Entry *tab)
+// Piecewise degree-7 polynomials (mbb_host_tables.h) of a function of x >= 0 on intervals
+// [i/8, (i+1)/8): row i holds eight coefficients, lowest order first, in t = 8x - i, and
+// starts kPolyStride doubles after row i - 1.  The caller hands over X = 8x: the row is its
+// integer part (v_cvt_i32_f64) and t its fraction (v_fract_f64) -- two operations where
+// rounds 2-5 spent three adds on an interval centred on i/8.  Then Horner: 7 fma.
+// kPolyStride = 10: rows of 64 bytes sit on four bank positions of the LDS (a 16-byte read
+// covers 4 of 64 banks, row i starts at bank 16 i mod 64) and lanes whose samples fall into
+// rows i and i + 4 collide -- 22 % of round 5's LDS cycles; 80-byte rows start at bank
+// 20 i mod 64, sixteen different 4-bank positions before they repeat.
+constexpr int kPolyStride = 10;
+// how far the two tables go (mbb_host_tables.h): b(x) on [0, kPolyBMax], beyond which b(x) = x e^-x to the last bit;
+// C(y) on [0, kPolyCMax], beyond which 1 - e^-y is 1 (e^-37 < 2^-53)
+constexpr int kPolyBMax = 48, kPolyCMax = 37;
+MBB_HD double polyrow_eval(const double *tab, double X)
 {
-    int n;
-    const double q = expm1_small(reduce_ln2_256<LO, HI>(x, n));
-    const Exp2Entry t = tab[n & (kExp2N - 1)];
-    const double p = ldexp(1.0, n >> 8);           // inf for k >= 1024, as wanted
-    const double S = t.hi * p;
-    return (S - 1.0) + fma(S, q, t.lo * p);
-}
-
-// Piecewise degree-7 polynomial (mbb_host_tables.h): intervals of width 1/8 centred on
-// i/8, eight coefficients each, lowest order first.  0 <= x <= (number of intervals - 1)/8.
-// Adding 1.5 2^49, whose ulp is 1/8, rounds x to the nearest i/8: i is in the low
-// mantissa bits, subtracting gives i/8 back and t = x - i/8 is exact -- three adds,
-// no multiplications.  Then Horner: 7 fma.
-MBB_HD double poly8_eval(const double *tab, double x)
-{
-    const double shifted = x + 844424930131968.0;
 #ifdef MBB_MATH_HOST
-    union { double d; int64_t i; } u; u.d = shifted; const int i = (int)(u.i & 0xffffffff);
+    const int i = (int)X;
+    const double t = X - floor(X);
 #else
-    const int i = __double2loint(shifted);
+    const int i = (int)X;
+    const double t = __builtin_amdgcn_fract(X);
 #endif
-    const double t = x - (shifted - 844424930131968.0);
-    const double *c = tab + 8 * i;
+#ifdef MBB_MATH_HOST
+    const double *c = tab + kPolyStride * i;
+#else
+    // (v_mul_u32_u24: the row times its stride at full rate -- a plain 32-bit multiply is a quarter-rate instruction)
+    const double *c = reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + __mul24(i, kPolyStride * 8));
+#endif
     double p = fma(c[7], t, c[6]);
     p = fma(p, t, c[5]);
     p = fma(p, t, c[4]);

@@ -48,7 +48,7 @@ template <bool OPTHIN, bool NOALPHA, bool STAGE, bool OVL>
 __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ Exp2Entry s_tab[kExp2N];
+    __shared__ __align__(16) double s_tab[kExp2N];
     __shared__ __align__(16) double s_pb[kPolyBDoubles];
     __shared__ __align__(16) double s_pc[OPTHIN ? 2 : kPolyCDoubles];
     __shared__ unsigned long long s_req[2];
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                     WalkerK k0;
                     k0.hokt9 = m_div(1e9 * kH / kK, p[0]);
                     k0.lhokt9 = kLog1e9HoK - lT;
-                    k0.beta = p[1]; k0.bp3 = p[1] + 3.0; k0.bp2 = p[1] + 2.0;
+                    k0.beta = p[1]; k0.bp3 = p[1] + 3.0; k0.cq = 0.0;
                     k0.alpha = NOALPHA ? 0.0 : p[3];
                     k0.lx0 = OPTHIN ? 0.0 : k0.lhokt9 + kLogUmToGHz - lL;
                     k0.xmerge = __builtin_inf();
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                             if (NOALPHA || !(x > xhi)) rg_f[j] = fnu_sample<OPTHIN, NOALPHA, true, false>(k, nu, ln, &tabs);
                             if constexpr (!NOALPHA) {
                                 rg_w[j] = 0.0;
-                                if (x > xlo) rg_w[j] = m_exp_t<true, false>(-k.alpha * (k.lhokt9 + ln), tabs.e);
+                                if (x > xlo) rg_w[j] = wien_pow_tab(k, ln, &tabs);
                             }
                         }
                     }
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
                 const int st = kfin.status;
                 double acc = 0.0;
                 if (st == ROW_OK) {
-                    const double cbb = kfin.cbb;
+                    const double cbb = kfin.cq;
                     auto band = [&](const int b) {
                         double sum = 0.0;
                         const int2 rng = s_band[b];

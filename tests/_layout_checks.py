@@ -60,11 +60,12 @@ def check(L):
     assert not np.isnan(nu).any() and not np.isnan(wt).any() and not np.isnan(lnnu).any()
     pad = (nu == 1.0) & (wt == 0.0) & (lnnu == 0.0)
     real = ~pad
-    # every sample exactly once, with its own weight, and log(nu) beside it
+    # every sample exactly once, with its own weight TIMES nu^2 (the quadrature sums f/x^2: mbb_host_tables.h), and
+    # log(nu) beside it
     assert real.sum() == L["nq"]
     order = np.argsort(nu[real])
     assert np.array_equal(nu[real][order], np.sort(L["freq"]))
-    assert np.array_equal(wt[real][order], L["weight"][np.argsort(L["freq"])])
+    assert np.array_equal(wt[real][order], (L["weight"] * L["freq"] ** 2)[np.argsort(L["freq"])])
     assert np.array_equal(lnnu[real], np.log(nu[real]))
     # the units tile the chunks
     ut = L["unit_tab"]
@@ -101,7 +102,7 @@ def check(L):
         assert 0 <= s0 < s1 <= npart
         seen[s0:s1] += 1
         lo, hi = L["offsets"][b], L["offsets"][b + 1]
-        assert part[s0:s1].sum() == np.sum(L["weight"][lo:hi] * L["freq"][lo:hi]), b
+        assert part[s0:s1].sum() == np.sum(L["weight"][lo:hi] * L["freq"][lo:hi] ** 3), b
     S = int(seen.sum())
     assert np.all(seen[:S] == 1) and np.all(seen[S:] == 0) and npart - S < 64
     return True

@@ -6,9 +6,7 @@ N = 256
 lines = []
 for j in range(N):
     t = mp.power(2, mp.mpf(j)/N)
-    hi = float(t)
-    lo = float(t - mp.mpf(hi))
-    lines.append("    {%s, %s}," % (float(hi).hex(), float(lo).hex()))
+    lines.append("    %s," % float(t).hex())        # 2^(j/256) rounded to nearest (rounds 2-5: a hi/lo pair)
 open("exp2_256.inc", "w").write("\n".join(lines) + "\n")
 print(lines[0]); print(lines[1]); print(lines[255])
 c = mp.log(2)/N
