@@ -552,38 +552,46 @@ __device__ __forceinline__ double fnu_sample(const WalkerK &w, double nu, double
     }
 }
 
-// wave64 sum through the DPP crossbar (no LDS traffic): butterflies inside each
-// row of 16 lanes, then row_bcast15 / row_bcast31 carry the row totals upward;
-// the grand total lands in lane 63 and is broadcast through an SGPR.
-// KEEP: lanes the row mask leaves out keep v (the butterflies, where every lane has a
-// partner) or get 0 (the masked carries).
-template <int CTRL, int ROW_MASK>
+// wave64 sum through the DPP crossbar (no LDS traffic): butterflies inside each row of 16 lanes, then row_bcast15 /
+// row_bcast31 carry the row totals upward; the grand total lands in lane 63.  The tree is the balanced one over the
+// lanes in their order -- ((l0 + l1) + (l2 + l3)) + ... per row, then (R3 + R2) + (R1 + R0) -- and every form of every
+// kernel sums a unit by it: that is what makes a walker's band fluxes the same bit for bit wherever they are formed.
+// A stage is two DPP moves and an add.  (Rounds 2-5 wrote the moves as update_dpp with the value itself as the
+// `old` operand -- a register the instruction overwrites, so the compiler copied it first: five instructions a stage,
+// 34 for a wave's sum where 20 do; a quarter of everything a 250 000-row launch executed was these reductions.)  The
+// carries go to every row: rows 0 and 2 then hold sums nobody reads, lane 63's is the tree's.
+template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    constexpr bool all = ROW_MASK == 0xf;
-    const int plo = __builtin_amdgcn_update_dpp(all ? lo : 0, lo, CTRL, ROW_MASK, 0xf, false);
-    const int phi = __builtin_amdgcn_update_dpp(all ? hi : 0, hi, CTRL, ROW_MASK, 0xf, false);
+    const int plo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    const int phi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return v + __hiloint2double(phi, plo);
 }
 
 __device__ __forceinline__ double row_sum(double v)    // every lane: the total of its row
 {
-    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
-    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
-    v = dpp_add<0x140, 0xf>(v);     // row_mirror
+    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);      // row_half_mirror
+    v = dpp_add<0x140>(v);      // row_mirror
     return v;
 }
 
-__device__ __forceinline__ double wave_sum(double v)
+__device__ __forceinline__ double wave_sum_l63(double v)     // the total in lane 63 (the other lanes: partial sums)
 {
     v = row_sum(v);
-    v = dpp_add<0x142, 0xa>(v);     // row_bcast15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);     // row_bcast31 into rows 2 and 3
+    v = dpp_add<0x142>(v);      // row_bcast15: rows 1 and 3 take R0 and R2 in
+    v = dpp_add<0x143>(v);      // row_bcast31: row 3 takes R1 + R0 in
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)         // uniform: the total in every lane
+{
+    v = wave_sum_l63(v);
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);    // uniform: the total in every lane
+    return __hiloint2double(hi, lo);
 }
 
 // The same total when only lanes 0..15 hold non-zero terms (the other rows would add

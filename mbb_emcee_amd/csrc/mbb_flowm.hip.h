@@ -328,8 +328,8 @@ __global__ void __launch_bounds__(1024) k_flowm(const LikeArgs a)
                         acc = fma(f, T_wt(i), acc);
                     }
                     if (us.w == 0) {
-                        acc = wave_sum(acc);
-                        if (lane == 0) part[s] = acc;
+                        acc = wave_sum_l63(acc);           // (the total is lane 63's)
+                        if (lane == 63) part[s] = acc;
                     } else if (us.w == 2) {
                         acc = row_sum(acc);
                         if ((lane & 15) == 0) {

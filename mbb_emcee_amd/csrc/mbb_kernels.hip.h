@@ -999,8 +999,8 @@ __global__ void __launch_bounds__(1024) k_lnlike(const LikeArgs a_val)
         }
         WSTAMPD(3, acc);
         if (us.w == 0) {
-            acc = wave_sum(acc);
-            if (lane == 0) partial[j * npart + s] = acc;
+            acc = wave_sum_l63(acc);           // (the total is lane 63's)
+            if (lane == 63) partial[j * npart + s] = acc;
         } else if (us.w == 2) {                               // four band leftovers, one per row
             acc = row_sum(acc);
             if ((lane & 15) == 0) {

@@ -219,8 +219,8 @@ __global__ void __launch_bounds__(1024) k_serve(const LikeArgs a)
             auto store_unit = [&](const int4 us, double acc) {
                 const int s = us.x;
                 if (us.w == 0) {
-                    acc = wave_sum(acc);
-                    if (lane == 0) partial[s] = acc;
+                    acc = wave_sum_l63(acc);           // (the total is lane 63's)
+                    if (lane == 63) partial[s] = acc;
                 } else if (us.w == 2) {
                     acc = row_sum(acc);
                     if ((lane & 15) == 0) {
