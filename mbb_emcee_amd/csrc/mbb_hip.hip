@@ -80,7 +80,6 @@ MBB_SERVE_EXT(true, false)
 MBB_SERVE_EXT(true, true)
 #undef MBB_SERVE_EXT
 constexpr unsigned long long kServeQuitHost = 0xffffull;
-constexpr int kXcds = 8;                      // MI355X: 8 XCDs of 32 CUs
 constexpr int kServePasses = 2;               // rows a workgroup of a resident server takes of one request, at most
 static size_t serve_lds_bytes(size_t nb, size_t npart, bool cov_in_lds)                  // = serve_lds() of mbb_serve.hip.h
 {
@@ -169,7 +168,7 @@ static int load_rccl()
 struct mbb_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    int cu_count = 256;
+    int cu_count = 256, xcds = 8;
     // model
     int opthin = 0, noalpha = 0;
     double wavenorm = 500.0;
@@ -344,7 +343,7 @@ extern "C" int mbb_device_count(void)
 
 struct DeviceStatics {
     bool ready = false;
-    int cu_count = 0;
+    int cu_count = 0, xcds = 8;
     double *d_poly_b = nullptr, *d_poly_c = nullptr;
     std::vector<hipStream_t> idle_streams;
     std::atomic<int> live{0};        // contexts of this process on the device
@@ -408,6 +407,9 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
             hipDeviceProp_t prop;
             HIPCHK(hipGetDeviceProperties(&prop, device));
             d.cu_count = prop.multiProcessorCount;
+            int xcc = 0;                  // (MI355X: 8 XCDs of 32 CUs; the share of a device is dealt in whole rows of them)
+            if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) (void)hipGetLastError();
+            d.xcds = xcc > 0 && d.cu_count % xcc == 0 ? xcc : 8;
             std::vector<double> pb, pc;
             mbbh::build_poly_tables(pb, pc);
             HIPCHK(hipMalloc((void **)&d.d_poly_b, pb.size() * sizeof(double)));
@@ -420,6 +422,7 @@ extern "C" int mbb_ctx_create(int device, mbb_ctx **out)
     mbb_ctx *c = new mbb_ctx();
     c->device = device;
     c->cu_count = g_dev[device].cu_count;
+    c->xcds = g_dev[device].xcds;
     c->d_poly_b = g_dev[device].d_poly_b;
     c->d_poly_c = g_dev[device].d_poly_c;
     // A stream costs ~5 ms to create (a hardware queue): the streams of contexts that have gone are kept, idle,
@@ -1233,9 +1236,9 @@ static int serve_grid(const mbb_ctx *c, int n, int share)
     return std::min(std::min(g, share), c->cu_count);
 }
 
-static int serve_start(mbb_ctx *c, int n, unsigned long long word, int grid)
+// (the launch itself; serve_start below claims the device around it)
+static int serve_launch(mbb_ctx *c, int n, unsigned long long word, int grid)
 {
-    if (grid <= 0 || n > kServePasses * grid) return 1;
     if (!c->w_door) {
         if (hipExtMallocWithFlags((void **)&c->w_door, 64, hipDeviceMallocFinegrained) != hipSuccess) {
             (void)hipGetLastError();
@@ -1311,11 +1314,29 @@ static int serve_start(mbb_ctx *c, int n, unsigned long long word, int grid)
     c->serving = true;
     c->srv_run = 0;
     { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); c->srv_t0_ns = ts.tv_sec * 1000000000L + ts.tv_nsec; }
-    {
+    return MBB_OK;                                 // (the device has had this context's name since the claim above)
+}
+
+// Starts a resident server for this context.  The device is CLAIMED before anything is launched: two contexts on two
+// threads that both found no server resident (yield_server) would otherwise both start one, the device would remember
+// the second, and nobody could find the first to tell it to leave.  Whoever comes second sends its rows by
+// a launch (1); its next call finds the first's server by name and tells it to go.
+static int serve_start(mbb_ctx *c, int n, unsigned long long word, int grid)
+{
+    if (grid <= 0 || n > kServePasses * grid) return 1;
+    const bool named = c->device >= 0 && c->device < 64;
+    if (named) {
         std::lock_guard<std::mutex> lk(g_dev_mutex);
-        g_dev[c->device].server = c;
+        mbb_ctx *&sv = g_dev[c->device].server;
+        if (sv && sv != c) return 1;
+        sv = c;
     }
-    return MBB_OK;
+    const int rc = serve_launch(c, n, word, grid);
+    if (rc != MBB_OK && named) {
+        std::lock_guard<std::mutex> lk(g_dev_mutex);
+        if (g_dev[c->device].server == c) g_dev[c->device].server = nullptr;
+    }
+    return rc;
 }
 
 // One request: MBB_OK when the results are in the pinned slots, 1 when the rows have to go by a launch after all,
@@ -1425,7 +1446,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
             // (the dispatcher deals a kernel's workgroups to the device's 8 XCDs in turn, and there they stay: what has to fit
             // is every process's ceil(workgroups / 8) into an XCD's CUs -- three servers of 85 are 33 on the first XCDs of 32,
             // one workgroup never starts and every request of its server times out)
-            share = kXcds * ((c->cu_count / kXcds) / (busy + 1));
+            share = c->xcds * ((c->cu_count / c->xcds) / (busy + 1));
             c->srv_busy = busy;
         }
         c->srv_want = std::max(c->srv_want, std::min((n + 7) & ~7, c->cu_count));

@@ -254,11 +254,15 @@ __device__ __forceinline__ double stretch_q(double cv, double sv, double zz)
 }
 
 // Philox draw of state row `row` at half-step (step, half): z of the stretch move, the
-// partner's index in the other half, the uniform of the accept test.
+// partner's index in the other half, the uniform of the accept test.  The key (`seed`) carries the step's number in
+// the sampler's LIFE, the counter the row and the half: what is drawn for a step does not depend on how a run was cut
+// into launches -- run_mcmc(p0, 64) twice and run_mcmc(p0, 128) make the same chain (rounds 1-5 also counted the
+// step's place in its launch, `step`: another grouping was another chain -- ADVICE r05).
 __device__ __forceinline__ void stretch_draw(int row, int step, int half, unsigned long long seed,
                                              double stretch_a, int c_count, double &zz, int &pj, double &u3)
 {
-    unsigned int c4[4] = {(unsigned int)row, (unsigned int)(2 * step + half), 0u, 0u};
+    (void)step;
+    unsigned int c4[4] = {(unsigned int)row, (unsigned int)half, 0u, 0u};
     philox4x32(c4, (unsigned int)seed, (unsigned int)(seed >> 32));
     const double u1 = fma((double)(c4[0] >> 5), 67108864.0, (double)(c4[1] >> 6)) * (1.0 / 9007199254740992.0);   // (exact)
     const double u2 = (double)c4[2] * (1.0 / 4294967296.0);

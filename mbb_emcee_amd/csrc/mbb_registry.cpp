@@ -114,7 +114,16 @@ bool attach()
         g.tried = true;
         const char *forced = getenv("MBB_REGISTRY_NAME");       // (tests: a table of their own)
         if (forced && forced[0] == '/') snprintf(g.name, sizeof g.name, "%s", forced);
-        else snprintf(g.name, sizeof g.name, "/mbb_hip_registry3_%u", (unsigned)getuid());
+        else {
+            // One table per user AND per PID namespace: whether a slot's owner is still there is asked of kill() and /proc,
+            // which answer for the asker's namespace only -- two containers that share /dev/shm would take each other's
+            // live processes for dead ones and claim their slots.  Processes of another namespace are simply
+            // not in this table: they are "processes the library cannot see" and get what those get (the CUs a server
+            // does not hold at once, all of them when its lease is up).
+            struct stat ns;
+            const unsigned long long ino = stat("/proc/self/ns/pid", &ns) == 0 ? (unsigned long long)ns.st_ino : 0ull;
+            snprintf(g.name, sizeof g.name, "/mbb_hip_registry3_%u_%llx", (unsigned)getuid(), ino);
+        }
         int fd = shm_open(g.name, O_RDWR | O_CREAT, 0600);
         if (fd < 0) return false;
         if (ftruncate(fd, (off_t)sizeof(Table)) != 0) { close(fd); return false; }

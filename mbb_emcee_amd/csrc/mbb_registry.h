@@ -8,7 +8,7 @@
 // wide as its process's calls have rows and no wider than the process's share of the device: the CUs divided by the
 // processes that are making boundary calls on it (registry_busy).
 //
-// How: a small table in POSIX shared memory (/dev/shm/mbb_hip_registry3_<uid>), one slot per process: its pid and
+// How: a small table in POSIX shared memory (/dev/shm/mbb_hip_registry3_<uid>_<pid namespace>), one slot per process: its pid and
 // the keys (PCI domain:bus:device -- not the HIP ordinal, which HIP_VISIBLE_DEVICES renumbers) of the devices it
 // holds contexts on; a generation word, bumped at every change, makes the per-call check one load of shared memory.
 // A slot whose process is gone (kill(pid, 0) == ESRCH, or the pid belongs to a process born at another time than the slot

@@ -178,15 +178,18 @@ class DeviceEnsembleSampler(object):
     def sample(self, p0, lnprob0=None, rstate0=None, iterations=1, storechain=True, chunk=64):
         """emcee's generator form (``for pos, lnprob, rstate in sampler.sample(p0, iterations=N)``): the ensemble after
         every step.  The steps are made ``chunk`` at a time in one launch on the device -- a launch has a fixed cost of
-        ~20 us beside ~6 us per step -- and handed out one by one: the chain is the one the same sequence of
-        run_mcmc(.., chunk) calls makes (with ``chunk`` >= ``iterations``: run_mcmc(p0, iterations)'s; the draws of a step are
-        keyed by the sampler's step count AND the step's place in its launch, so another grouping is another, equally valid,
-        chain).  Breaking out of the loop early leaves the sampler ahead of the step that was handed out last by at most
-        ``chunk`` - 1 steps."""
+        ~20 us beside ~6 us per step -- and handed out one by one.  The chain is run_mcmc(p0, iterations)'s whatever the
+        chunk: a step's draws are keyed by its number in the sampler's life, not by its place in a launch.  While step j is
+        out, ``chain``, ``lnprobability``, ``iterations`` and ``naccepted`` are those of the steps handed out so far -- as
+        with emcee, where a step exists only once it has been yielded -- although the device is up to ``chunk`` - 1 steps
+        ahead; breaking out of the loop early leaves the sampler at the end of the chunk it was in (``run_mcmc(None, n)``
+        goes on from there, and the attributes then show that whole chunk).  ``rstate0`` is accepted for emcee's call
+        convention and ignored: the random stream is the sampler's ``seed`` (Philox, counted by step and row)."""
         iterations, chunk = int(iterations), max(1, int(chunk))
         ax = 1 if self.nsources == 1 else 2
         kept_c, kept_l = self._chain, self._lnprob
         n_prev = kept_c.shape[ax]
+        it_prev = self.iterations
         if storechain:
             # (room for the whole run once, filled chunk by chunk: no chain is copied more than that)
             big_c = np.empty(kept_c.shape[:ax] + (n_prev + iterations, self.dim))
@@ -194,27 +197,42 @@ class DeviceEnsembleSampler(object):
             big_c[..., :n_prev, :] = kept_c
             big_l[..., :n_prev] = kept_l
         pos0, l0 = p0, lnprob0
-        done = 0
+        done = made = 0                       # steps handed out / made on the device by this call
+        acc_made = self.naccepted
+        cur = None if p0 is None else np.asarray(p0, dtype=np.float64)
+        if cur is None and self._last is not None:
+            cur = self._last[0]
         try:
             while done < iterations:
                 k = min(chunk, iterations - done)
+                acc_before = np.array(self.naccepted, dtype=np.float64, copy=True)
                 self._chain, self._lnprob = kept_c[..., :0, :], kept_l[..., :0]
                 self.run_mcmc(pos0, k, lnprob0=l0, storechain=True)
                 steps, lnps = self._chain, self._lnprob          # (this chunk's own arrays)
+                made, acc_made = made + k, self.naccepted
                 pos0 = l0 = None
                 if storechain:
                     big_c[..., n_prev + done:n_prev + done + k, :] = steps
                     big_l[..., n_prev + done:n_prev + done + k] = lnps
-                done += k
+                # a walker's accepted moves step by step: a stretch move that is accepted changes the walker's position
+                prev = np.concatenate((cur[..., None, :], steps[..., :-1, :]), axis=ax)
+                moved = np.cumsum(np.any(steps != prev, axis=-1), axis=-1)
+                cur = steps[..., k - 1, :]
                 for j in range(k):
+                    done += 1
                     if storechain:
                         self._chain, self._lnprob = big_c[..., :n_prev + done, :], big_l[..., :n_prev + done]
                     else:
                         self._chain, self._lnprob = kept_c, kept_l
+                    self.iterations = it_prev + done
+                    self.naccepted = acc_made if j == k - 1 else acc_before + moved[..., j]
                     yield steps[..., j, :], lnps[..., j], self.seed
         finally:
+            # (left early, inside a chunk: the device made the whole chunk and run_mcmc(None, n) goes on from its end --
+            # the attributes then show all of it)
+            self.iterations, self.naccepted = it_prev + made, acc_made
             if storechain:
-                self._chain, self._lnprob = big_c[..., :n_prev + done, :], big_l[..., :n_prev + done]
+                self._chain, self._lnprob = big_c[..., :n_prev + made, :], big_l[..., :n_prev + made]
             else:
                 self._chain, self._lnprob = kept_c, kept_l
 

@@ -523,7 +523,7 @@ def _host_stretch_step(like, pos, lnp, seed, steps_done, t, a=2.0):
         q = np.empty((half, 5)); lz = np.empty(half); lu = np.empty(half)
         for w in range(half):
             row = s_begin + w
-            r = _philox4x32([row, 2 * t + h, 0, 0], key & 0xFFFFFFFF, key >> 32)
+            r = _philox4x32([row, h, 0, 0], key & 0xFFFFFFFF, key >> 32)      # (the key carries the step's number)
             u1 = ((r[0] >> 5) * 67108864.0 + (r[1] >> 6)) / 9007199254740992.0
             u2 = r[2] / 4294967296.0
             u3 = (r[3] + 0.5) / 4294967296.0
@@ -608,30 +608,37 @@ def test_device_sampler_statistics_match_host_sampler(mbb):
 def test_device_sampler_generator_form_equals_run_mcmc(mbb, g_lnl):
     """emcee's generator form, ``for pos, lnprob, rstate in sampler.sample(p0, iterations=N)`` (the host sampler has it:
     ensemble.py), on the device sampler: the steps are made a chunk at a time in one launch and handed out one by one.  The
-    chain is the one the same sequence of run_mcmc calls makes, bit for bit -- with a chunk of the whole run, run_mcmc's own --
-    stored or not, continued by run_mcmc, broken out of early; and whatever the chunk it samples the same posterior."""
+    chain is run_mcmc(p0, N)'s bit for bit WHATEVER the chunk (round 6: a step's draws are keyed by its number in the
+    sampler's life, not by its place in a launch) -- stored or not, continued by run_mcmc, broken out of early; and while
+    a step is out, chain / lnprobability / iterations / naccepted are those of the steps handed out so far."""
     like = _cfg2_like(mbb, g_lnl)
     rng = np.random.RandomState(8)
     p0 = np.array([12.0, 1.8, 600.0, 3.0, 40.0]) * (1.0 + 0.02 * rng.normal(size=(64, 5)))
+    whole = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
+    whole.run_mcmc(p0, 100)
+    whole.run_mcmc(None, 50)
+    acc_by_step = np.cumsum(np.any(np.diff(np.concatenate((p0[:, None, :], whole.chain), axis=1), axis=1) != 0, axis=-1), axis=1)
     for chunk in (1, 7, 64, 1000):
         ref = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
         pos, left = p0, 100
         while left > 0:                                              # the same steps by run_mcmc, chunk by chunk
             ref.run_mcmc(pos, min(chunk, left)); pos = None; left -= min(chunk, left)
         ref.run_mcmc(None, 50)
+        # (a step's draws are keyed by its number in the sampler's life: the grouping into launches does not show)
+        assert np.array_equal(ref.chain, whole.chain) and np.array_equal(ref.naccepted, whole.naccepted), chunk
         s = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
         seen = 0
-        for pos, lnp, _ in s.sample(p0, iterations=100, chunk=chunk):
+        for pos, lnp, _ in s.sample(p0, iterations=100, chunk=chunk, rstate0=np.random.RandomState(1)):
             assert np.array_equal(pos, ref.chain[:, seen, :]) and np.array_equal(lnp, ref.lnprobability[:, seen]), (chunk, seen)
             seen += 1
-            assert s.chain.shape[1] >= seen                           # (what has been handed out is in the chain)
+            # while a step is out, the sampler shows the steps handed out so far and nothing of those the device has
+            # made ahead of them
+            assert s.chain.shape == (64, seen, 5) and s.lnprobability.shape == (64, seen) and s.iterations == seen
+            assert np.array_equal(s.chain[:, -1], pos) and np.array_equal(s.naccepted, acc_by_step[:, seen - 1]), (chunk, seen)
         assert seen == 100 and s.chain.shape == (64, 100, 5) and s.iterations == 100
         s.run_mcmc(None, 50)                                          # ... and goes on as run_mcmc does
         assert np.array_equal(s.chain, ref.chain) and np.array_equal(s.lnprobability, ref.lnprobability), chunk
         assert np.array_equal(s.naccepted, ref.naccepted)
-    whole = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
-    whole.run_mcmc(p0, 100)
-    assert np.array_equal(s.chain[:, :100], whole.chain)              # (the last chunk above was the whole run)
     # nothing stored: the same ensembles, the chain untouched
     ref = mbb.DeviceEnsembleSampler(64, 5, like, seed=21)
     ref.run_mcmc(p0, 16); ref.run_mcmc(None, 16); ref.run_mcmc(None, 8)
