@@ -672,7 +672,7 @@ def short_line(full):
     if "parity_max_err_vs_oracle" in full:
         out["parity_max_err_vs_oracle"] = _num(full["parity_max_err_vs_oracle"], 3)
     if isinstance(full.get("cfg5"), dict):          # BASELINE.json configs[4] asks for its roofline fraction
-        o = _pick(full["cfg5"], ("kernel_ms", "evals_per_s"))
+        o = _pick(full["cfg5"], ("kernel_ms", "evals_per_s", "algorithmic_frac"))
         if isinstance(full["cfg5"].get("roofline"), dict):
             o["counted_frac"] = _num(full["cfg5"]["roofline"].get("frac"))
         out["cfg5"] = o
@@ -1724,6 +1724,10 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
                 "sampler_ms_per_step": t5 * 1e3, "sampler_evals_per_s": n5 / t5,
                 "geometry": {"walkers_per_workgroup": c5.info("last_wpb"), "threads": c5.info("last_threads")},
                 "roofline": r5,
+                # SURVEY.md 8d (ii)'s algorithmic count, 90 flop per quadrature sample, against the fp64 vector peak: the
+                # fraction that can be compared across rounds (the COUNTED flops fall when the same integrals take fewer
+                # operations -- round 6: 3.28e10 -> 2.58e10 per launch -- so counted / time rewards executing more)
+                "algorithmic_frac": 90.0 * nq * n5 / (ms5 * 1e-3) / (FP64_VALU_PEAK_TFLOPS * 1e12),
                 "sample_arithmetic": {"peak": slots5 / sec5, "achieved": n5 * nchunk * 64.0 / (ms5 * 1e-3),
                                       "frac": n5 * nchunk * 64.0 / (ms5 * 1e-3) / (slots5 / sec5),
                                       "unit": "quadrature samples/s (lane slots)",
