@@ -280,7 +280,10 @@ int mbb_get_info(mbb_ctx *ctx, const char *name, long *value);
 /* ---- multi-GPU: one process per GPU, lnprob all-gather over RCCL -------- */
 /* Replaces: emcee's multiprocessing pool selected by threads= (mbb_fit.py:80-81).
  * id is an opaque 128-byte ncclUniqueId made on rank 0 and handed to the other
- * ranks by the launcher (any side channel). */
+ * ranks by the launcher (any side channel).  The collective library is librccl as the process
+ * finds it, or -- environment variable MBB_RCCL_LIB -- the one library named there and no other
+ * (a name that does not load is MBB_ERR_RCCL; the one-GPU tests name a stand-in that lets ranks
+ * share a device: tests/rccl_standin/). */
 int mbb_comm_unique_id(char id[128]);
 int mbb_comm_init(mbb_ctx *ctx, int nranks, int rank, const char id[128]);
 int mbb_comm_destroy(mbb_ctx *ctx);

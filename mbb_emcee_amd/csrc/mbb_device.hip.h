@@ -450,10 +450,13 @@ __device__ inline void make_walker_k(double beta, double alpha, const SedScalars
 {
     w.hokt9 = s.hokt9;
     w.lhokt9 = s.lhokt9;
-    w.beta = beta;
+    // (exponents beyond 1e80 are held there: the sample loop multiplies them by a logarithm, and the product must stay
+    // below 1e90 for its exp (mbb_math.hip.h, reduce_ln2_256) -- which gives 0, 1 or inf for such powers whatever the
+    // exponent's exact size)
+    w.beta = fmin(beta, 1.0e80);
     w.bp3 = beta + 3.0;
     w.cq = s.normfac * (s.hokt9 * s.hokt9);
-    w.alpha = NOALPHA ? 0.0 : alpha;
+    w.alpha = NOALPHA ? 0.0 : fmin(alpha, 1.0e80);
     w.lx0 = OPTHIN ? 0.0 : s.lx0;
     w.xmerge = NOALPHA ? __builtin_inf() : s.xmerge;
     w.cbb = s.normfac;

@@ -91,7 +91,9 @@ __device__ __align__(16) const double kExp2Tab[kExp2N] = {
 // n = round(x 256/ln2) as an integer, r = x - n ln2/256.  The integer comes out of a
 // SATURATING conversion (v_cvt_i32_f64), so an argument far outside exp's range needs no
 // clamp: n pins at INT_MIN / INT_MAX, ldexp by n >> 8 = -+8388608 gives 0 / inf, and r --
-// formed from the unsaturated double -- stays small.  (Rounds 2-5 rounded by adding
+// formed from the unsaturated double, off by ~1e-16 |x| there -- stays small enough for its fourth power to be
+// finite (and 1 + r + .. + r^4/24 is positive for every r) as long as |x| < 1e90, which the callers' exponents (held
+// at 1e80) times a logarithm are.  (Rounds 2-5 rounded by adding
 // 1.5 2^52 and read the integer off the mantissa: two operations instead of three, but
 // wrong beyond |x| = 5.8e6, hence a v_max and a v_min in front of every exp.)
 MBB_HD double reduce_ln2_256(double x, int &n)
