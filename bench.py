@@ -1031,7 +1031,10 @@ def worker_body(args, rank, world, local_rank, base, fail):
     if ndev <= 0:
         fail(2, error="no ROCm device on this box: the likelihood path has no CPU fall-back",
              collective="unavailable: no device")
-    if world > ndev and not (args.oversubscribe and args.exchange in ("ipc", "auto")):
+    # (ranks that share a device -- a rehearsal on one GPU -- can go through the collective library too when MBB_RCCL_LIB names
+    # one that lets them: tests/rccl_standin/, which is how the rccl exchange and the sharded boundary get rehearsed at all)
+    rccl_named = bool(os.environ.get("MBB_RCCL_LIB"))
+    if world > ndev and not (args.oversubscribe and (args.exchange in ("ipc", "auto") or rccl_named)):
         fail(2, error="%d ranks on %d device(s): RCCL needs one device per rank" % (world, ndev),
              collective="unavailable: %d ranks on %d device(s)" % (world, ndev), valid_for_scaling=False)
     like, flux = make_likelihood(local_rank % ndev)     # one GPU per rank on a real node
@@ -1063,9 +1066,11 @@ def worker_body(args, rank, world, local_rank, base, fail):
         modes.reverse()
     skipped = {}
     if world > ndev:
-        # (ranks sharing a device: no RCCL, and their one-launch kernels cannot all be resident)
-        skipped["rccl"] = {"ok": None, "why": "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev)}
-        modes = [m for m in modes if m != "rccl"]
+        # (ranks sharing a device: no RCCL -- unless a library that allows it was named --, and their one-launch kernels
+        # cannot all be resident)
+        if not rccl_named:
+            skipped["rccl"] = {"ok": None, "why": "skipped: %d ranks share %d device(s), RCCL needs a device per rank" % (world, ndev)}
+            modes = [m for m in modes if m != "rccl"]
         if not os.environ.get("MBB_BENCH_TRY_ONE_LAUNCH"):
             skipped["ipc"] = {"ok": None, "why": "skipped: ranks sharing a device cannot all keep a one-launch run resident"}
             modes = [m for m in modes if m != "ipc"]
@@ -1303,8 +1308,9 @@ def worker_body(args, rank, world, local_rank, base, fail):
                                                  "note": "eight more timed regions of the same K steps right behind the reported one"}}
                        if run.get("again") else {}),
                     **({"sampler_runs": run["runs"]} if run.get("runs") else {}),
-                    # (sharded: the counts of this rank's own walkers)
-                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt / world) / (60 + run.get("pre_steps", 0) + args.warmup + args.steps * (1 + len(run.get("again") or []))),
+                    # (sharded with the one-hop exchange: the counts of this rank's own walkers; over RCCL every rank ends up
+                    # with everybody's -- found by the first rehearsal of that leg with three ranks: 1.18)
+                    "acceptance_fraction": float(np.sum(smp.naccepted)) / (nwt if mode_used == "rccl" else nwt / world) / (60 + run.get("pre_steps", 0) + args.warmup + args.steps * (1 + len(run.get("again") or []))),
                     "ranks_agree": True})
         k_us = stream_ms * 1e3 / (2 * args.steps)       # one half-step of the dominant kernel
         form = run["form"]
@@ -1381,7 +1387,7 @@ def worker_body(args, rank, world, local_rank, base, fail):
         # the fused kernel and ONE ncclAllGather of the blocks' log-probabilities gives every rank the whole
         # vector: literally emcee's pool (mbb_fit.py:80-81) replaced.  Host arrays in and out, never `value`.
         hung = None
-        if world <= ndev and not args.no_sharded_boundary:
+        if (world <= ndev or rccl_named) and not args.no_sharded_boundary:
             if still_time():
                 try:
                     def bcast(obj):

@@ -190,6 +190,33 @@ def test_rccl_paths_with_several_ranks_on_one_gpu(world):
         assert "RCCL_RANKS_OK %d" % r in text
 
 
+def test_bench_rccl_legs_with_two_ranks_sharing_this_gpu():
+    """bench.py's two RCCL legs -- the `rccl` exchange of the device sampler (one launch per half-step + an in-place
+    all-gather of the moved rows) and `boundary_sharded`, north_star's own split (likelihood.__call__ sharded, ONE
+    all-gather of lnprob per call) -- had never run with more than one rank: real RCCL wants a device per rank.  Here
+    `python bench.py --gpus 2 --exchange rccl` end to end with the two ranks on this GPU and the collective library named
+    by MBB_RCCL_LIB (tests/rccl_standin/): the unique id's broadcast, the guarded ncclCommInitRank, the rehearsal against
+    the unsharded sampler, the timed run, the sharded boundary's loops with their bitwise check, tear-down.  The line
+    says it is a rehearsal; what is proved is bench.py's code around the collective, not RCCL."""
+    import json, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side = os.path.join(tempfile.mkdtemp(), "bench_full.json")
+    env = dict(os.environ, MBB_BENCH_WALKERS_PER_GPU="32", MBB_BENCH_FULL=side, MBB_RCCL_LIB=_standin_rccl())
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                          "--oversubscribe", "--exchange", "rccl"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] and d["value"] > 0 and d["ranks_agree"] is True, d
+    assert d["valid_for_scaling"] is False and "rehearsal" in d["config"]["note"] and len(lines[0]) < 4096
+    assert d["exchange_validation"]["rccl"] == "ok", d["exchange_validation"]
+    sb = d["boundary_sharded"]
+    assert sb["ok"] is True and sb["rows_64"] > 0 and sb["rows_32"] > 0, sb
+    full = json.load(open(side))
+    assert full["boundary_sharded"]["rows_64"]["equals_unsharded_bitwise"] is True
+    assert full["exchange_validation"]["rccl"]["kernel_form"] == 1
+
+
 def test_a_named_rccl_library_that_does_not_load_is_an_error(mbb, g_lnl):
     """MBB_RCCL_LIB is not a search path: a name that does not load fails the call that needs the communicator (in a
     child process: the library resolves RCCL once per process)."""
