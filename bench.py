@@ -658,11 +658,11 @@ def short_line(full):
     b = full.get("boundary_M1")
     if isinstance(b, dict):
         o = _pick(b, ("rows", "p50_us", "p90_us", "p99_us", "max_us", "evals_per_s", "calls", "slow_calls", "slow_runs",
-                      "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes",
+                      "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes", "serve_rests",
                       "launch_per_call_p50_us", "two_processes_p50_us"), 5)
         if isinstance(b.get("last_leg"), dict):
             o["last_leg"] = _pick(b["last_leg"], ("median_us", "p90_us", "p99_us", "max_us", "slow_calls", "slow_runs",
-                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes"), 5)
+                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes", "serve_rests"), 5)
         out["boundary_M1"] = o
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -1523,7 +1523,7 @@ def boundary_loop(like, ctx, p, n, ncalls=400, warm=50):
     calls were slow and what the library's serve counters moved by over exactly these calls."""
     for _ in range(warm):
         like(p)
-    names = ("serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes")
+    names = ("serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes", "serve_rests")
     before = [ctx.info(k) for k in names]
     ts = np.empty(ncalls)
     clock = time.perf_counter
@@ -1578,7 +1578,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
     out["boundary_M1"] = {"rows": half, "p50_us": b125["median_us"], "p90_us": b125["p90_us"],
                           "evals_per_s": b125["evals_per_s"],
                           **{k: b125[k] for k in ("p99_us", "max_us", "calls", "slow_calls", "slow_runs", "serve_requests",
-                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes")},
+                                                  "serve_fallbacks", "serve_lease_yields", "serve_resizes", "serve_rests")},
                           "launch_per_call_p50_us": bnd["launch_per_call"]["rows_%d" % half]["median_us"],
                           "what": "synchronous likelihood.__call__(float64[125, 5]) -> float64[125], host arrays in and out, in a "
                                   "loop of calls (the rows are served by a kernel resident between the calls); slow_calls: "
@@ -1780,7 +1780,7 @@ def extras(args, like, flux, ctx, allw, k_us, kern_label, nq, nb, form=1, pairs=
         again = boundary_loop(like, ctx, np.ascontiguousarray(pos[:half]), half)
         if isinstance(out.get("boundary_M1"), dict):
             out["boundary_M1"]["last_leg"] = {k: again[k] for k in ("median_us", "p90_us", "p99_us", "max_us", "slow_calls", "slow_runs",
-                                                                     "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes")}
+                                                                     "serve_requests", "serve_fallbacks", "serve_lease_yields", "serve_resizes", "serve_rests")}
         out["boundary"]["last_leg_rows_%d" % half] = again
     except Exception as e:      # noqa -- a side leg
         out["boundary"]["last_leg_error"] = repr(e)

@@ -220,7 +220,7 @@ int mbb_event_destroy(mbb_ctx *ctx, void *ev);
  * answered 256 requests: likelihoods used in turns do not spend their time starting and stopping kernels), tells it to
  * leave first; it leaves by itself "serve_idle_us" (1000) after the last request; a request
  * whose results do not appear within "serve_budget_us" (400) is evaluated by a launch instead and three such in a row
- * switch the feature off.  A server holds a CU per workgroup, and nothing of another PROCESS fits on those (emcee's pool,
+ * rest the feature for the next 4096 boundary calls (mbb_get_info "serve_rests": how often, "serve_resting": calls left).  A server holds a CU per workgroup, and nothing of another PROCESS fits on those (emcee's pool,
  * mbb_fit.py:80-81 with threads > 1): so it is as wide as the calls have rows (in eights; "serve_grid" > 0: that many
  * workgroups; mbb_get_info "serve_grid": the resident one's) and no wider than this process's share of the device -- the CUs
  * divided (in whole rows of the 8 XCDs) by the processes of this library that are making boundary calls on it right now (a table in POSIX shared memory

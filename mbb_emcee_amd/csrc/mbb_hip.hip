@@ -219,7 +219,8 @@ struct mbb_ctx {
                                               // opt_serve_after once a server has answered 256 requests: two likelihoods used
                                               // in turns must not spend their time starting and stopping kernels
     long srv_run = 0;                         // requests the present server has answered
-    int srv_strikes = 0;                      // servers that had to be given up in a row; three switch the feature off
+    int srv_strikes = 0;                      // servers that had to be given up in a row; three rest the feature
+    long srv_rest = 0, srv_rests = 0;         // boundary calls the feature still rests for; how often it has had to
     long srv_requests = 0, srv_fallbacks = 0;
     long opt_serve = 1;                       // 0: every boundary call is a launch; 2: a server even beside other contexts (tests)
     long opt_serve_after = 3;                 // boundary calls in a row before a server is started
@@ -798,6 +799,7 @@ static bool lookahead_plan(const mbb_ctx *c, int movers, int threads, int half, 
 }
 
 constexpr long kFlowStrikes = 3, kFlowRest = 16;
+constexpr long kServeRest = 4096;            // boundary calls the served path rests for after three lost servers in a row
 static std::atomic<unsigned long long> g_flow_serial{0};   // one-launch sampler runs started in this process (their check words)
 
 struct SamplerLaunch {
@@ -1397,10 +1399,15 @@ static int serve_request(mbb_ctx *c, int n, int grid)
     // the records did not turn: the server had left when the request came (it says so: nothing wrong, the sampler's
     // calls were further apart than its patience), or it was leaving, or it is not resident.  It is told to go, waited
     // for, and the rows go by a launch; three requests in a row lost to a server that had NOT said it was gone, and
-    // the feature rests for the life of the context.
+    // the feature rests for the next kServeRest boundary calls (rounds 4-5: for the life of the context -- one bad
+    // stretch on a shared box, and a sampler's every later call was a launch; the sampler forms rest the same way).
     ++c->srv_fallbacks;
     c->srv_hot = 0;
-    if (__atomic_load_n(c->h_gone, __ATOMIC_ACQUIRE) == 0 && ++c->srv_strikes >= 3) c->opt_serve = 0;
+    if (__atomic_load_n(c->h_gone, __ATOMIC_ACQUIRE) == 0 && ++c->srv_strikes >= 3) {
+        c->srv_strikes = 0;
+        c->srv_rest = kServeRest;
+        ++c->srv_rests;
+    }
     int rc = serve_stop(c);
     return rc ? rc : 1;
 }
@@ -1426,6 +1433,7 @@ extern "C" int mbb_lnlike_call(mbb_ctx *c, int n)
     // host path is the default one.  One server per device and process: whichever context comes to the device tells a
     // sibling's to leave first (use(), and the line below).
     bool can_serve = c->opt_serve && push && n <= kServePasses * c->cu_count && c->nsrc <= 1 && c->opt_spin == 2 && c->data_nb == c->nb;
+    if (c->srv_rest > 0) { --c->srv_rest; can_serve = false; }      // (resting after three lost servers in a row)
     // ... and across PROCESSES (emcee's pool, mbb_fit.py:80-81 threads > 1: the likelihood pickled into workers that share the
     // GPU): a server holds a CU per workgroup, and nothing of another process fits on those -- with round 4's server on every
     // CU one worker's call waited 42 ms for the other's whole loop (profiles/r05/pool_two_processes_before.txt).  So a server is
@@ -2349,7 +2357,7 @@ extern "C" int mbb_set_option(mbb_ctx *c, const char *name, long value)
     else if (!strcmp(name, "bar_params")) c->opt_bar_params = value;
     else if (!strcmp(name, "launch_api")) c->opt_launch_api = value;
     else if (!strcmp(name, "serve_overlap")) c->opt_serve_overlap = value;
-    else if (!strcmp(name, "serve")) { c->opt_serve = value; c->srv_strikes = 0; }
+    else if (!strcmp(name, "serve")) { c->opt_serve = value; c->srv_strikes = 0; c->srv_rest = 0; }
     else if (!strcmp(name, "serve_after")) { c->opt_serve_after = value < 1 ? 1 : value; c->srv_need = 0; }
     else if (!strcmp(name, "serve_idle_us")) c->opt_serve_idle_us = value;
     else if (!strcmp(name, "serve_budget_us")) c->opt_serve_budget_us = value < 1 ? 1 : value;
@@ -2391,6 +2399,8 @@ extern "C" int mbb_get_info(mbb_ctx *c, const char *name, long *value)
     else if (!strcmp(name, "device_peers")) *value = mbbh::registry_peers(c->reg_key, true);
     else if (!strcmp(name, "serve_peer_yields")) *value = c->srv_peer_yields;
     else if (!strcmp(name, "serve_resizes")) *value = c->srv_resizes;
+    else if (!strcmp(name, "serve_rests")) *value = c->srv_rests;
+    else if (!strcmp(name, "serve_resting")) *value = c->srv_rest;
     else if (!strcmp(name, "device_busy")) *value = c->srv_busy;
     else if (!strcmp(name, "serve_grid")) *value = c->serving ? c->srv_grid : 0;
     else if (!strcmp(name, "serve_lease_yields")) *value = c->srv_lease_yields;

@@ -53,7 +53,7 @@ def main():
            "p50_us": float(np.median(ts) * 1e6), "p99_us": float(np.percentile(ts, 99) * 1e6), "max_us": float(ts.max() * 1e6),
            "calls_over_1ms": int((ts > 1e-3).sum()), "calls_over_100us": int((ts > 1e-4).sum()),
            "serve_requests": ctx.info("serve_requests"), "serve_fallbacks": ctx.info("serve_fallbacks"),
-           "serve_enabled_at_end": ctx.info("serve_enabled"), "serving_at_end": ctx.info("serving"),
+           "serve_enabled_at_end": ctx.info("serve_enabled"), "serve_rests": ctx.info("serve_rests"), "serving_at_end": ctx.info("serving"),
            "serve_peer_yields": ctx.info("serve_peer_yields") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "serve_grid_at_end": ctx.info("serve_grid") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,
            "serve_resizes": ctx.info("serve_resizes") if os.environ.get("MBB_POOL_HAS_PEERS_INFO") else None,

@@ -1504,7 +1504,7 @@ def test_two_threads_two_likelihoods_one_device(mbb, g_lnl):
     assert bad == [] and len(done) == 2, bad[:5]
     assert time.time() - t0 < 60
     ca, cb = a._sync_device(), b._sync_device()
-    assert ca.info("serve_enabled") == 2 and cb.info("serve_enabled") == 2
+    assert ca.info("serve_enabled") == 2 and cb.info("serve_enabled") == 2 and ca.info("serve_rests") == 0 and cb.info("serve_rests") == 0
     # (how often each was served says how the two got along; nothing is asserted about it)
     print("served requests: %d / %d, fall-backs %d / %d" % (ca.info("serve_requests"), cb.info("serve_requests"),
                                                              ca.info("serve_fallbacks"), cb.info("serve_fallbacks")))

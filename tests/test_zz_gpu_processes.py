@@ -107,7 +107,7 @@ def test_served_boundary_in_two_processes_on_one_gpu(mbb, g_lnl):
     for r in rep:
         assert r["first_ok"] and r["bad_calls"] == 0 and r["calls"] == ncalls, r
         assert r["wall_s"] < 5.0 and r["max_us"] < 20000.0, r          # nobody starved: 3000 calls take ~0.03-0.1 s
-        assert r["serve_enabled_at_end"] == 1, r                       # the feature did not strike out either
+        assert r["serve_enabled_at_end"] == 1 and r["serve_rests"] == 0, r   # the feature did not strike out either
         assert r["peers_at_start"] >= 1, r                             # (each sees the other, and this session's process)
     assert overlap > 0.0, rep                                          # (the two loops did run at the same time)
     # side by side: all but the first few calls of each were answered by its own resident kernel, 128 workgroups wide
