@@ -1798,6 +1798,44 @@ def test_wide_parameter_ranges_vs_oracle(mbb, oracle, opthin, noalpha):
     lnl_close(got, ref)                     # (a row whose root find failed would have raised)
 
 
+@pytest.mark.parametrize("opthin,noalpha", [(False, False), (False, True), (True, False), (True, True)])
+def test_table_ends_and_first_rows_vs_oracle(mbb, oracle, opthin, noalpha):
+    """Where the sample loop's tables begin and end (round 6: b(x) on [0, 48], beyond it the far branch b = x e^-x; C(y) on
+    [0, 37], y held there; row 0 of C built as y times an interpolant so that it keeps its relative accuracy down to 0):
+    temperatures of 1 to 8 K put whole passbands beyond x = 48 (fluxes down to 1e-48: never NaN), thousands of kelvin put them into the first rows (x < 1/8); lambda0 of 1 um makes y tiny everywhere
+    (row 0 of C: the flux is proportional to y), 4500 um makes it huge (C = 1).  Every band flux against the oracle at the
+    stated 1e-12, lnL likewise; -inf rows must agree."""
+    Ts = np.array([1.0, 1.2, 1.5, 2.0, 2.5, 3.0, 3.2, 3.6, 4.0, 5.0, 8.0, 150.0, 300.0, 1000.0, 5000.0])
+    l0s = np.array([1.0, 30.0, 600.0, 3000.0, 4500.0])
+    betas = np.array([0.5, 1.8, 3.5])
+    T, L0, B = (x.ravel() for x in np.meshgrid(Ts, l0s, betas, indexing="ij"))
+    n = T.size
+    pars = np.column_stack([T, B, L0, np.full(n, 2.5), np.full(n, 40.0)])
+    names = ["PACS_70um", "PACS_160um", "SPIRE_250um", "SPIRE_500um", "SCUBA2_850um", "Bolocam_1.1mm"]
+    like = mbb.likelihood(opthin=opthin, noalpha=noalpha, response=True)
+    flux = np.array([20.0, 60.0, 50.0, 25.0, 6.0, 2.0])
+    unc = 0.1 * flux + 0.2
+    like.set_phot(names, flux, unc)
+    like.set_uplim("lambda0", 5000.0)                                       # (3 x max wavelength would cut the grid short)
+    bands = [(r.wavelength, r._sedmult, r._normfac) for r in like._responses]
+    orc = oracle.OracleLikelihood(flux, unc, bands=bands, opthin=opthin, noalpha=noalpha, wavenorm=500.0,
+                                  lowlim=like.lowlims, has_uplim=[int(b) for b in like.has_uplims], uplim=like.uplims)
+    ref, rflux = orc(pars, nthreads=4, return_flux=True)
+    got = like(pars)
+    gflux = like.model_flux(pars)
+    assert not np.isnan(got).any() and not np.isnan(gflux).any()
+    assert np.array_equal(np.isneginf(got), np.isneginf(ref))
+    big = rflux > 1e-280
+    # (the far branch is the models' without alpha: with the Wien-side power law x > 48 lies beyond the merge point;
+    # their cold rows' PACS fluxes go down to 1e-48 of the normalisation here)
+    assert big.sum() > 0.9 * rflux.size and (rflux.min() < 1e-30) == bool(noalpha)
+    ferr = np.max(np.abs(gflux[big] / rflux[big] - 1.0))
+    parity_record("band flux (rel)", ferr, FLUX_RTOL)
+    assert ferr < FLUX_RTOL                                                 # SURVEY 8(c)
+    assert np.all(gflux[~big] < 1e-270)                                     # what the reference makes 0 or denormal is no larger here
+    lnl_close(got, ref)
+
+
 def test_sharded_device_sampler_equals_unsharded(mbb, g_lnl):
     """The sharded form of the device sampler (each rank moves a contiguous block of
     the half-ensemble, in-place all-gather of the state rows) is exercised on one
