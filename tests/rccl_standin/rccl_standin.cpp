@@ -94,6 +94,15 @@ const char *ncclGetErrorString(int r)
     }
 }
 
+// (a segment whose communicator was never destroyed -- a rank that died -- goes with the process that made it)
+static char g_made[16][128];
+static std::atomic<int> g_nmade{0};
+static void unlink_made()
+{
+    for (int i = 0; i < g_nmade.load() && i < 16; ++i)
+        if (g_made[i][0]) shm_unlink(g_made[i]);
+}
+
 int ncclGetUniqueId(ncclUniqueId *id)
 {
     static std::atomic<int> serial{0};
@@ -104,6 +113,9 @@ int ncclGetUniqueId(ncclUniqueId *id)
     if (fd < 0) return 2;
     if (ftruncate(fd, sizeof(Seg)) != 0) { close(fd); shm_unlink(id->internal); return 2; }
     close(fd);                  // (zero-filled: every counter starts at 0)
+    const int k = g_nmade.fetch_add(1);
+    if (k == 0) atexit(unlink_made);
+    if (k < 16) memcpy(g_made[k], id->internal, 128);
     return 0;
 }
 
@@ -120,18 +132,29 @@ int ncclCommInitRank(void **out, int nranks, ncclUniqueId id, int rank)
     Comm *c = new Comm;
     c->seg = (Seg *)m; c->n = nranks; c->rank = rank;
     memcpy(c->name, id.internal, 128);
-    if (hipMalloc((void **)&c->stage[rank], kStage) != hipSuccess) return 1;
+    auto give_up = [&](int code) {              // whatever was set up so far goes; the peers' barriers time out or see `broken`
+        c->seg->broken.store(1, std::memory_order_relaxed);
+        for (int r = 0; r < nranks; ++r)
+            if (r != rank && c->stage[r]) (void)hipIpcCloseMemHandle(c->stage[r]);
+        if (c->stage[rank]) (void)hipFree(c->stage[rank]);
+        munmap(c->seg, sizeof(Seg));
+        delete c;
+        return code;
+    };
+    if (hipMalloc((void **)&c->stage[rank], kStage) != hipSuccess) return give_up(1);
     if (nranks > 1) {
-        if (hipIpcGetMemHandle(&c->seg->handle[rank], c->stage[rank]) != hipSuccess) return 1;
+        if (hipIpcGetMemHandle(&c->seg->handle[rank], c->stage[rank]) != hipSuccess) return give_up(1);
         c->seg->ready[rank].store(1, std::memory_order_release);
         int rc = barrier(c);
-        if (rc) return rc;
+        if (rc) return give_up(rc);
         for (int r = 0; r < nranks; ++r) {
             if (r == rank) continue;
-            if (hipIpcOpenMemHandle((void **)&c->stage[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess)
-                return 1;
+            if (hipIpcOpenMemHandle((void **)&c->stage[r], c->seg->handle[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                c->stage[r] = nullptr;
+                return give_up(1);
+            }
         }
-        if ((rc = barrier(c))) return rc;
+        if ((rc = barrier(c))) return give_up(rc);
     }
     *out = c;
     return 0;
@@ -168,7 +191,11 @@ int ncclCommDestroy(void *comm)
         if (r != c->rank && c->stage[r]) (void)hipIpcCloseMemHandle(c->stage[r]);
     if (c->n > 1) (void)barrier(c);                         // (handles closed before the owner's memory goes)
     if (c->stage[c->rank]) (void)hipFree(c->stage[c->rank]);
-    if (c->rank == 0) shm_unlink(c->name);
+    if (c->rank == 0) {
+        shm_unlink(c->name);
+        for (int i = 0; i < g_nmade.load() && i < 16; ++i)
+            if (!strncmp(g_made[i], c->name, 128)) g_made[i][0] = 0;
+    }
     munmap(c->seg, sizeof(Seg));
     delete c;
     return 0;
