@@ -629,6 +629,34 @@ def test_sharded_two_ranks_gloo():
     assert "DIST_OK" in texts[0]
 
 
+def test_sharded_three_ranks_file_side_channel():
+    """The same sharding logic with THREE ranks (ragged last block, fewer rows than ranks, a -inf row in the last
+    block, a whole sharded sampler run) over the side channel the multi-process GPU tests use -- ranks started by the
+    test itself, meeting through files, no torch and no port (tests/_filecomm.py) -- and that harness's own
+    behaviour: a rank that fails ends the others' waits and the launcher reports it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _filecomm import launch
+    ok, text = launch(os.path.join(ROOT, "tests", "_filecomm_worker.py"), 3, extra_env={"OMP_NUM_THREADS": "1"}, timeout=300.0)
+    assert ok and all("FILECOMM_OK %d" % r in text for r in range(3)), text[-4000:]
+    # a rank that dies: the others are told (the abort mark), nobody waits for the timeout
+    import tempfile, textwrap, time
+    d = tempfile.mkdtemp()
+    bad = os.path.join(d, "bad_rank.py")
+    open(bad, "w").write(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        from _filecomm import FileComm
+        c = FileComm(timeout=60.0)
+        c.barrier()
+        if c.rank == 1:
+            os._exit(5)
+        c.barrier()
+    """ % os.path.join(ROOT, "tests")))
+    t0 = time.time()
+    ok, text = launch(bad, 3, timeout=120.0)
+    assert not ok and "status 5" in text and "another rank gave up" in text and time.time() - t0 < 40.0, text[-3000:]
+
+
 # ------------------------------------------------- host-only table builders (C++), sanitizers
 def _hosttables_lib():
     import _layout_checks as LC
